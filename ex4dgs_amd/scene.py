@@ -1,0 +1,285 @@
+"""Host-side inputs of the rasterizer hot path: cameras, the static+dynamic Gaussian model's
+per-timestamp getters, and the deterministic synthetic scene generator of SURVEY.md 8(d).
+
+Reference anchors (all under /root/reference, never imported at run time):
+  * camera conventions  scene/cameras.py:119-127, utils/graphics_utils.py:45-117
+  * per-frame getters   scene/c_gaussian_model.py:170-215, :330-375, utils/interpolations.py:33-93
+Pure PyTorch (plumbing for the kernels); works on CPU and on ROCm devices.
+"""
+import math
+from typing import NamedTuple
+
+import numpy as np
+import torch
+
+
+# ----------------------------------------------------------------------------------------------
+# Cameras
+# ----------------------------------------------------------------------------------------------
+def world_to_view(R, t, translate=(0.0, 0.0, 0.0), scale=1.0):
+    """utils/graphics_utils.py:45-56 (getWorld2View2): 4x4 float32 world->camera matrix."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = np.asarray(R).transpose()
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    C2W = np.linalg.inv(Rt)
+    C2W[:3, 3] = (C2W[:3, 3] + np.asarray(translate)) * scale
+    return np.linalg.inv(C2W).astype(np.float32)
+
+
+def projection_matrix(znear, zfar, fovX, fovY, cx=0.0, cy=0.0, cv=False):
+    """utils/graphics_utils.py:58-78 (centred) and :81-117 (off-centre 'CV' variant, cv=True)."""
+    tanY, tanX = math.tan(fovY / 2), math.tan(fovX / 2)
+    top, right = tanY * znear, tanX * znear
+    bottom, left = -top, -right
+    if cv:
+        dx, dy = (2 * tanX * znear) * cx, (2 * tanY * znear) * cy
+        left += dx; right += dx; top += dy; bottom += dy
+    P = torch.zeros(4, 4)
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = 1.0
+    P[2, 2] = (zfar + znear) / (zfar - znear) if cv else zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+class Camera(NamedTuple):
+    image_height: int
+    image_width: int
+    FoVx: float
+    FoVy: float
+    world_view_transform: torch.Tensor   # (W2C)^T, scene/cameras.py:119
+    full_proj_transform: torch.Tensor    # (W2C)^T P^T, :125
+    camera_center: torch.Tensor          # :126
+    timestamp: float = 0.0
+
+    def to(self, device):
+        return self._replace(world_view_transform=self.world_view_transform.to(device),
+                             full_proj_transform=self.full_proj_transform.to(device),
+                             camera_center=self.camera_center.to(device))
+
+
+def make_camera(width, height, FoVx, FoVy, R=None, T=None, znear=0.01, zfar=100.0, cxr=0.0, cyr=0.0, timestamp=0.0):
+    """Cameravideo.__init__ matrix block, scene/cameras.py:119-126 (off-centre projection iff cyr != 0)."""
+    R = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    T = np.zeros(3) if T is None else np.asarray(T, dtype=np.float64)
+    wvt = torch.tensor(world_to_view(R, T), dtype=torch.float32).transpose(0, 1)
+    proj = projection_matrix(znear, zfar, FoVx, FoVy, cxr, cyr, cv=(cyr != 0.0)).transpose(0, 1)
+    full = wvt.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+    center = wvt.inverse()[3, :3]
+    return Camera(int(height), int(width), float(FoVx), float(FoVy), wvt.contiguous(), full.contiguous(), center.contiguous(), timestamp)
+
+
+def focal_camera(width, height, focal, **kw):
+    """Pinhole camera from a focal length in pixels (tanfov = size / (2 focal))."""
+    return make_camera(width, height, 2 * math.atan(width / (2 * focal)), 2 * math.atan(height / (2 * focal)), **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# Static + keyframe-interpolated dynamic Gaussians (per-frame getters of CGaussianModel)
+# ----------------------------------------------------------------------------------------------
+def _cube_interp(y0, y1, y2, y3, d):
+    """utils/interpolations.py:81-93: Catmull-Rom Hermite; the basis is evaluated as Python doubles."""
+    h00 = 2 * d ** 3 - 3 * d ** 2 + 1
+    h10 = d ** 3 - 2 * d ** 2 + d
+    h01 = -2 * d ** 3 + 3 * d ** 2
+    h11 = d ** 3 - d ** 2
+    m_k = (y2 - y0) / 2
+    m_k1 = (y3 - y1) / 2
+    return h00 * y1 + h10 * m_k + h01 * y2 + h11 * m_k1
+
+
+def _quat_slerp(v1, v2, t):
+    """utils/interpolations.py:33-52."""
+    v1 = v1 / torch.norm(v1, dim=-1, keepdim=True)
+    v2 = v2 / torch.norm(v2, dim=-1, keepdim=True)
+    d = (v1 * v2).sum(-1, keepdim=True).clamp(-1 + 1e-4, 1 - 1e-4)
+    omega = torch.acos(d).clamp_min(1e-4)
+    s_omega = torch.sin(omega).clamp_min(1e-4)
+    p_0 = torch.sin((1 - t) * omega) / s_omega
+    p_1 = torch.sin(t * omega) / s_omega
+    p_sum = (p_0 + p_1).clamp_min(1e-4)
+    p_0 = p_0 / p_sum
+    p_1 = p_1 / p_sum
+    ret = v1 * p_0 + v2 * p_1
+    ret = torch.where(ret.abs().sum(-1, keepdim=True) > 1e-4, ret, v1)
+    return ret / ret.norm(dim=-1, keepdim=True)
+
+
+def _time_bigaussian(mean, var, t, var_min):
+    """utils/interpolations.py:55-61."""
+    m = (t - mean).min(dim=1)[0]
+    v = torch.where((t > mean).any(dim=1), var[:, 1], var[:, 0])
+    o = torch.exp(-1 * (m.pow(2) / (v.exp() + var_min / 2.36).pow(2)))
+    return torch.where((mean[:, 0] - t) * (mean[:, 1] - t) < 0, torch.ones_like(o), o)
+
+
+class DynamicGaussians:
+    """Parameter container + the five per-frame getters the rasterizer boundary consumes
+    (scene/c_gaussian_model.py:170-215, :330-375; 'cube' xyz interpolation, 'slerp' rotation).
+
+    Parameter names and shapes follow CGaussianModel: static `_xyz[Ns,3] _xyz_disp[Ns,3] _rotation[Ns,4]
+    _opacity[Ns,1] _scaling[Ns,3] _features_dc[Ns,1,3] _features_rest[Ns,15,3]`; dynamic
+    `_xyz_motion[Nd,K,3] _rotation_motion[Nd,K,4] _opacity_motion[Nd,1] _opacity_duration_center[Nd,2,1]
+    _opacity_duration_var[Nd,2,1] _scaling_motion[Nd,3] _features_dc_motion[Nd,1,3] _features_rest_motion[Nd,15,3]`.
+    """
+    PARAM_NAMES = ("_xyz", "_xyz_disp", "_rotation", "_opacity", "_scaling", "_features_dc", "_features_rest",
+                   "_xyz_motion", "_rotation_motion", "_opacity_motion", "_opacity_duration_center",
+                   "_opacity_duration_var", "_scaling_motion", "_features_dc_motion", "_features_rest_motion")
+
+    def __init__(self, params, duration=300, interval=10, time_pad=2, var_pad=3, kernel_size=0.1, sh_degree=3):
+        for n in self.PARAM_NAMES:
+            setattr(self, n, params[n])
+        self.duration = max(duration, 1)
+        self.interval = interval
+        self.time_pad = time_pad
+        self.time_shift = time_pad + interval      # c_gaussian_model.py:76,119 ('cube')
+        self.var_pad = var_pad
+        self.kernel_size = kernel_size
+        self.active_sh_degree = sh_degree
+        self.max_sh_degree = 3
+
+    @staticmethod
+    def keyframe_count(duration=300, interval=10, time_pad=2):
+        """c_gaussian_model.py:1254: ceil((duration + time_shift + 2 time_pad + 1)/interval) + 3 (35 for N3V)."""
+        return math.ceil((duration + time_pad + interval + 2 * time_pad + 1) / interval) + 3
+
+    def parameters(self):
+        return [getattr(self, n) for n in self.PARAM_NAMES]
+
+    @property
+    def num_static(self):
+        return self._xyz.shape[0]
+
+    @property
+    def num_dynamic(self):
+        return self._xyz_motion.shape[0]
+
+    def _tk(self, t):
+        t = t + self.time_shift
+        return int(t // self.interval), (t % self.interval) / self.interval
+
+    def get_xyz_at_t(self, t):
+        static = self._xyz + self._xyz_disp * t / self.duration               # :180
+        if self.num_dynamic == 0:
+            return static
+        k, d = self._tk(t)
+        y = self._xyz_motion
+        dyn = _cube_interp(y[:, k - 1, :3], y[:, k, :3], y[:, k + 1, :3], y[:, k + 2, :3], d)   # :118
+        return torch.cat([static, dyn], dim=0).contiguous()
+
+    def get_rotation_at_t(self, t):
+        if self.num_dynamic == 0:
+            return self._rotation                                             # :198 (raw, un-normalised)
+        k, d = self._tk(t)
+        y = self._rotation_motion
+        return torch.cat([self._rotation, _quat_slerp(y[:, k, :], y[:, k + 1, :], d)], dim=0).contiguous()
+
+    def get_opacity_at_t(self, t):
+        static = torch.sigmoid(self._opacity)
+        if self.num_dynamic == 0:
+            return static
+        tau = (t + self.time_shift) / self.interval                           # :364
+        o = _time_bigaussian(self._opacity_duration_center, self._opacity_duration_var, tau,
+                             var_min=self.var_pad / self.interval) * torch.sigmoid(self._opacity_motion)
+        return torch.cat([static, o], dim=0).contiguous()
+
+    def get_scaling(self):
+        if self.num_dynamic == 0:
+            return torch.exp(self._scaling)
+        return torch.exp(torch.cat([self._scaling, self._scaling_motion], dim=0))   # :335
+
+    def get_features(self):
+        s = torch.cat((self._features_dc, self._features_rest), dim=1)
+        if self.num_dynamic == 0:
+            return s
+        return torch.cat((s, torch.cat((self._features_dc_motion, self._features_rest_motion), dim=1)), dim=0).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# Synthetic scene generator; deterministic in (config, seed), generated on CPU
+# ----------------------------------------------------------------------------------------------
+class SceneConfig(NamedTuple):
+    name: str
+    P: int
+    width: int
+    height: int
+    focal: float
+    dyn_frac: float = 0.0
+    min_depth: float = 4.0
+    max_depth: float = 300.0
+    z_lo: float = 4.5
+    z_hi: float = 80.0
+    sigma_px_med: float = 2.5
+    sigma_px_logstd: float = 0.7
+    cxr: float = 0.0
+    cyr: float = 0.0
+    seed: int = 0
+
+
+CONFIGS = {
+    # BASELINE.json configs[0..4]
+    "cfg1": SceneConfig("cfg1: 256 static, 256x256", 256, 256, 256, 140.0, z_lo=4.5, z_hi=30.0, sigma_px_med=6.0, seed=1),
+    "cfg2": SceneConfig("cfg2: 100k static, 1352x1014", 100_000, 1352, 1014, 730.0, seed=2),
+    "cfg3": SceneConfig("cfg3: 1.0M static+dynamic (K=35), 1352x1014", 1_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=3),
+    "cfg4": SceneConfig("cfg4: 2.0M static+dynamic x 300 frames, 1352x1014", 2_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=4),
+    "cfg5": SceneConfig("cfg5: 1.0M deep-overlap, 2048x1088 off-centre", 1_000_000, 2048, 1088, 1100.0, min_depth=0.01,
+                        z_lo=0.5, z_hi=40.0, sigma_px_med=6.0, sigma_px_logstd=0.8, cxr=0.02, cyr=-0.01, seed=5),
+}
+
+
+def make_scene(cfg, P=None, device="cpu", duration=300):
+    """Returns (DynamicGaussians, Camera, bg[3]).  Distributions: SURVEY.md 8(d)."""
+    if isinstance(cfg, str):
+        cfg = CONFIGS[cfg]
+    P = cfg.P if P is None else P
+    g = torch.Generator().manual_seed(cfg.seed)
+    N = lambda *s: torch.randn(*s, generator=g)
+    U = lambda *s: torch.rand(*s, generator=g)
+    Nd = int(round(P * cfg.dyn_frac))
+    Ns = P - Nd
+    tanx, tany = cfg.width / (2 * cfg.focal), cfg.height / (2 * cfg.focal)
+
+    z = torch.exp(math.log(cfg.z_lo) + U(P) * (math.log(cfg.z_hi) - math.log(cfg.z_lo)))
+    x = z * tanx * (U(P) * 2.3 - 1.15)
+    y = z * tany * (U(P) * 2.3 - 1.15)
+    xyz = torch.stack([x, y, z], -1)
+    sigma_px = torch.exp(math.log(cfg.sigma_px_med) + cfg.sigma_px_logstd * N(P))
+    scale = (z * sigma_px / cfg.focal).unsqueeze(-1) * torch.exp(0.35 * N(P, 3))
+    q = torch.nn.functional.normalize(N(P, 4), dim=-1) * (1 + 0.05 * N(P, 1))
+    opacity_logit = 2.0 * N(P, 1)
+    f_dc = N(P, 1, 3)
+    f_rest = 0.15 * N(P, 15, 3)
+
+    K = DynamicGaussians.keyframe_count(duration)
+    params = dict(
+        _xyz=xyz[:Ns], _xyz_disp=(0.002 * z[:Ns]).unsqueeze(-1) * N(Ns, 3), _rotation=q[:Ns], _opacity=opacity_logit[:Ns],
+        _scaling=torch.log(scale[:Ns]), _features_dc=f_dc[:Ns], _features_rest=f_rest[:Ns])
+    zd = z[Ns:]
+    walk = torch.cumsum((0.01 * zd).view(Nd, 1, 1) * N(Nd, K, 3), dim=1)
+    rot_walk = torch.nn.functional.normalize(q[Ns:].unsqueeze(1) + torch.cumsum(0.05 * N(Nd, K, 4), dim=1), dim=-1)
+    centers = torch.sort(2 + U(Nd, 2, 1) * (K - 5), dim=1)[0]
+    params.update(
+        _xyz_motion=xyz[Ns:].unsqueeze(1) + walk, _rotation_motion=rot_walk, _opacity_motion=opacity_logit[Ns:],
+        _opacity_duration_center=centers, _opacity_duration_var=N(Nd, 2, 1), _scaling_motion=torch.log(scale[Ns:]),
+        _features_dc_motion=f_dc[Ns:], _features_rest_motion=f_rest[Ns:])
+    params = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in params.items()}
+    model = DynamicGaussians(params, duration=duration)
+    cam = focal_camera(cfg.width, cfg.height, cfg.focal, znear=0.01, zfar=100.0, cxr=cfg.cxr, cyr=cfg.cyr).to(device)
+    bg = U(3).to(device)
+    return model, cam, bg
+
+
+def upstream_grads(acc, H, W, seed=0, grad_acc_zero=True, device="cpu"):
+    """Synthetic dL/d(outputs) of SURVEY.md 8(d): grad_color ~ N(0,1), grad_depth ~ 0.1 N(0,1),
+    grad_flow = stack(acc, |N|, U) (mirrors the train.py:149-152 hook), grad_acc = 0 or N(0,1)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    gc = torch.randn(3, H, W, generator=g).to(device)
+    gd = (0.1 * torch.randn(1, H, W, generator=g)).to(device)
+    gf = torch.stack([acc.reshape(H, W).detach().to(device), torch.randn(H, W, generator=g).abs().to(device),
+                      torch.rand(H, W, generator=g).to(device)], 0)
+    ga = torch.zeros(1, H, W, device=device) if grad_acc_zero else torch.randn(1, H, W, generator=g).to(device)
+    return gc, gd, gf, ga
