@@ -1,0 +1,252 @@
+"""Host-side mirror of the reference's pybind module `diff_gaussian_rasterization_df._C`
+(submodules/diff_gaussian_rasterization_df/ext.cpp:15-19): the same three functions with the same
+positional arguments and return tuples as RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA /
+markVisible (submodules/diff_gaussian_rasterization_df/rasterize_points.cu:35-133, :135-234, :236-259),
+implemented by calling the C ABI of include/ex4d_rasterizer.h (libex4d_hip.so, hand-written HIP for
+gfx950) through ctypes.  PyTorch is only used for device memory and the current HIP stream.
+
+There is NO fallback: if the library is missing or a tensor is not on a ROCm device, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_LIB_PATH = os.path.join(_CSRC, "libex4d_hip.so")
+_lib = None
+
+NUM_CHANNELS = 3   # cuda_rasterizer/config.h:15
+
+
+class Ex4dParams(C.Structure):
+    _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("kernel_size", C.c_float), ("scale_modifier", C.c_float),
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+
+
+class GeomLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("depths", "means2D", "conic_opacity", "rgb", "cov3D", "clamped", "tiles_touched",
+                                          "depth_order", "sorted_offsets", "total")]
+
+
+class BinningLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("point_list", "tile_ids", "total")]
+
+
+class ImgLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "ranges", "total")]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forward", "ex4d_backward",
+           "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
+           "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset")
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load():
+    """dlopen libex4d_hip.so (built in-tree by ex4dgs_amd.build); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -m ex4dgs_amd.build` "
+                           "(there is no CPU / PyTorch fallback for the rasterizer)")
+    lib = C.CDLL(_LIB_PATH)
+    lib.ex4d_last_error.restype = C.c_char_p
+    lib.ex4d_target_arch.restype = C.c_char_p
+    lib.ex4d_abi_version.restype = C.c_int
+    for n in ("ex4d_backward_scratch_bytes", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes", "ex4d_backward_scratch_acc_offset"):
+        getattr(lib, n).restype = C.c_size_t
+    lib.ex4d_forward.restype = C.c_int
+    lib.ex4d_backward.restype = C.c_int
+    lib.ex4d_mark_visible.restype = C.c_int
+    lib.ex4d_forward.argtypes = ([C.POINTER(Ex4dParams)] + [C.c_void_p] * 13 + [ALLOC_FN, C.c_void_p] * 3
+                                 + [C.c_void_p] * 6 + [C.c_void_p, C.POINTER(C.c_int32)])
+    lib.ex4d_backward.argtypes = [C.POINTER(Ex4dParams), C.c_int32] + [C.c_void_p] * 32
+    lib.ex4d_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(code):
+    if code != 0:
+        raise RuntimeError(load().ex4d_last_error().decode() or f"ex4d error {code}")
+
+
+def _dev_f32(t, name, device):
+    """contiguous float32 tensor on `device` -> (tensor kept alive, pointer); empty tensor -> (None, None)
+    (the reference distinguishes absent optionals by a null data pointer, forward.cu:218,254)."""
+    if t is None or t.numel() == 0:
+        return None, None
+    if t.device != device:
+        raise RuntimeError(f"{name} must be on {device}, got {t.device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    t = t.contiguous()
+    return t, t.data_ptr()
+
+
+def _require_rocm(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the ex4dgs_amd rasterizer only runs on a ROCm GPU (no CPU fallback)")
+
+
+def _params(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug):
+    return Ex4dParams(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, int(bool(prefiltered)), int(bool(debug)))
+
+
+def _resizer(t):
+    """rasterize_points.cu:27-33 resizeFunctional: grow a torch byte tensor, hand back its data pointer."""
+    def fn(_user, nbytes):
+        t.resize_(int(nbytes))
+        return t.data_ptr()
+    return ALLOC_FN(fn)
+
+
+def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width,
+                        sh, degree, campos, prefiltered, min_depth, max_depth, debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-133): 24 positional arguments ->
+    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idx)."""
+    lib = load()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_rocm(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    geomBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
+    binningBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
+    imgBuffer = torch.empty(0, dtype=torch.uint8, device=dev)
+    if P == 0:   # rasterize_points.cu:90
+        return (0, torch.zeros(NUM_CHANNELS, H, W, **f32), torch.zeros(P, **i32), geomBuffer, binningBuffer, imgBuffer,
+                torch.zeros(1, H, W, **f32), torch.zeros(1, H, W, **f32), torch.zeros(3, H, W, **f32), torch.full((1, H, W), -1, **i32))
+    out_color = torch.empty(NUM_CHANNELS, H, W, **f32)
+    radii = torch.empty(P, **i32)
+    out_depth = torch.empty(1, H, W, **f32)
+    out_acc = torch.empty(1, H, W, **f32)
+    out_flow = torch.empty(3, H, W, **f32)
+    out_idx = torch.empty(1, H, W, **i32)
+
+    M = sh.size(1) if sh.numel() != 0 else 0     # rasterize_points.cu:92-96
+    keep = []
+    ptr = {}
+    for name, t in (("background", background), ("means3D", means3D), ("dir3D", dir3D), ("sh", sh), ("colors", colors),
+                    ("opacity", opacity), ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos), ("subpixel_offset", subpixel_offset)):
+        kt, ptr[name] = _dev_f32(t, name, dev)
+        keep.append(kt)
+    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug)
+    cbs = [_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer)]
+    num_rendered = C.c_int32(0)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        code = lib.ex4d_forward(
+            C.byref(prm), ptr["background"], ptr["means3D"], ptr["dir3D"], ptr["sh"], ptr["colors"], ptr["opacity"],
+            ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
+            ptr["subpixel_offset"], cbs[0], None, cbs[1], None, cbs[2], None,
+            out_color.data_ptr(), radii.data_ptr(), out_depth.data_ptr(), out_acc.data_ptr(), out_flow.data_ptr(), out_idx.data_ptr(),
+            C.c_void_p(stream), C.byref(num_rendered))
+    _check(code)
+    return (int(num_rendered.value), out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth, out_acc, out_flow, out_idx)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, acc_depth, acc, min_depth, max_depth,
+                                 scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size,
+                                 subpixel_offset, dL_dout_color, dL_dout_depth, dL_grad_out_flow, dL_grad_out_acc, sh, degree,
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:135-234): 30 positional arguments ->
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dflow)."""
+    lib = load()
+    _require_rocm(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    shapes = [(P, 3), (P, NUM_CHANNELS), (P, 1), (P, 3), (P, 6), (P, M, 3), (P, 3), (P, 4), (P, 3)]
+    if P == 0:   # rasterize_points.cu:189
+        return tuple(torch.zeros(*s, **f32) for s in shapes)
+    outs = [torch.empty(*s, **f32) for s in shapes]
+    keep = []
+    ptr = {}
+    for name, t in (("background", background), ("means3D", means3D), ("sh", sh), ("colors", colors), ("scales", scales),
+                    ("rotations", rotations), ("cov3D_precomp", cov3D_precomp), ("viewmatrix", viewmatrix), ("projmatrix", projmatrix),
+                    ("campos", campos), ("subpixel_offset", subpixel_offset), ("acc_depth", acc_depth), ("acc", acc),
+                    ("dL_dout_color", dL_dout_color), ("dL_dout_depth", dL_dout_depth), ("dL_grad_out_flow", dL_grad_out_flow),
+                    ("dL_grad_out_acc", dL_grad_out_acc)):
+        kt, ptr[name] = _dev_f32(t, name, dev)
+        keep.append(kt)
+    radii_c = radii.contiguous()
+    scratch = torch.empty(lib.ex4d_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, False, debug)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        code = lib.ex4d_backward(
+            C.byref(prm), C.c_int32(int(R)), ptr["background"], ptr["means3D"], radii_c.data_ptr(), ptr["sh"], ptr["colors"],
+            ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
+            ptr["subpixel_offset"], ptr["acc_depth"], ptr["acc"],
+            geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
+            ptr["dL_dout_color"], ptr["dL_dout_depth"], ptr["dL_grad_out_flow"], ptr["dL_grad_out_acc"],
+            outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(),
+            outs[5].data_ptr() if M > 0 else None, outs[6].data_ptr(), outs[7].data_ptr(), outs[8].data_ptr(),
+            scratch.data_ptr(), C.c_void_p(stream))
+    _check(code)
+    rasterize_gaussians_backward.last_scratch = scratch      # kept for parity tests (internal accumulators)
+    return tuple(outs)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix, min_depth, max_depth=3.4028234663852886e38):
+    """markVisible (rasterize_points.cu:236-259).  The reference's Python wrapper passes 4 arguments to a
+    5-argument C++ function (diff_gaussian_rasterization_df/__init__.py:207-211) and therefore cannot be
+    called; here max_depth defaults to FLT_MAX so the 4-argument call works."""
+    lib = load()
+    _require_rocm(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros(P, dtype=torch.bool, device=dev)
+    if P == 0:
+        return present
+    _, pm3 = _dev_f32(means3D, "means3D", dev)
+    m = means3D.contiguous(); v = viewmatrix.contiguous(); p = projmatrix.contiguous()
+    with torch.cuda.device(dev):
+        _check(lib.ex4d_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), C.c_float(min_depth), C.c_float(max_depth),
+                                     present.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return present
+
+
+# ---- parity-test helpers: typed views into the opaque buffers -------------------------------------
+def geom_views(geomBuffer, P):
+    lay = GeomLayout()
+    load().ex4d_geom_layout(P, C.byref(lay))
+    g = geomBuffer
+    v = lambda off, n, dt: g[off: off + n * torch.empty(0, dtype=dt).element_size()].view(dt)
+    return dict(depths=v(lay.depths, P, torch.float32), means2D=v(lay.means2D, 2 * P, torch.float32).view(P, 2),
+                conic_opacity=v(lay.conic_opacity, 4 * P, torch.float32).view(P, 4), rgb=v(lay.rgb, 3 * P, torch.float32).view(P, 3),
+                cov3D=v(lay.cov3D, 6 * P, torch.float32).view(P, 6), clamped=v(lay.clamped, P, torch.uint8),
+                tiles_touched=v(lay.tiles_touched, P, torch.int32), depth_order=v(lay.depth_order, P, torch.int32))
+
+
+def binning_views(binningBuffer, R, W, H):
+    lay = BinningLayout()
+    load().ex4d_binning_layout(R, W, H, C.byref(lay))
+    b = binningBuffer
+    return dict(point_list=b[lay.point_list: lay.point_list + 4 * R].view(torch.int32),
+                tile_ids=b[lay.tile_ids: lay.tile_ids + 4 * R].view(torch.int32))
+
+
+def img_views(imgBuffer, W, H):
+    lay = ImgLayout()
+    load().ex4d_img_layout(W, H, C.byref(lay))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    i = imgBuffer
+    return dict(final_T=i[lay.final_T: lay.final_T + 4 * W * H].view(torch.float32).view(H, W),
+                n_contrib=i[lay.n_contrib: lay.n_contrib + 4 * W * H].view(torch.int32).view(H, W),
+                ranges=i[lay.ranges: lay.ranges + 8 * T].view(torch.int32).view(T, 2))

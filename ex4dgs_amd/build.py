@@ -1,0 +1,63 @@
+"""Builds libex4d_hip.so (the C-ABI library of include/ex4d_rasterizer.h) for gfx950 with hipcc.
+
+In-tree build: objects and the .so land next to the sources (ex4dgs_amd/csrc/), so the built library
+travels with a repo snapshot.  hipcc cross-compiles without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libex4d_hip.so")
+ARCH = "gfx950"
+
+# per-file flags: the per-Gaussian preprocess must not fuse multiply-adds (bit-exact integer decisions)
+SOURCES = {
+    "ex4d_preprocess.hip": ["-ffp-contract=off"],
+    "ex4d_binning.hip": [],
+    "ex4d_composite.hip": ["-ffp-contract=fast", "-munsafe-fp-atomics"],
+    "ex4d_api.hip": [],
+}
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libex4d_hip.so cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source for gfx950 and link libex4d_hip.so.  Returns the library path."""
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "ex4d_internal.h"), os.path.join(HERE, "..", "include", "ex4d_rasterizer.h"), os.path.abspath(__file__)]
+    objs = []
+    for src, flags in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + COMMON + flags + list(extra_flags) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

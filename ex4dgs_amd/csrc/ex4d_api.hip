@@ -1,0 +1,261 @@
+// C-ABI entry points of libex4d_hip.so: scratch-buffer carving, kernel sequencing, error reporting.
+//
+// Replaces CudaRasterizer::Rasterizer::{forward, backward, markVisible}
+// (submodules/diff_gaussian_rasterization_df/cuda_rasterizer/rasterizer_impl.cu:204-363, :367-486, :143-159)
+// and the GeometryState / BinningState / ImageState::fromChunk carving (:161-200).
+#include "ex4d_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(EX4D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// auxiliary.h:296-303 (CHECK_CUDA): in debug mode synchronise after every stage and surface the error
+#define STAGE(expr, prm, stream)                                                                   \
+    do {                                                                                           \
+        HIP_TRY(expr);                                                                             \
+        if ((prm)->debug) HIP_TRY(hipStreamSynchronize(stream));                                   \
+    } while (0)
+
+struct Carver {
+    char *base; size_t off;
+    explicit Carver(void *b) : base((char *)b), off(0) {}
+    template <typename T> T *take(size_t count)
+    {
+        T *p = base ? (T *)(base + off) : nullptr;
+        off = ex4d_align_up(off + count * sizeof(T));
+        return p;
+    }
+};
+
+GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
+{
+    Carver c(buf);
+    GeomState g;
+    Ex4dGeomLayout l;
+    l.depths = c.off;         g.depths = c.take<float>(P);
+    l.means2D = c.off;        g.means2D = c.take<float2>(P);
+    l.conic_opacity = c.off;  g.conic_opacity = c.take<float4>(P);
+    l.rgb = c.off;            g.rgb = c.take<float>(3 * (size_t)P);
+    l.cov3D = c.off;          g.cov3D = c.take<float>(6 * (size_t)P);
+    l.clamped = c.off;        g.clamped = c.take<uint8_t>(P);
+    l.tiles_touched = c.off;  g.tiles_touched = c.take<uint32_t>(P);
+    l.depth_order = c.off;    g.depth_order = c.take<uint32_t>(P);
+    l.sorted_offsets = c.off; g.sorted_offsets = c.take<uint32_t>(P);
+    g.sort_keys_a = c.take<uint32_t>(P);
+    g.sort_keys_b = c.take<uint32_t>(P);
+    g.sort_vals_b = c.take<uint32_t>(P);
+    g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
+    g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
+    g.total = c.take<uint32_t>(64);       // [0] instance count, [1] prefilter violation flag
+    l.total = c.off;
+    if (lay) *lay = l;
+    if (total) *total = c.off;
+    return g;
+}
+
+BinState carve_binning(void *buf, uint32_t R, Ex4dBinningLayout *lay, size_t *total)
+{
+    Carver c(buf);
+    BinState b;
+    Ex4dBinningLayout l;
+    const size_t n = R ? R : 1;
+    l.point_list = c.off; b.point_list = c.take<uint32_t>(n);
+    l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(n);
+    b.vals_tmp = c.take<uint32_t>(n);
+    b.keys_tmp = c.take<uint32_t>(n);
+    b.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words(R));
+    l.total = c.off;
+    if (lay) *lay = l;
+    if (total) *total = c.off;
+    return b;
+}
+
+ImgState carve_img(void *buf, int W, int H, Ex4dImgLayout *lay, size_t *total)
+{
+    Carver c(buf);
+    ImgState s;
+    Ex4dImgLayout l;
+    const size_t HW = (size_t)W * H;
+    const int T = ((W + EX4D_TILE - 1) / EX4D_TILE) * ((H + EX4D_TILE - 1) / EX4D_TILE);
+    l.final_T = c.off;   s.final_T = c.take<float>(HW);
+    l.n_contrib = c.off; s.n_contrib = c.take<uint32_t>(HW);
+    l.ranges = c.off;    s.ranges = c.take<uint2>(T);
+    l.total = c.off;
+    if (lay) *lay = l;
+    if (total) *total = c.off;
+    return s;
+}
+
+// number of key bits needed for tile ids 0..T-1 (the reference's getHigherMsb over-estimates by design,
+// rasterizer_impl.cu:35-50; any bit count covering every tile id yields the identical stable order)
+int tile_bits(int T)
+{
+    int b = 1;
+    while ((1 << b) < T) b++;
+    return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ex4d_last_error(void) { return g_err; }
+int ex4d_abi_version(void) { return 1; }
+const char *ex4d_target_arch(void) { return "gfx950"; }
+
+size_t ex4d_geom_bytes(int32_t P) { size_t t; carve_geom(nullptr, P, nullptr, &t); return t; }
+size_t ex4d_binning_bytes(int32_t R, int32_t W, int32_t H) { (void)W; (void)H; size_t t; carve_binning(nullptr, (uint32_t)R, nullptr, &t); return t; }
+size_t ex4d_img_bytes(int32_t W, int32_t H) { size_t t; carve_img(nullptr, W, H, nullptr, &t); return t; }
+void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out) { carve_geom(nullptr, P, out, nullptr); }
+void ex4d_binning_layout(int32_t R, int32_t W, int32_t H, Ex4dBinningLayout *out) { (void)W; (void)H; carve_binning(nullptr, (uint32_t)R, out, nullptr); }
+void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out) { carve_img(nullptr, W, H, out, nullptr); }
+size_t ex4d_backward_scratch_bytes(int32_t P) { return ex4d_align_up((size_t)P * 16 * sizeof(float)); }
+size_t ex4d_backward_scratch_acc_offset(int32_t P) { (void)P; return 0; }
+
+int ex4d_forward(
+    const Ex4dParams *prm,
+    const float *background, const float *means3D, const float *dir3D, const float *shs, const float *colors_precomp,
+    const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *campos, const float *subpixel_offset,
+    ex4d_alloc_fn geom_alloc, void *geom_user, ex4d_alloc_fn binning_alloc, void *binning_user,
+    ex4d_alloc_fn img_alloc, void *img_user,
+    float *out_color, int32_t *radii, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx,
+    void *stream_, int32_t *num_rendered)
+{
+    g_err[0] = 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!prm || !num_rendered) return fail(EX4D_ERR_ARG, "null params");
+    const int P = prm->P, W = prm->W, H = prm->H;
+    if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
+    if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !campos)
+        return fail(EX4D_ERR_ARG, "means3D, opacities, background, viewmatrix, projmatrix, campos are required");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(EX4D_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+    if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
+        ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr))
+        return fail(EX4D_ERR_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (shs && prm->M < (prm->D + 1) * (prm->D + 1)) return fail(EX4D_ERR_ARG, "sh has fewer coefficients than the active degree needs");
+    if (!out_color || !radii || !out_depth || !out_acc || !out_flow || !out_idx) return fail(EX4D_ERR_ARG, "null output");
+    const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
+    const int T = gx * gy;
+
+    void *geom_buf = geom_alloc(geom_user, ex4d_geom_bytes(P));
+    if (!geom_buf) return fail(EX4D_ERR_ALLOC, "geometry buffer allocation failed");
+    GeomState g = carve_geom(geom_buf, P, nullptr, nullptr);
+    void *img_buf = img_alloc(img_user, ex4d_img_bytes(W, H));
+    if (!img_buf) return fail(EX4D_ERR_ALLOC, "image buffer allocation failed");
+    ImgState im = carve_img(img_buf, W, H, nullptr, nullptr);
+
+    HIP_TRY(hipMemsetAsync(g.total, 0, 2 * sizeof(uint32_t), stream));
+    // 1. per-Gaussian preprocess
+    STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                     viewmatrix, projmatrix, campos, radii, g, g.total + 1, stream), prm, stream);
+    // 2. order Gaussians by depth (stable; invisible ones last)
+    STAGE(ex4d_launch_depth_keys(P, radii, g.depths, g.sort_keys_a, g.depth_order, stream), prm, stream);
+    bool in_a = true;
+    STAGE(ex4d_radix_sort_pairs(g.sort_keys_a, g.depth_order, g.sort_keys_b, g.sort_vals_b, (uint32_t)P, 32, g.sort_hist, &in_a, stream), prm, stream);
+    // 4 passes: the result is back in the (a) pair = depth_order.  (end_bit 32 / 8 = even number of passes)
+    if (!in_a) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
+    // 3. instance offsets in depth order + total
+    STAGE(ex4d_launch_scan_tiles(P, g.tiles_touched, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.total, stream), prm, stream);
+    // 4. the one blocking read-back the reference also has (rasterizer_impl.cu:298-299)
+    uint32_t host_total[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(host_total, g.total, sizeof(host_total), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (prm->prefiltered && host_total[1])
+        return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    const uint32_t R = host_total[0];
+    if (R > 0x7FFFFFFFu) return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances");
+    *num_rendered = (int32_t)R;
+
+    void *bin_buf = binning_alloc(binning_user, ex4d_binning_bytes((int32_t)R, W, H));
+    if (!bin_buf) return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed");
+    BinState b = carve_binning(bin_buf, R, nullptr, nullptr);
+
+    // 5. emit (tile, id) instances in depth order, 6. stable sort by tile, 7. ranges
+    const int passes = (tile_bits(T) + 7) / 8;
+    uint32_t *k0 = (passes % 2 == 0) ? b.tile_ids : b.keys_tmp;   // start so that the result lands in (tile_ids, point_list)
+    uint32_t *v0 = (passes % 2 == 0) ? b.point_list : b.vals_tmp;
+    uint32_t *k1 = (passes % 2 == 0) ? b.keys_tmp : b.tile_ids;
+    uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
+    if (R > 0) {
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, radii, g.means2D, k0, v0, stream), prm, stream);
+        bool res_a = true;
+        STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);
+    }
+    STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
+    // 8. compositing
+    const float *features = colors_precomp ? colors_precomp : g.rgb;
+    STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.means2D, features, g.conic_opacity,
+                                    g.depths, dir3D, background, im.final_T, im.n_contrib,
+                                    out_color, out_depth, out_acc, out_flow, out_idx, stream), prm, stream);
+    return EX4D_OK;
+}
+
+int ex4d_backward(
+    const Ex4dParams *prm, int32_t num_rendered,
+    const float *background, const float *means3D, const int32_t *radii,
+    const float *shs, const float *colors_precomp, const float *scales, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    const float *subpixel_offset, const float *out_depth, const float *out_acc,
+    const void *geom_buffer, const void *binning_buffer, const void *img_buffer,
+    const float *dL_dout_color, const float *dL_dout_depth, const float *dL_dout_flow, const float *dL_dout_acc,
+    float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, void *bwd_scratch, void *stream_)
+{
+    g_err[0] = 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!prm) return fail(EX4D_ERR_ARG, "null params");
+    const int P = prm->P, W = prm->W, H = prm->H;
+    if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
+    if (!geom_buffer || !binning_buffer || !img_buffer || !bwd_scratch) return fail(EX4D_ERR_ARG, "null state buffer");
+    if (!dL_dout_color || !dL_dout_depth || !dL_dout_flow || !dL_dout_acc) return fail(EX4D_ERR_ARG, "null upstream gradient");
+    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh))
+        return fail(EX4D_ERR_ARG, "null gradient output");
+    GeomState g = carve_geom((void *)geom_buffer, P, nullptr, nullptr);
+    BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, nullptr, nullptr);
+    ImgState im = carve_img((void *)img_buffer, W, H, nullptr, nullptr);
+    float *acc16 = (float *)bwd_scratch;
+
+    HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+    const float *color_ptr = colors_precomp ? colors_precomp : g.rgb;            // rasterizer_impl.cu:426
+    if (num_rendered > 0)
+        STAGE(ex4d_launch_composite_bwd(*prm, im.ranges, b.point_list, subpixel_offset, background, g.means2D, g.conic_opacity,
+                                        color_ptr, g.depths, out_depth, out_acc, im.final_T, im.n_contrib,
+                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, stream), prm, stream);
+    const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;            // rasterizer_impl.cu:460
+    STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16,
+                                     dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir,
+                                     stream), prm, stream);
+    return EX4D_OK;
+}
+
+int ex4d_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                      float min_depth, float max_depth, uint8_t *present, void *stream_)
+{
+    g_err[0] = 0;
+    if (P <= 0) return EX4D_OK;
+    if (!means3D || !viewmatrix || !projmatrix || !present) return fail(EX4D_ERR_ARG, "null argument");
+    HIP_TRY(ex4d_launch_mark_visible(P, means3D, viewmatrix, projmatrix, min_depth, max_depth, present, (hipStream_t)stream_));
+    return EX4D_OK;
+}
+
+}  // extern "C"

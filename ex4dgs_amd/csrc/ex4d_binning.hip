@@ -1,0 +1,325 @@
+// Binning for gfx950: depth ordering of Gaussians, tile-instance duplication, stable radix sort by tile,
+// tile ranges.
+//
+// Replaces (CR/ = submodules/diff_gaussian_rasterization_df/cuda_rasterizer/):
+//   cub::DeviceScan::InclusiveSum      CR/rasterizer_impl.cu:295
+//   duplicateWithKeys                  CR/rasterizer_impl.cu:72-113
+//   cub::DeviceRadixSort::SortPairs    CR/rasterizer_impl.cu:321-326  (64-bit keys [tile | depth bits], 32-bit values)
+//   identifyTileRanges (+ cudaMemset)  CR/rasterizer_impl.cu:118-140, :328
+//
+// Same result, different factorisation.  The reference sorts R (= instances, ~6x the Gaussian count)
+// 96-bit pairs over 45 key bits (6 radix passes over R).  A stable sort by (tile, depth) with ties in
+// ascending Gaussian id is identical to: (1) stable-sort the P Gaussians by depth bits (ties: ascending
+// id), (2) emit their tile instances in that order, (3) stable-sort the instances by tile id alone.
+// Step (1) touches P elements (4 passes), step (3) needs only ceil(log2 T)=13..14 key bits = 2 passes
+// over R with 32-bit keys: ~5x less HBM traffic than the 6-pass 64-bit sort, bit-identical point_list.
+// All of it is integer work and HBM/latency bound; wave64 ballots give the stable in-wave ranks.
+#include "ex4d_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int to_int_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+// ---------------------------------------------------------------- depth keys
+// key = bit pattern of p_view.z for visible Gaussians (depth > min_depth >= 0 => unsigned order == numeric
+// order, the same bits the reference puts in the low key word, CR/rasterizer_impl.cu:106); invisible
+// Gaussians get 0xFFFFFFFF and end up behind every visible one.
+__global__ __launch_bounds__(256) void depth_keys_kernel(int P, const int32_t *__restrict__ radii,
+    const float *__restrict__ depths, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    keys[i] = (radii[i] > 0) ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
+    vals[i] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------- radix sort (8-bit digits, stable)
+// pass structure: histogram -> row scan -> scatter.  hist layout: [bin][block] followed by [bin] totals.
+__global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift,
+    uint32_t mask, uint32_t nblocks, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[RS_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_CHUNK;
+#pragma unroll 4
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const uint32_t i = base + it * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// one block per bin: exclusive scan of that bin's per-block counts; bin total to hist[RS_BINS*nblocks + bin]
+__global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t carry_s;
+    uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? row[i] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wave_sums[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wave_sums[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) row[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) hist[(size_t)RS_BINS * nblocks + blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
+    const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+    uint32_t n, int shift, uint32_t mask, uint32_t nblocks, const uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t digit_base[RS_BINS];     // running global position of the next item of each digit for this block
+    __shared__ uint32_t wave_cnt[4][RS_BINS];    // per-round per-wave digit counts -> exclusive offsets
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        // exclusive scan of the 256 bin totals (global digit offsets) + this block's row offset
+        const uint32_t tot = hist[(size_t)RS_BINS * nblocks + tid];
+        uint32_t x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wave_cnt[0][wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wave_cnt[0][w];
+        __syncthreads();
+        digit_base[tid] = woff + x - tot + hist[(size_t)tid * nblocks + blockIdx.x];
+    }
+    const uint32_t base = blockIdx.x * RS_CHUNK;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const uint32_t i = base + it * RS_THREADS + tid;
+        const bool valid = i < n;
+        uint32_t key = 0, val = 0, d = 0;
+        if (valid) { key = keys_in[i]; val = vals_in[i]; d = (key >> shift) & mask; }
+        // lanes of this wave holding the same digit (wave64 match via 8 ballots)
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        const uint32_t cnt = __popcll(peers);
+        wave_cnt[wave][tid & 63] = 0; wave_cnt[wave][64 + (tid & 63)] = 0; wave_cnt[wave][128 + (tid & 63)] = 0; wave_cnt[wave][192 + (tid & 63)] = 0;
+        __syncthreads();
+        if (valid && rank == 0) wave_cnt[wave][d] = cnt;
+        __syncthreads();
+        {
+            // thread tid owns digit tid: turn the 4 per-wave counts into exclusive offsets, advance digit_base
+            const uint32_t c0 = wave_cnt[0][tid], c1 = wave_cnt[1][tid], c2 = wave_cnt[2][tid], c3 = wave_cnt[3][tid];
+            const uint32_t b0 = digit_base[tid];
+            wave_cnt[0][tid] = b0; wave_cnt[1][tid] = b0 + c0; wave_cnt[2][tid] = b0 + c0 + c1; wave_cnt[3][tid] = b0 + c0 + c1 + c2;
+            digit_base[tid] = b0 + c0 + c1 + c2 + c3;
+        }
+        __syncthreads();
+        if (valid) {
+            const uint32_t pos = wave_cnt[wave][d] + rank;
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- scan of tiles_touched in depth order
+__global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint32_t *__restrict__ tiles_touched,
+    const uint32_t *__restrict__ order, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums)
+{
+    // each thread scans 8 consecutive items (blocked arrangement), then wave + block scan of the thread totals
+    __shared__ uint32_t wave_sums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * SCAN_CHUNK + threadIdx.x * 8;
+    uint32_t v[8];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int i = first + k;
+        v[k] = (i < P) ? tiles_touched[order[i]] : 0;
+        run += v[k];
+        v[k] = run;
+    }
+    uint32_t x = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wave_sums[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wave_sums[w];
+    const uint32_t excl = woff + x - run;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int i = first + k;
+        if (i < P) out[i] = excl + v[k];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + x;
+}
+
+// single block: exclusive scan of block sums in place; grand total -> *total
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(int nblocks, uint32_t *__restrict__ block_sums, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_sums[i] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wave_sums[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wave_sums[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+// ---------------------------------------------------------------- duplication
+// One lane per Gaussian (in depth order).  Small rects are written by the owning lane; rects larger than
+// a wave-width are expanded cooperatively by the whole wave (coalesced stores, no long serial tails).
+__global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
+    const int32_t *__restrict__ radii, const float2 *__restrict__ means2D,
+    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t gid = 0, off = 0, count = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (k < P) {
+        gid = order[k];
+        const int r = radii[gid];
+        if (r > 0) {
+            const float2 p = means2D[gid];
+            // getRect, CR/auxiliary.h:46-56
+            x0 = min(gx, max(0, to_int_sat((p.x - (float)r) / (float)EX4D_TILE)));
+            y0 = min(gy, max(0, to_int_sat((p.y - (float)r) / (float)EX4D_TILE)));
+            x1 = min(gx, max(0, to_int_sat((p.x + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
+            y1 = min(gy, max(0, to_int_sat((p.y + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
+            count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+            // exclusive offset = inclusive scan value of the previous element (+ its block's base)
+            off = (k == 0) ? 0u : (sorted_offsets[k - 1] + block_sums[(k - 1) / SCAN_CHUNK]);
+        }
+    }
+    const bool big = count > 32;
+    if (count > 0 && !big) {
+        uint32_t o = off;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) { tile_keys[o] = (uint32_t)(y * gx + x); vals[o] = gid; o++; }
+    }
+    uint64_t todo = __ballot(big);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t s_gid = __shfl(gid, src, 64), s_off = __shfl(off, src, 64), s_cnt = __shfl(count, src, 64);
+        const int s_x0 = __shfl(x0, src, 64), s_y0 = __shfl(y0, src, 64), s_w = __shfl(x1 - x0, src, 64);
+        for (uint32_t t = lane; t < s_cnt; t += 64) {
+            const int ty = s_y0 + (int)(t / (uint32_t)s_w), tx = s_x0 + (int)(t % (uint32_t)s_w);
+            tile_keys[s_off + t] = (uint32_t)(ty * gx + tx);
+            vals[s_off + t] = s_gid;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- tile ranges
+__global__ __launch_bounds__(256) void zero_ranges_kernel(int T, uint2 *__restrict__ ranges)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < T) ranges[i] = make_uint2(0u, 0u);
+}
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint32_t *__restrict__ tile_ids, uint2 *__restrict__ ranges)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t cur = tile_ids[i];
+    if (i == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = tile_ids[i - 1];
+        if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
+    }
+    if (i == R - 1) ranges[cur].y = R;
+}
+
+}  // namespace
+
+size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)RS_BINS * rs_num_blocks(n) + RS_BINS; }
+
+hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream)
+{
+    *result_in_a = true;
+    if (n == 0) return hipSuccess;
+    const uint32_t nb = rs_num_blocks(n);
+    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        const int nbits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const uint32_t mask = (1u << nbits) - 1u;
+        hipLaunchKernelGGL(rs_histogram_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_BINS), dim3(256), 0, stream, nb, hist);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, mask, nb, hist);
+        uint32_t *t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+        *result_in_a = !*result_in_a;
+    }
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_depth_keys(int P, const int32_t *radii, const float *depths, uint32_t *keys, uint32_t *vals, hipStream_t stream)
+{
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii, depths, keys, vals);
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_scan_tiles(int P, const uint32_t *tiles_touched, const uint32_t *order, uint32_t *sorted_offsets,
+    uint32_t *block_sums, uint32_t *total, hipStream_t stream)
+{
+    const int nb = (P + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, tiles_touched, order, sorted_offsets, block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(256), 0, stream, nb, block_sums, total);
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
+    const uint32_t *block_sums, const int32_t *radii, const float2 *means2D, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream)
+{
+    const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
+    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
+        radii, means2D, tile_keys, vals);
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream)
+{
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, ranges);
+    if (R > 0)
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, tile_ids, ranges);
+    return hipGetLastError();
+}

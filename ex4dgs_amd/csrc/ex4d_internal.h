@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units of libex4d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ex4d_rasterizer.h"
+
+#define EX4D_ALIGN 256
+
+static inline size_t ex4d_align_up(size_t x) { return (x + (EX4D_ALIGN - 1)) & ~(size_t)(EX4D_ALIGN - 1); }
+
+// Typed views over the three opaque scratch buffers (layouts reported by ex4d_*_layout()).
+struct GeomState {
+    float *depths;
+    float2 *means2D;
+    float4 *conic_opacity;
+    float *rgb;
+    float *cov3D;
+    uint8_t *clamped;
+    uint32_t *tiles_touched;
+    uint32_t *depth_order;
+    uint32_t *sorted_offsets;
+    // scratch used only inside forward (not needed by backward)
+    uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
+    uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
+    uint32_t *sort_hist;                                 // radix histogram table for the depth sort
+    uint32_t *total;                                     // [1] number of instances (device copy of num_rendered)
+};
+struct BinState {
+    uint32_t *point_list;     // final sorted Gaussian ids
+    uint32_t *tile_ids;       // final sorted tile ids
+    uint32_t *vals_tmp, *keys_tmp;   // ping-pong
+    uint32_t *sort_hist;
+};
+struct ImgState {
+    float *final_T;
+    uint32_t *n_contrib;
+    uint2 *ranges;
+};
+
+// radix sort geometry (shared by size computations and kernels)
+#define RS_THREADS 256
+#define RS_ITEMS 16                       // items per thread per block
+#define RS_CHUNK (RS_THREADS * RS_ITEMS)  // 4096 items per block
+#define RS_BINS 256
+#define SCAN_CHUNK 2048                   // items per block in the tiles_touched scan
+
+static inline uint32_t rs_num_blocks(uint32_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK; }
+
+// ---- launchers (each launches on `stream`, returns hipGetLastError()) -------------------------
+hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *scales,
+    const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
+    const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    int32_t *radii, GeomState g, uint32_t *prefilter_violation, hipStream_t stream);
+
+hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+    float min_depth, float max_depth, uint8_t *present, hipStream_t stream);
+
+hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3D, const int32_t *radii,
+    const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
+    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
+    float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, hipStream_t stream);
+
+// stable LSD radix sort of (key,value) uint32 pairs over key bits [0, end_bit); result lands in
+// (keys_out, vals_out) which must be one of the two ping-pong pairs; returns which through *result_in_a.
+hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream);
+size_t ex4d_radix_hist_words(uint32_t n);
+
+hipError_t ex4d_launch_depth_keys(int P, const int32_t *radii, const float *depths, uint32_t *keys, uint32_t *vals, hipStream_t stream);
+hipError_t ex4d_launch_scan_tiles(int P, const uint32_t *tiles_touched, const uint32_t *order, uint32_t *sorted_offsets,
+    uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
+    const uint32_t *block_sums, const int32_t *radii, const float2 *means2D, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
+hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
+
+hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
+    const float *subpixel_offset, const float2 *means2D, const float *features, const float4 *conic_opacity,
+    const float *depths, const float *dir3D, const float *bg, float *final_T, uint32_t *n_contrib,
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, hipStream_t stream);
+
+hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
+    const float *subpixel_offset, const float *bg, const float2 *means2D, const float4 *conic_opacity,
+    const float *colors, const float *depths, const float *out_depth, const float *out_acc,
+    const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
+    const float *dL_dflow, const float *dL_dacc, float *acc16, hipStream_t stream);

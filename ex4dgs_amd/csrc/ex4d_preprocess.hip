@@ -1,0 +1,560 @@
+// Per-Gaussian preprocess (forward + backward) and markVisible for gfx950.
+//
+// Replaces (reference, CR/ = submodules/diff_gaussian_rasterization_df/cuda_rasterizer/):
+//   preprocessCUDA fwd  CR/forward.cu:165-269  (+ computeCov2D :74-124, computeCov3D :128-162, SH :20-71)
+//   computeCov2DCUDA    CR/backward.cu:144-300 and preprocessCUDA bwd :372-423 (+ SH bwd :20-139, cov3D bwd :304-367)
+//   checkFrustum        CR/rasterizer_impl.cu:54-68
+//
+// This translation unit is compiled with -ffp-contract=off: every value that decides an integer
+// (cull, radius, tile rect, tiles_touched, depth key) must be bit-identical to the CPU oracle, so no
+// FMA fusion, correctly-rounded / and sqrt (hipcc default), and the reference's double promotions
+// (CR/auxiliary.h:43, :284; CR/forward.cu:112-116) are kept.  One thread per Gaussian, 256-thread
+// blocks (4 wave64); the kernels are HBM-bound (SH read / SH-grad write of 192 B per Gaussian).
+#include "ex4d_internal.h"
+
+namespace {
+
+__constant__ float kSH_C0 = 0.28209479177387814f;
+__constant__ float kSH_C1 = 0.4886025119029199f;
+__constant__ float kSH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                 -1.0925484305920792f, 0.5462742152960396f };
+__constant__ float kSH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                 -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+struct Mat3 { float m[3][3]; };   // m[col][row], GLM storage order
+
+// product with GLM's summation order: out[c][r] = a[0][r]*b[c][0] + a[1][r]*b[c][1] + a[2][r]*b[c][2]
+__device__ __forceinline__ Mat3 mul(const Mat3 &a, const Mat3 &b)
+{
+    Mat3 o;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            o.m[c][r] = a.m[0][r] * b.m[c][0] + a.m[1][r] * b.m[c][1] + a.m[2][r] * b.m[c][2];
+    return o;
+}
+__device__ __forceinline__ Mat3 transpose(const Mat3 &a)
+{
+    Mat3 o;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            o.m[c][r] = a.m[r][c];
+    return o;
+}
+__device__ __forceinline__ Mat3 from_columns(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2)
+{
+    Mat3 o;
+    o.m[0][0] = a0; o.m[0][1] = a1; o.m[0][2] = a2;
+    o.m[1][0] = b0; o.m[1][1] = b1; o.m[1][2] = b2;
+    o.m[2][0] = c0; o.m[2][1] = c1; o.m[2][2] = c2;
+    return o;
+}
+
+// float -> int with truncation, saturation and NaN -> 0 (the conversion the reference's target performs)
+__device__ __forceinline__ int to_int_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+__device__ __forceinline__ float3 xform4x3(float3 p, const float *m)
+{
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(float3 p, const float *m)
+{
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14],
+                       m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+// frustum test of CR/auxiliary.h:267-294; returns visibility, p_view and the NDC xy
+__device__ __forceinline__ bool frustum_test(float3 p, const float *vm, const float *pm, float min_depth, float max_depth,
+                                             float3 &p_view, float &ndc_x, float &ndc_y)
+{
+    float4 h = xform4x4(p, pm);
+    float inv_w = 1.0f / (h.w + 0.0000001f);
+    ndc_x = h.x * inv_w;
+    ndc_y = h.y * inv_w;
+    p_view = xform4x3(p, vm);
+    return !((p_view.z <= min_depth) || (p_view.z > max_depth) ||
+             ((double)ndc_x < -1.3 || (double)ndc_x > 1.3 || (double)ndc_y < -1.3 || (double)ndc_y > 1.3));
+}
+
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
+{
+    // CR/auxiliary.h:46-56 (float arithmetic, truncation toward zero, clamp to the tile grid)
+    x0 = min(gx, max(0, to_int_sat((px - (float)radius) / (float)EX4D_TILE)));
+    y0 = min(gy, max(0, to_int_sat((py - (float)radius) / (float)EX4D_TILE)));
+    x1 = min(gx, max(0, to_int_sat((px + (float)radius + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
+    y1 = min(gy, max(0, to_int_sat((py + (float)radius + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
+}
+
+__device__ __forceinline__ Mat3 rotation_from_quat(float r, float x, float y, float z)
+{
+    return from_columns(
+        1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+// Screen-space covariance pieces shared by forward and backward (CR/forward.cu:80-106 == CR/backward.cu:171-199)
+struct Cov2DCtx { float3 t; float txtz, tytz, limx, limy; Mat3 Wm, T, Vrk, cov; };
+__device__ __forceinline__ void cov2d_common(float3 mean, float fx, float fy, float tanx, float tany, const float *cov3D,
+                                             const float *vm, Cov2DCtx &c)
+{
+    c.t = xform4x3(mean, vm);
+    c.limx = 1.3f * tanx;
+    c.limy = 1.3f * tany;
+    c.txtz = c.t.x / c.t.z;
+    c.tytz = c.t.y / c.t.z;
+    c.t.x = fminf(c.limx, fmaxf(-c.limx, c.txtz)) * c.t.z;
+    c.t.y = fminf(c.limy, fmaxf(-c.limy, c.tytz)) * c.t.z;
+    Mat3 J = from_columns(fx / c.t.z, 0.0f, -(fx * c.t.x) / (c.t.z * c.t.z),
+                          0.0f, fy / c.t.z, -(fy * c.t.y) / (c.t.z * c.t.z),
+                          0.0f, 0.0f, 0.0f);
+    c.Wm = from_columns(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+    c.T = mul(c.Wm, J);
+    c.Vrk = from_columns(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    Mat3 Tt = transpose(c.T);
+    Mat3 Vt = transpose(c.Vrk);
+    Mat3 TV = mul(Tt, Vt);
+    c.cov = mul(TV, c.T);
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+    int P, int D, int M,
+    const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
+    const float *__restrict__ cov3D_precomp, const float *__restrict__ colors_precomp,
+    const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos,
+    int W, int H, float tanx, float tany, float fx, float fy, float kernel_size, float min_depth, float max_depth,
+    int prefiltered, uint32_t *__restrict__ prefilter_violation,
+    int32_t *__restrict__ radii, float *__restrict__ depths, float2 *__restrict__ means2D,
+    float4 *__restrict__ conic_opacity, float *__restrict__ rgb, float *__restrict__ cov3Ds,
+    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    // the 2x16 camera floats are wave-uniform: they live in SGPRs / the scalar cache
+    float vm[16], pm[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
+
+    int out_radius = 0;
+    uint32_t out_tiles = 0;
+    do {
+        const float3 p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+        float3 p_view; float ndc_x, ndc_y;
+        if (!frustum_test(p, vm, pm, min_depth, max_depth, p_view, ndc_x, ndc_y)) {
+            if (prefiltered) atomicOr(prefilter_violation, 1u);
+            break;
+        }
+        float cov3D[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            // Sigma = (S R)^T (S R), CR/forward.cu:128-162; raw (un-normalised) quaternion
+            const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+            Mat3 S = from_columns(1.0f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f);
+            S.m[0][0] = scale_modifier * scales[3 * (size_t)idx];
+            S.m[1][1] = scale_modifier * scales[3 * (size_t)idx + 1];
+            S.m[2][2] = scale_modifier * scales[3 * (size_t)idx + 2];
+            Mat3 R = rotation_from_quat(q.x, q.y, q.z, q.w);
+            Mat3 Mx = mul(S, R);
+            Mat3 Sigma = mul(transpose(Mx), Mx);
+            cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+            cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3Ds[6 * (size_t)idx + i] = cov3D[i];
+        }
+        Cov2DCtx c;
+        cov2d_common(p, fx, fy, tanx, tany, cov3D, vm, c);
+        // anti-aliasing coefficient, CR/forward.cu:112-118 (float products, double max / sqrt / compare)
+        const float det_0 = (float)fmax(1e-6, (double)(c.cov.m[0][0] * c.cov.m[1][1] - c.cov.m[0][1] * c.cov.m[0][1]));
+        const float det_1 = (float)fmax(1e-6, (double)((c.cov.m[0][0] + kernel_size) * (c.cov.m[1][1] + kernel_size) - c.cov.m[0][1] * c.cov.m[0][1]));
+        float coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+        if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = 0.0f;
+        const float ca = c.cov.m[0][0] + kernel_size, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + kernel_size;
+
+        const float det = ca * cc - cb * cb;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float3 conic = make_float3(cc * det_inv, -cb * det_inv, ca * det_inv);
+        const float mid = 0.5f * (ca + cc);
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix_x = (float)((((double)ndc_x + 1.0) * (double)W - 1.0) * 0.5);   // ndc2Pix, CR/auxiliary.h:41-44
+        const float pix_y = (float)((((double)ndc_y + 1.0) * (double)H - 1.0) * 0.5);
+        const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
+        const int ri = to_int_sat(my_radius);
+        int x0, y0, x1, y1;
+        tile_rect(pix_x, pix_y, ri, gx, gy, x0, y0, x1, y1);
+        const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+        if (area == 0) break;
+
+        if (!colors_precomp) {
+            // SH -> RGB, CR/forward.cu:20-71.  48 floats per Gaussian read as 12 x 16 B.
+            float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float x = dx / len, y = dy / len, z = dz / len;
+            const float *sh = shs + (size_t)idx * M * 3;
+            float res[3];
+            uint8_t clamp_bits = 0;
+            const int ncoef = (D + 1) * (D + 1);
+            float coefv[16][3];
+            if (M == 16) {
+                const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
+                float tmp[48];
+                const int nvec = (ncoef * 3 + 3) / 4;
+#pragma unroll
+                for (int v = 0; v < 12; v++) {
+                    if (v < nvec) { float4 t4 = sh4[v]; tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w; }
+                    else { tmp[4 * v] = tmp[4 * v + 1] = tmp[4 * v + 2] = tmp[4 * v + 3] = 0.f; }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) { coefv[k][0] = tmp[3 * k]; coefv[k][1] = tmp[3 * k + 1]; coefv[k][2] = tmp[3 * k + 2]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) coefv[k][ch] = (k < ncoef && k < M) ? sh[3 * k + ch] : 0.f;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+#define SHK(k) coefv[k][ch]
+                float result = kSH_C0 * SHK(0);
+                if (D > 0) {
+                    result = result - kSH_C1 * y * SHK(1) + kSH_C1 * z * SHK(2) - kSH_C1 * x * SHK(3);
+                    if (D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        result = result +
+                            kSH_C2[0] * xy * SHK(4) +
+                            kSH_C2[1] * yz * SHK(5) +
+                            kSH_C2[2] * (2.0f * zz - xx - yy) * SHK(6) +
+                            kSH_C2[3] * xz * SHK(7) +
+                            kSH_C2[4] * (xx - yy) * SHK(8);
+                        if (D > 2) {
+                            result = result +
+                                kSH_C3[0] * y * (3.0f * xx - yy) * SHK(9) +
+                                kSH_C3[1] * xy * z * SHK(10) +
+                                kSH_C3[2] * y * (4.0f * zz - xx - yy) * SHK(11) +
+                                kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHK(12) +
+                                kSH_C3[4] * x * (4.0f * zz - xx - yy) * SHK(13) +
+                                kSH_C3[5] * z * (xx - yy) * SHK(14) +
+                                kSH_C3[6] * x * (xx - 3.0f * yy) * SHK(15);
+                        }
+                    }
+                }
+#undef SHK
+                result += 0.5f;
+                if (result < 0) clamp_bits |= (uint8_t)(1u << ch);
+                res[ch] = fmaxf(result, 0.0f);
+            }
+            rgb[3 * (size_t)idx] = res[0]; rgb[3 * (size_t)idx + 1] = res[1]; rgb[3 * (size_t)idx + 2] = res[2];
+            clamped[idx] = clamp_bits;
+        }
+        depths[idx] = p_view.z;
+        means2D[idx] = make_float2(pix_x, pix_y);
+        conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opacities[idx] * coef);
+        out_radius = ri;
+        out_tiles = area;
+    } while (0);
+    radii[idx] = out_radius;
+    tiles_touched[idx] = out_tiles;
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
+    const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, float min_depth, float max_depth,
+    uint8_t *__restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    float vm[16], pm[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
+    const float3 p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    float3 pv; float nx, ny;
+    present[idx] = frustum_test(p, vm, pm, min_depth, max_depth, pv, nx, ny) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the per-Gaussian stage.  Fuses computeCov2DCUDA + preprocessCUDA(bwd) + the zero-fill /
+// unpack of the ten gradient tensors: every output row is written exactly once.
+// acc16[idx][0..12] are the sums produced by the compositing backward:
+//   0..2 dL_dmean2D.xyz, 3..5 dL_dconic.(x,y,w), 6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+    int P, int D, int M,
+    const float *__restrict__ means3D, const int32_t *__restrict__ radii, const float *__restrict__ shs,
+    const uint8_t *__restrict__ clamped, const float *__restrict__ scales, const float *__restrict__ rotations,
+    float scale_modifier, const float *__restrict__ cov3Ds, const float *__restrict__ viewmatrix,
+    const float *__restrict__ projmatrix, const float *__restrict__ campos,
+    float fx, float fy, float tanx, float tany, float kernel_size,
+    const float *__restrict__ acc16,
+    float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
+    float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    float g_mean2D[3] = { 0, 0, 0 }, g_color[3] = { 0, 0, 0 }, g_dir[3] = { 0, 0, 0 }, g_opacity = 0;
+    float g_mean3D[3] = { 0, 0, 0 }, g_cov[6] = { 0, 0, 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_rot[4] = { 0, 0, 0, 0 };
+    float g_sh[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
+
+    if (radii[idx] > 0) {
+        float vm[16], pm[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
+        const float4 *row = reinterpret_cast<const float4 *>(acc16 + 16 * (size_t)idx);
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        g_mean2D[0] = r0.x; g_mean2D[1] = r0.y; g_mean2D[2] = r0.z;
+        const float gA = r0.w, gB = r1.x, gC = r1.y;
+        g_opacity = r1.z;
+        g_color[0] = r1.w; g_color[1] = r2.x; g_color[2] = r2.y;
+        g_dir[0] = r2.z; g_dir[1] = r2.w; g_dir[2] = r3.x;
+
+        const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+        float cov3D[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3D[i] = cov3Ds[6 * (size_t)idx + i];
+
+        // ---- computeCov2DCUDA, CR/backward.cu:144-300 (the coef-gradient block :201-218 affects no output)
+        Cov2DCtx c;
+        cov2d_common(mean, fx, fy, tanx, tany, cov3D, vm, c);
+        const float a = c.cov.m[0][0] + kernel_size, b = c.cov.m[0][1], cc = c.cov.m[1][1] + kernel_size;
+        const float denom = a * cc - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define TT(i, j) c.T.m[i][j]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * gA + 2 * b * cc * gB + (denom - a * cc) * gC);
+            dL_dc = denom2inv * (-a * a * gC + 2 * a * b * gB + (denom - a * cc) * gA);
+            dL_db = denom2inv * 2 * (b * cc * gA - (denom + 2 * b * b) * gB + a * b * gC);
+            g_cov[0] = (TT(0,0) * TT(0,0) * dL_da + TT(0,0) * TT(1,0) * dL_db + TT(1,0) * TT(1,0) * dL_dc);
+            g_cov[3] = (TT(0,1) * TT(0,1) * dL_da + TT(0,1) * TT(1,1) * dL_db + TT(1,1) * TT(1,1) * dL_dc);
+            g_cov[5] = (TT(0,2) * TT(0,2) * dL_da + TT(0,2) * TT(1,2) * dL_db + TT(1,2) * TT(1,2) * dL_dc);
+            g_cov[1] = 2 * TT(0,0) * TT(0,1) * dL_da + (TT(0,0) * TT(1,1) + TT(0,1) * TT(1,0)) * dL_db + 2 * TT(1,0) * TT(1,1) * dL_dc;
+            g_cov[2] = 2 * TT(0,0) * TT(0,2) * dL_da + (TT(0,0) * TT(1,2) + TT(0,2) * TT(1,0)) * dL_db + 2 * TT(1,0) * TT(1,2) * dL_dc;
+            g_cov[4] = 2 * TT(0,2) * TT(0,1) * dL_da + (TT(0,1) * TT(1,2) + TT(0,2) * TT(1,1)) * dL_db + 2 * TT(1,1) * TT(1,2) * dL_dc;
+        }
+        // NOTE: the mean gradient this kernel stage produces (CR/backward.cu:261-299) is overwritten by the
+        // assignment at CR/backward.cu:414, so it is not computed here at all.
+#undef TT
+
+        // ---- preprocessCUDA (bwd), CR/backward.cu:372-423
+        const float4 m_hom = xform4x4(mean, pm);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (pm[0] * mean.x + pm[4] * mean.y + pm[8] * mean.z + pm[12]) * m_w * m_w;
+        const float mul2 = (pm[1] * mean.x + pm[5] * mean.y + pm[9] * mean.z + pm[13]) * m_w * m_w;
+        const float mul3 = (pm[2] * mean.x + pm[6] * mean.y + pm[10] * mean.z + pm[14]) * m_w * m_w;
+        const float gx = g_mean2D[0], gy = g_mean2D[1], gz = g_mean2D[2];
+        g_mean3D[0] = (pm[0] * m_w - pm[3] * mul1) * gx + (pm[1] * m_w - pm[3] * mul2) * gy + (pm[2] * m_w - pm[3] * mul3) * gz;
+        g_mean3D[1] = (pm[4] * m_w - pm[7] * mul1) * gx + (pm[5] * m_w - pm[7] * mul2) * gy + (pm[6] * m_w - pm[7] * mul3) * gz;
+        g_mean3D[2] = (pm[8] * m_w - pm[11] * mul1) * gx + (pm[9] * m_w - pm[11] * mul2) * gy + (pm[10] * m_w - pm[11] * mul3) * gz;
+
+        if (shs) {
+            // SH backward, CR/backward.cu:20-139
+            const float3 dir_orig = make_float3(mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]);
+            const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+            const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+            const float *sh = shs + (size_t)idx * M * 3;
+            const uint8_t cl = clamped[idx];
+            float dRGB[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = g_color[ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
+            float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+#define SHK(k) sh[3 * (k) + ch]
+#define DSH(k, coefexpr) { const float c_ = (coefexpr); g_sh[k][0] = c_ * dRGB[0]; g_sh[k][1] = c_ * dRGB[1]; g_sh[k][2] = c_ * dRGB[2]; }
+            DSH(0, kSH_C0)
+            if (D > 0) {
+                DSH(1, -kSH_C1 * y)
+                DSH(2, kSH_C1 * z)
+                DSH(3, -kSH_C1 * x)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] = -kSH_C1 * SHK(3);
+                    dRGBdy[ch] = -kSH_C1 * SHK(1);
+                    dRGBdz[ch] = kSH_C1 * SHK(2);
+                }
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    DSH(4, kSH_C2[0] * xy)
+                    DSH(5, kSH_C2[1] * yz)
+                    DSH(6, kSH_C2[2] * (2.f * zz - xx - yy))
+                    DSH(7, kSH_C2[3] * xz)
+                    DSH(8, kSH_C2[4] * (xx - yy))
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
+                        dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
+                        dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
+                    }
+                    if (D > 2) {
+                        DSH(9, kSH_C3[0] * y * (3.f * xx - yy))
+                        DSH(10, kSH_C3[1] * xy * z)
+                        DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy))
+                        DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy))
+                        DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy))
+                        DSH(14, kSH_C3[5] * z * (xx - yy))
+                        DSH(15, kSH_C3[6] * x * (xx - 3.f * yy))
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            dRGBdx[ch] += (
+                                kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
+                                kSH_C3[1] * SHK(10) * yz +
+                                kSH_C3[2] * SHK(11) * -2.f * xy +
+                                kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
+                                kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
+                                kSH_C3[5] * SHK(14) * 2.f * xz +
+                                kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
+                            dRGBdy[ch] += (
+                                kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
+                                kSH_C3[1] * SHK(10) * xz +
+                                kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
+                                kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
+                                kSH_C3[4] * SHK(13) * -2.f * xy +
+                                kSH_C3[5] * SHK(14) * -2.f * yz +
+                                kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
+                            dRGBdz[ch] += (
+                                kSH_C3[1] * SHK(10) * xy +
+                                kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
+                                kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
+                                kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
+                                kSH_C3[5] * SHK(14) * (xx - yy));
+                        }
+                    }
+                }
+            }
+#undef SHK
+#undef DSH
+            const float3 dL_ddirv = make_float3(
+                dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
+                dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
+                dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]);
+            // Jacobian of the direction normalisation, CR/auxiliary.h:235-245
+            const float3 v = dir_orig;
+            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float jx = ((+sum2 - v.x * v.x) * dL_ddirv.x - v.y * v.x * dL_ddirv.y - v.z * v.x * dL_ddirv.z) * invsum32;
+            const float jy = (-v.x * v.y * dL_ddirv.x + (sum2 - v.y * v.y) * dL_ddirv.y - v.z * v.y * dL_ddirv.z) * invsum32;
+            const float jz = (-v.x * v.z * dL_ddirv.x - v.y * v.z * dL_ddirv.y + (sum2 - v.z * v.z) * dL_ddirv.z) * invsum32;
+            g_mean3D[0] += jx; g_mean3D[1] += jy; g_mean3D[2] += jz;
+        }
+        if (scales) {
+            // cov3D backward, CR/backward.cu:304-367 (gradient w.r.t. the raw quaternion)
+            const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            Mat3 R = rotation_from_quat(r, x, y, z);
+            const float s[3] = { scale_modifier * scales[3 * (size_t)idx], scale_modifier * scales[3 * (size_t)idx + 1], scale_modifier * scales[3 * (size_t)idx + 2] };
+            Mat3 S = from_columns(1.0f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f);
+            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+            Mat3 Mx = mul(S, R);
+            Mat3 dSigma = from_columns(
+                g_cov[0], 0.5f * g_cov[1], 0.5f * g_cov[2],
+                0.5f * g_cov[1], g_cov[3], 0.5f * g_cov[4],
+                0.5f * g_cov[2], 0.5f * g_cov[4], g_cov[5]);
+            Mat3 M2;
+#pragma unroll
+            for (int cI = 0; cI < 3; cI++)
+#pragma unroll
+                for (int rI = 0; rI < 3; rI++) M2.m[cI][rI] = Mx.m[cI][rI] * 2.0f;
+            Mat3 dM = mul(M2, dSigma);
+            Mat3 Rt = transpose(R);
+            Mat3 dMt = transpose(dM);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                g_scale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int rI = 0; rI < 3; rI++) dMt.m[k][rI] *= s[k];
+#define DM(i, j) dMt.m[i][j]
+            g_rot[0] = 2 * z * (DM(0,1) - DM(1,0)) + 2 * y * (DM(2,0) - DM(0,2)) + 2 * x * (DM(1,2) - DM(2,1));
+            g_rot[1] = 2 * y * (DM(1,0) + DM(0,1)) + 2 * z * (DM(2,0) + DM(0,2)) + 2 * r * (DM(1,2) - DM(2,1)) - 4 * x * (DM(2,2) + DM(1,1));
+            g_rot[2] = 2 * x * (DM(1,0) + DM(0,1)) + 2 * r * (DM(2,0) - DM(0,2)) + 2 * z * (DM(1,2) + DM(2,1)) - 4 * y * (DM(2,2) + DM(0,0));
+            g_rot[3] = 2 * r * (DM(0,1) - DM(1,0)) + 2 * x * (DM(2,0) + DM(0,2)) + 2 * y * (DM(1,2) + DM(2,1)) - 4 * z * (DM(1,1) + DM(0,0));
+#undef DM
+        }
+    }
+    // every output row written exactly once (replaces the ten torch::zeros of DGR/rasterize_points.cu:178-187)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dL_dmeans2D[3 * (size_t)idx + k] = g_mean2D[k];
+        dL_dcolors[3 * (size_t)idx + k] = g_color[k];
+        dL_dmeans3D[3 * (size_t)idx + k] = g_mean3D[k];
+        dL_dscales[3 * (size_t)idx + k] = g_scale[k];
+        dL_ddir[3 * (size_t)idx + k] = g_dir[k];
+    }
+    dL_dopacity[idx] = g_opacity;
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = g_cov[k];
+    reinterpret_cast<float4 *>(dL_drotations)[idx] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]);
+    if (M == 16) {
+        float4 *o = reinterpret_cast<float4 *>(dL_dsh + (size_t)idx * 48);
+#pragma unroll
+        for (int v = 0; v < 12; v++) {
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
+            o[v] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    } else {
+        for (int k = 0; k < M; k++)
+            for (int ch = 0; ch < 3; ch++)
+                dL_dsh[((size_t)idx * M + k) * 3 + ch] = (k < 16) ? g_sh[k][ch] : 0.f;
+    }
+}
+
+}  // namespace
+
+hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *scales,
+    const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
+    const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    int32_t *radii, GeomState g, uint32_t *prefilter_violation, hipStream_t stream)
+{
+    const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
+    const float fx = prm.W / (2.0f * prm.tanfovx);
+    const int blocks = (prm.P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, stream,
+        prm.P, prm.D, prm.M, means3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
+        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
+        radii, g.depths, g.means2D, g.conic_opacity, g.rgb, g.cov3D, g.clamped, g.tiles_touched);
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+    float min_depth, float max_depth, uint8_t *present, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream,
+        P, means3D, viewmatrix, projmatrix, min_depth, max_depth, present);
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3D, const int32_t *radii,
+    const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
+    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
+    float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, hipStream_t stream)
+{
+    const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:417-418
+    const float fx = prm.W / (2.0f * prm.tanfovx);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
+        prm.P, prm.D, prm.M, means3D, radii, shs, g.clamped, scales, rotations, prm.scale_modifier, cov3D_ptr,
+        viewmatrix, projmatrix, campos, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16,
+        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir);
+    return hipGetLastError();
+}

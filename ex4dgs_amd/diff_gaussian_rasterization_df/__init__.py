@@ -1,0 +1,123 @@
+"""Drop-in for the reference's Python operator surface
+(submodules/diff_gaussian_rasterization_df/diff_gaussian_rasterization_df/__init__.py):
+
+  GaussianRasterizationSettings  -- NamedTuple, same 16 fields in the same order (:180-196)
+  GaussianRasterizer             -- nn.Module, same forward(...) keywords and return tuple (:198-251)
+  rasterize_gaussians / _RasterizeGaussians -- autograd.Function with the same 10 inputs, 6 outputs and
+                                    gradient routing (:22-178)
+
+so that gaussian_renderer.render(), train.py and render.py of the reference run unchanged with
+`ex4dgs_amd/` on sys.path.  The native layer underneath is ex4dgs_amd._C (ctypes -> libex4d_hip.so).
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from .. import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    subpixel_offset: torch.Tensor
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    min_depth: float
+    max_depth: float
+    debug: bool
+
+
+def _snapshot(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_native(fn, args, debug, dump_name, what):
+    """Debug mode keeps a CPU copy of the inputs and dumps it if the native call throws (reference :92-99, :152-159)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print(f"\nAn error occured in {what}. Inputs written to {dump_name} for debugging.\n")
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        s = raster_settings
+        # positional order of RasterizeGaussiansCUDA (rasterize_points.cu:36-60)
+        args = (s.bg, means3D, dir3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
+                s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size, s.subpixel_offset,
+                s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered, s.min_depth, s.max_depth, s.debug)
+        (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idxs) = _call_native(
+            _C.rasterize_gaussians, args, s.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = s
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              geomBuffer, binningBuffer, imgBuffer, depth, acc, flow)
+        ctx.mark_non_differentiable(radii, idxs)
+        return color, radii, depth, flow, acc, idxs
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, grad_out_depth, grad_out_flow, grad_out_acc, _grad_idx):
+        s = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+         geomBuffer, binningBuffer, imgBuffer, depth, acc, _flow) = ctx.saved_tensors
+        # positional order of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:136-166)
+        args = (s.bg, means3D, radii, colors_precomp, scales, rotations, depth, acc, s.min_depth, s.max_depth,
+                s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size,
+                s.subpixel_offset, grad_out_color, grad_out_depth, grad_out_flow, grad_out_acc, sh, s.sh_degree, s.campos,
+                geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+         grad_scales, grad_rotations, grad_dir3D) = _call_native(
+            _C.rasterize_gaussians_backward, args, s.debug, "snapshot_bw.dump", "backward")
+        # one gradient per forward input, in input order (reference :165-176)
+        return (grad_means3D, grad_means2D, grad_dir3D, grad_sh, grad_colors_precomp, grad_opacities,
+                grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean frustum-visibility mask (reference :203-213)."""
+        s = self.raster_settings
+        with torch.no_grad():
+            return _C.mark_visible(positions, s.viewmatrix, s.projmatrix, s.min_depth, s.max_depth)
+
+    def forward(self, means3D, means2D, dir3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+           ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        # absent optionals travel as empty CPU tensors, exactly like the reference (:225-237)
+        empty = lambda: torch.Tensor([])
+        shs = empty() if shs is None else shs
+        colors_precomp = empty() if colors_precomp is None else colors_precomp
+        scales = empty() if scales is None else scales
+        rotations = empty() if rotations is None else rotations
+        cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
+        dir3D = empty() if dir3D is None else dir3D
+        return rasterize_gaussians(means3D, means2D, dir3D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)

@@ -1,0 +1,169 @@
+/*
+ * ex4d_rasterizer.h -- C ABI of the MI355X-native (gfx950) differentiable 4D-Gaussian rasterizer.
+ *
+ * Drop-in boundary for the reference's native layer
+ *   CudaRasterizer::Rasterizer::{forward, backward, markVisible}
+ *     (submodules/diff_gaussian_rasterization_df/cuda_rasterizer/rasterizer.h:20-106)
+ * as it is driven by the torch binding
+ *   RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible
+ *     (submodules/diff_gaussian_rasterization_df/rasterize_points.cu:35-133, :135-234, :236-259).
+ *
+ * Plain pointers and sizes only: every pointer is a DEVICE pointer of the current HIP device unless
+ * stated otherwise; `stream` is a hipStream_t passed as void* (0 = null stream).  Optional inputs
+ * are passed as NULL (the reference uses "empty tensor => null data pointer",
+ * cuda_rasterizer/forward.cu:218,254).  All matrices use the reference's memory convention
+ * mem[c*4+r] = M[r][c] (cuda_rasterizer/auxiliary.h:68-87).
+ *
+ * The three scratch buffers (geometry / binning / image state) are opaque to the caller, exactly as
+ * in the reference (rasterizer_impl.h:29-65); the caller owns their storage and provides it through
+ * the allocation callbacks (reference: std::function<char*(size_t)>, rasterize_points.cu:27-33).
+ * Their INTERNAL layout is this library's own (ex4d_*_layout below reports it for tests).
+ */
+#ifndef EX4D_RASTERIZER_H_INCLUDED
+#define EX4D_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EX4D_TILE 16          /* cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y): part of the parity contract */
+#define EX4D_CHANNELS 3       /* cuda_rasterizer/config.h:15 */
+
+/* Scalar arguments of Rasterizer::forward / ::backward (rasterizer.h:33-67, :69-104). */
+typedef struct Ex4dParams {
+    int32_t P;                /* number of Gaussians (means3D.size(0)) */
+    int32_t D;                /* active SH degree */
+    int32_t M;                /* SH coefficients stored per Gaussian per channel (sh.size(1)), 0 if no SH */
+    int32_t W, H;             /* image width / height */
+    float tanfovx, tanfovy;
+    float kernel_size;        /* 2D mip filter added to the screen-space covariance */
+    float scale_modifier;
+    float min_depth, max_depth;
+    int32_t prefiltered;      /* reference traps on a culled Gaussian when set; here: error EX4D_ERR_PREFILTERED */
+    int32_t debug;            /* synchronise + check after every kernel (auxiliary.h:296-303) */
+} Ex4dParams;
+
+/* Scratch allocation callback: must return a device pointer to at least `bytes` bytes, 256-byte aligned,
+ * that stays valid until the matching backward has run (the reference resizes a torch byte tensor). */
+typedef void *(*ex4d_alloc_fn)(void *user, size_t bytes);
+
+enum {
+    EX4D_OK = 0,
+    EX4D_ERR_ARG = 1,          /* bad argument (shape/NULL/colour source), std::runtime_error in the reference */
+    EX4D_ERR_HIP = 2,          /* a HIP runtime call or kernel failed */
+    EX4D_ERR_ALLOC = 3,        /* allocation callback returned NULL */
+    EX4D_ERR_PREFILTERED = 4   /* prefiltered=1 but a Gaussian was culled (auxiliary.h:286-290 traps) */
+};
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *ex4d_last_error(void);
+
+/* Library/ABI version and the gfx target the kernels were compiled for (e.g. "gfx950"). */
+int ex4d_abi_version(void);
+const char *ex4d_target_arch(void);
+
+/*
+ * Forward: replaces CudaRasterizer::Rasterizer::forward (rasterizer_impl.cu:204-363).
+ * Outputs follow rasterize_points.cu:73-78: out_color[3,H,W], radii[P] (int32), out_depth[1,H,W],
+ * out_acc[1,H,W], out_flow[3,H,W], out_idx[1,H,W] (int32); all are fully written by the call
+ * (no pre-initialisation needed; out_idx = -1 where nothing contributed).
+ * *num_rendered receives the number of (Gaussian, tile) instances (host int, one blocking 4-byte D2H
+ * exactly like rasterizer_impl.cu:298-299).  P == 0 is handled by the caller (rasterize_points.cu:90).
+ */
+int ex4d_forward(
+    const Ex4dParams *prm,
+    const float *background,      /* [3] */
+    const float *means3D,         /* [P,3] */
+    const float *dir3D,           /* [P,3] per-Gaussian "flow" channel composited into out_flow; NULL = zeros */
+    const float *shs,             /* [P,M,3] or NULL */
+    const float *colors_precomp,  /* [P,3] or NULL (exactly one of shs / colors_precomp) */
+    const float *opacities,       /* [P] */
+    const float *scales,          /* [P,3] or NULL */
+    const float *rotations,       /* [P,4] (r,x,y,z), NOT normalised (forward.cu:137), or NULL */
+    const float *cov3D_precomp,   /* [P,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
+    const float *viewmatrix,      /* [16] */
+    const float *projmatrix,      /* [16] */
+    const float *campos,          /* [3] */
+    const float *subpixel_offset, /* [H,W,2] or NULL = zeros */
+    ex4d_alloc_fn geom_alloc, void *geom_user,
+    ex4d_alloc_fn binning_alloc, void *binning_user,
+    ex4d_alloc_fn img_alloc, void *img_user,
+    float *out_color, int32_t *radii, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx,
+    void *stream,
+    int32_t *num_rendered);
+
+/*
+ * Backward: replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:367-486) including the
+ * zero-fill of the ten gradient tensors (rasterize_points.cu:178-187): every output below is fully
+ * written for all P Gaussians (zeros for invisible ones), so the caller may pass uninitialised memory.
+ * `bwd_scratch` must hold ex4d_backward_scratch_bytes(P) bytes (internal per-Gaussian accumulators,
+ * the reference's dL_dconic[P,2,2] among them).
+ * Reference-specific semantics reproduced exactly: dL_dopacity is w.r.t. opacity*coef,
+ * dL_dmeans3D = projection path + SH path only (backward.cu:414 overwrites the covariance path), etc.
+ */
+int ex4d_backward(
+    const Ex4dParams *prm, int32_t num_rendered,
+    const float *background, const float *means3D, const int32_t *radii,
+    const float *shs, const float *colors_precomp, const float *scales, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    const float *subpixel_offset,
+    const float *out_depth, const float *out_acc,            /* forward outputs [1,H,W] */
+    const void *geom_buffer, const void *binning_buffer, const void *img_buffer,
+    const float *dL_dout_color /*[3,H,W]*/, const float *dL_dout_depth /*[1,H,W]*/,
+    const float *dL_dout_flow /*[3,H,W]*/, const float *dL_dout_acc /*[1,H,W]*/,
+    float *dL_dmeans2D /*[P,3]*/, float *dL_dcolors /*[P,3]*/, float *dL_dopacity /*[P,1]*/,
+    float *dL_dmeans3D /*[P,3]*/, float *dL_dcov3D /*[P,6]*/, float *dL_dsh /*[P,M,3]*/,
+    float *dL_dscales /*[P,3]*/, float *dL_drotations /*[P,4]*/, float *dL_ddir /*[P,3]*/,
+    void *bwd_scratch,
+    void *stream);
+
+size_t ex4d_backward_scratch_bytes(int32_t P);
+
+/* markVisible: replaces Rasterizer::markVisible (rasterizer_impl.cu:143-159); present[P] bytes (0/1). */
+int ex4d_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                      float min_depth, float max_depth, uint8_t *present, void *stream);
+
+/* Sizes the allocation callbacks will be asked for (rasterizer_impl.h required<T>(N) equivalent). */
+size_t ex4d_geom_bytes(int32_t P);
+size_t ex4d_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
+size_t ex4d_img_bytes(int32_t W, int32_t H);
+
+/* Byte offsets of the internal arrays inside the opaque buffers -- for parity tests only.
+ * (reference counterparts: GeometryState / BinningState / ImageState, rasterizer_impl.h:29-65) */
+typedef struct Ex4dGeomLayout {
+    size_t depths;          /* float[P]            p_view.z */
+    size_t means2D;         /* float2[P]           pixel-space mean */
+    size_t conic_opacity;   /* float4[P]           (conic.x, conic.y, conic.z, opacity*coef) */
+    size_t rgb;             /* float[3P]           SH colour (unused when colors_precomp given) */
+    size_t cov3D;           /* float[6P] */
+    size_t clamped;         /* uint8[P]            bit c set <=> channel c clamped at 0 (forward.cu:67-69) */
+    size_t tiles_touched;   /* uint32[P] */
+    size_t depth_order;     /* uint32[P]           Gaussian ids, stable-sorted by depth key (visible first) */
+    size_t sorted_offsets;  /* uint32[P]           inclusive scan of tiles_touched in depth order */
+    size_t total;
+} Ex4dGeomLayout;
+typedef struct Ex4dBinningLayout {
+    size_t point_list;      /* uint32[R]           Gaussian ids sorted by (tile, depth, id): == reference point_list */
+    size_t tile_ids;        /* uint32[R]           tile id of every sorted instance (high word of the reference key) */
+    size_t total;
+} Ex4dBinningLayout;
+typedef struct Ex4dImgLayout {
+    size_t final_T;         /* float[H*W]          reference accum_alpha */
+    size_t n_contrib;       /* uint32[H*W] */
+    size_t ranges;          /* uint2[T] */
+    size_t total;
+} Ex4dImgLayout;
+void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out);
+void ex4d_binning_layout(int32_t num_rendered, int32_t W, int32_t H, Ex4dBinningLayout *out);
+void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
+/* offset of the packed per-Gaussian accumulator rows (float[P][16]) inside bwd_scratch:
+ * 0..2 dL_dmean2D.xyz, 3..5 dL_dconic.(x,y,w), 6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir */
+size_t ex4d_backward_scratch_acc_offset(int32_t P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

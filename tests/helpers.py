@@ -1,0 +1,172 @@
+"""Shared helpers of the parity tests: build rasterizer inputs from a synthetic scene, run the CPU oracle
+and the HIP path on the same inputs, compare with the tolerances of BASELINE.json's north_star
+(bit-exact integers / 1e-5 max-abs floats, threshold-flip aware)."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ex4dgs_amd.scene import make_scene, upstream_grads, CONFIGS, SceneConfig   # noqa: E402
+
+
+def scene_inputs(cfg, P=None, t=0, sh_degree=3, dir_scale=0.1, device="cpu", seed=11):
+    """dict of rasterizer inputs (torch tensors on `device`) + settings kwargs for the oracle."""
+    model, cam, bg = make_scene(cfg, P=P)
+    model.active_sh_degree = sh_degree
+    cfgv = CONFIGS[cfg] if isinstance(cfg, str) else cfg
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        ins = dict(means3D=model.get_xyz_at_t(t), rotations=model.get_rotation_at_t(t), opacities=model.get_opacity_at_t(t),
+                   scales=model.get_scaling(), shs=model.get_features())
+    ins["dir3D"] = dir_scale * torch.randn(ins["means3D"].shape, generator=g)
+    ins = {k: v.to(device).contiguous() for k, v in ins.items()}
+    H, W = cam.image_height, cam.image_width
+    settings = dict(bg=bg.to(device), viewmatrix=cam.world_view_transform.to(device), projmatrix=cam.full_proj_transform.to(device),
+                    campos=cam.camera_center.to(device), image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                    tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=0.1, sh_degree=sh_degree, min_depth=cfgv.min_depth,
+                    max_depth=cfgv.max_depth, scale_modifier=1.0, prefiltered=False)
+    return ins, settings
+
+
+def oracle_forward(ins, settings, **over):
+    from oracle import oracle
+    kw = dict(settings); kw.update(over)
+    opt = {k: ins.get(k) for k in ("shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")}
+    return oracle.forward(ins["means3D"], ins.get("dir3D"), ins["opacities"], **opt, **kw)
+
+
+def gpu_settings(settings, device, subpixel_offset=None, debug=False):
+    from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSettings
+    H, W = settings["image_height"], settings["image_width"]
+    sub = torch.zeros(H, W, 2, device=device) if subpixel_offset is None else subpixel_offset.to(device)
+    return GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=settings["tanfovx"], tanfovy=settings["tanfovy"], kernel_size=settings["kernel_size"],
+        subpixel_offset=sub, bg=settings["bg"].to(device), scale_modifier=settings["scale_modifier"],
+        viewmatrix=settings["viewmatrix"].to(device), projmatrix=settings["projmatrix"].to(device), sh_degree=settings["sh_degree"],
+        campos=settings["campos"].to(device), prefiltered=settings["prefiltered"], min_depth=settings["min_depth"],
+        max_depth=settings["max_depth"], debug=debug)
+
+
+def gpu_forward_raw(ins, settings, device="cuda", subpixel_offset=None):
+    """Calls the `_C` mirror directly (no autograd) and returns outputs + typed views of the opaque buffers."""
+    from ex4dgs_amd import _C
+    s = gpu_settings(settings, device, subpixel_offset)
+    e = torch.Tensor([])
+    d = lambda k: ins[k].to(device) if ins.get(k) is not None else e
+    out = _C.rasterize_gaussians(s.bg, d("means3D"), d("dir3D"), d("colors_precomp"), d("opacities"), d("scales"), d("rotations"),
+                                 s.scale_modifier, d("cov3D_precomp"), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size,
+                                 s.subpixel_offset, s.image_height, s.image_width, d("shs"), s.sh_degree, s.campos, s.prefiltered,
+                                 s.min_depth, s.max_depth, s.debug)
+    R, color, radii, geom, binning, img, depth, acc, flow, idx = out
+    P, H, W = ins["means3D"].shape[0], s.image_height, s.image_width
+    res = dict(num_rendered=R, color=color, radii=radii, depth=depth, acc=acc, flow=flow, idx=idx,
+               geomBuffer=geom, binningBuffer=binning, imgBuffer=img, settings=s)
+    if P:
+        res.update(_C.geom_views(geom, P))
+        res.update(_C.binning_views(binning, R, W, H))
+        res.update(_C.img_views(img, W, H))
+    return res
+
+
+def gpu_backward_raw(ins, fwd, grads, device="cuda"):
+    from ex4dgs_amd import _C
+    s = fwd["settings"]
+    e = torch.Tensor([])
+    d = lambda k: ins[k].to(device) if ins.get(k) is not None else e
+    gc, gd, gf, ga = [g.to(device) for g in grads]
+    outs = _C.rasterize_gaussians_backward(
+        s.bg, d("means3D"), fwd["radii"], d("colors_precomp"), d("scales"), d("rotations"), fwd["depth"], fwd["acc"], s.min_depth,
+        s.max_depth, s.scale_modifier, d("cov3D_precomp"), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size,
+        s.subpixel_offset, gc, gd, gf, ga, d("shs"), s.sh_degree, s.campos, fwd["geomBuffer"], fwd["num_rendered"],
+        fwd["binningBuffer"], fwd["imgBuffer"], s.debug)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_ddir")
+    res = dict(zip(names, outs))
+    P = ins["means3D"].shape[0]
+    if P:
+        res["acc16"] = _C.rasterize_gaussians_backward.last_scratch[: P * 64].view(torch.float32).view(P, 16)
+    return res
+
+
+def to_np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4):
+    """o: oracle dict, g: gpu dict.  Integers bit-exact; floats <= atol (relative to max(1,|ref|)) on every
+    pixel that is not 'fragile' (an alpha/T/power decision within frag_eps of its threshold in the oracle:
+    a 1-ulp exp() difference legitimately flips those, CR/forward.cu:372-387)."""
+    rep = {}
+    P = o["P"]
+    if P:
+        vis = o["radii"] > 0
+        assert np.array_equal(o["radii"], to_np(g["radii"])), "radii differ"
+        assert np.array_equal(o["tiles_touched"].astype(np.int64), to_np(g["tiles_touched"]).astype(np.int64) & 0xFFFFFFFF), "tiles_touched differ"
+        for k in ("depths", "means2D", "conic_opacity", "cov3D"):
+            a, b = o[k][vis], to_np(g[k])[vis]
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k} not bit-exact (max abs {np.abs(a - b).max()})"
+        if o["_inputs"]["colors_precomp"] is None:
+            a, b = o["rgb"][vis], to_np(g["rgb"])[vis]
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"rgb not bit-exact (max abs {np.abs(a - b).max()})"
+            cl = to_np(g["clamped"])[vis]
+            assert np.array_equal(o["clamped"][vis], np.stack([(cl >> c) & 1 for c in range(3)], -1)), "clamped differ"
+        assert o["num_rendered"] == g["num_rendered"], (o["num_rendered"], g["num_rendered"])
+        assert np.array_equal(o["point_list"].astype(np.int64), to_np(g["point_list"]).astype(np.int64)), "point_list (sort order) differs"
+        assert np.array_equal((o["keys_sorted"] >> np.uint64(32)).astype(np.int64), to_np(g["tile_ids"]).astype(np.int64)), "sorted tile ids differ"
+        assert np.array_equal(o["ranges"].astype(np.int64), to_np(g["ranges"]).astype(np.int64)), "tile ranges differ"
+    H, W = o["H"], o["W"]
+    frag = o["fragile"] if o.get("fragile") is not None else np.ones((H, W), np.float32)
+    solid = frag > frag_eps
+    rep["fragile_frac"] = 1.0 - solid.mean()
+    assert rep["fragile_frac"] <= max_fragile_frac, rep
+    worst = 0.0
+    for k in ("color", "depth", "acc", "flow"):
+        a, b = o[k], to_np(g[k])
+        err = np.abs(a - b) / np.maximum(1.0, np.abs(a))
+        e = err[:, solid].max() if solid.any() else 0.0
+        rep[k] = float(e)
+        worst = max(worst, e)
+        assert e <= atol, f"{k}: max err {e} > {atol} on non-fragile pixels ({rep})"
+        # fragile pixels: a flipped 1/255 contribution is bounded by ~alpha_min * |value| -- loose sanity bound
+        if (~solid).any():
+            assert err[:, ~solid].max() < 0.05 * max(1.0, np.abs(a).max()), f"{k}: fragile pixel error too large"
+    if P:
+        a, b = o["idx"][0], to_np(g["idx"])[0]
+        assert np.array_equal(a[solid], b[solid]), "dominant index differs on non-fragile pixels"
+        a, b = o["n_contrib"].astype(np.int64), to_np(g["n_contrib"]).astype(np.int64)
+        assert np.array_equal(a[solid], b[solid]), "n_contrib differs on non-fragile pixels"
+        a, b = o["final_T"], to_np(g["final_T"])
+        assert np.abs(a - b)[solid].max() <= atol
+    rep["worst"] = float(worst)
+    return rep
+
+
+def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0):
+    """Accumulated quantities: |gpu - oracle_double_sum| <= atol + k_eps * 2^-24 * sum|terms| per entry (the
+    reference itself sums with float atomics in arbitrary order).  Per-Gaussian derived gradients:
+    same bound propagated loosely via relative tolerance on the row scale."""
+    rep = {}
+    P = fwd_o["P"]
+    if P == 0:
+        return rep
+    eps = 2.0 ** -24
+    acc = to_np(gb["acc16"])[:, :13].astype(np.float64)
+    tol = atol + k_eps * eps * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
+    err = np.abs(acc - ob["sum13"])
+    rep["acc16_worst_ratio"] = float((err / tol).max())
+    assert (err <= tol).all(), f"accumulators out of tolerance: worst ratio {rep['acc16_worst_ratio']}, at {np.unravel_index((err / tol).argmax(), err.shape)}"
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_ddir", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        a, b = ob[k].astype(np.float64), to_np(gb[k]).astype(np.float64)
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if a.size == 0:
+            continue
+        a2, b2 = a.reshape(P, -1), b.reshape(P, -1)
+        scale = np.maximum(np.abs(a2).max(1, keepdims=True), 1.0)
+        rel = np.abs(a2 - b2) / scale
+        rep[k] = float(rel.max())
+    return rep
