@@ -42,7 +42,8 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forward", "ex4d_backward",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
-           "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset")
+           "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset",
+           "ex4d_profile_enable", "ex4d_profile_read")
 
 
 def library_path():
@@ -214,7 +215,6 @@ def mark_visible(means3D, viewmatrix, projmatrix, min_depth, max_depth=3.4028234
     present = torch.zeros(P, dtype=torch.bool, device=dev)
     if P == 0:
         return present
-    _, pm3 = _dev_f32(means3D, "means3D", dev)
     m = means3D.contiguous(); v = viewmatrix.contiguous(); p = projmatrix.contiguous()
     with torch.cuda.device(dev):
         _check(lib.ex4d_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), C.c_float(min_depth), C.c_float(max_depth),
@@ -250,3 +250,15 @@ def img_views(imgBuffer, W, H):
     return dict(final_T=i[lay.final_T: lay.final_T + 4 * W * H].view(torch.float32).view(H, W),
                 n_contrib=i[lay.n_contrib: lay.n_contrib + 4 * W * H].view(torch.int32).view(H, W),
                 ranges=i[lay.ranges: lay.ranges + 8 * T].view(torch.int32).view(T, 2))
+
+
+def profile_enable(on=True):
+    load().ex4d_profile_enable(int(bool(on)))
+
+
+def profile_read(which):
+    """[(stage name, ms)] of the most recent forward (which=0) / backward (which=1) call."""
+    ms = (C.c_float * 16)()
+    names = (C.c_char_p * 16)()
+    n = load().ex4d_profile_read(int(which), ms, names, 16)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -33,6 +33,33 @@ int fail(int code, const char *fmt, ...)
         HIP_TRY(expr);                                                                             \
         if ((prm)->debug) HIP_TRY(hipStreamSynchronize(stream));                                   \
     } while (0)
+#define MARK(which, name) g_prof.mark(which, name, stream)
+
+// Optional per-stage timing with hipEvents on the caller's stream (used by bench.py for the roofline line;
+// off by default, single host thread).
+struct StageProfiler {
+    static const int kMax = 16;
+    bool on = false;
+    hipEvent_t ev[2][kMax + 1];
+    const char *names[2][kMax];
+    int n[2] = { 0, 0 };
+    bool created = false;
+    void begin(int which, hipStream_t s)
+    {
+        if (!on) return;
+        if (!created) { for (int w = 0; w < 2; w++) for (int i = 0; i <= kMax; i++) (void)hipEventCreate(&ev[w][i]); created = true; }
+        n[which] = 0;
+        (void)hipEventRecord(ev[which][0], s);
+    }
+    void mark(int which, const char *name, hipStream_t s)
+    {
+        if (!on || n[which] >= kMax) return;
+        names[which][n[which]] = name;
+        n[which]++;
+        (void)hipEventRecord(ev[which][n[which]], s);
+    }
+};
+StageProfiler g_prof;
 
 struct Carver {
     char *base; size_t off;
@@ -164,18 +191,22 @@ int ex4d_forward(
     if (!img_buf) return fail(EX4D_ERR_ALLOC, "image buffer allocation failed");
     ImgState im = carve_img(img_buf, W, H, nullptr, nullptr);
 
+    g_prof.begin(0, stream);
     HIP_TRY(hipMemsetAsync(g.total, 0, 2 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, g, g.total + 1, stream), prm, stream);
+    MARK(0, "preprocess_fwd");
     // 2. order Gaussians by depth (stable; invisible ones last)
     STAGE(ex4d_launch_depth_keys(P, radii, g.depths, g.sort_keys_a, g.depth_order, stream), prm, stream);
     bool in_a = true;
     STAGE(ex4d_radix_sort_pairs(g.sort_keys_a, g.depth_order, g.sort_keys_b, g.sort_vals_b, (uint32_t)P, 32, g.sort_hist, &in_a, stream), prm, stream);
     // 4 passes: the result is back in the (a) pair = depth_order.  (end_bit 32 / 8 = even number of passes)
     if (!in_a) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
+    MARK(0, "depth_sort");
     // 3. instance offsets in depth order + total
     STAGE(ex4d_launch_scan_tiles(P, g.tiles_touched, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.total, stream), prm, stream);
+    MARK(0, "scan_tiles");
     // 4. the one blocking read-back the reference also has (rasterizer_impl.cu:298-299)
     uint32_t host_total[2] = { 0, 0 };
     HIP_TRY(hipMemcpyAsync(host_total, g.total, sizeof(host_total), hipMemcpyDeviceToHost, stream));
@@ -198,15 +229,19 @@ int ex4d_forward(
     uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
     if (R > 0) {
         STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, radii, g.means2D, k0, v0, stream), prm, stream);
+        MARK(0, "duplicate");
         bool res_a = true;
         STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);
     }
+    MARK(0, "tile_sort");
     STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
+    MARK(0, "tile_ranges");
     // 8. compositing
     const float *features = colors_precomp ? colors_precomp : g.rgb;
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.means2D, features, g.conic_opacity,
                                     g.depths, dir3D, background, im.final_T, im.n_contrib,
                                     out_color, out_depth, out_acc, out_flow, out_idx, stream), prm, stream);
+    MARK(0, "composite_fwd");
     return EX4D_OK;
 }
 
@@ -235,17 +270,38 @@ int ex4d_backward(
     ImgState im = carve_img((void *)img_buffer, W, H, nullptr, nullptr);
     float *acc16 = (float *)bwd_scratch;
 
+    g_prof.begin(1, stream);
     HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+    MARK(1, "zero_accumulators");
     const float *color_ptr = colors_precomp ? colors_precomp : g.rgb;            // rasterizer_impl.cu:426
     if (num_rendered > 0)
         STAGE(ex4d_launch_composite_bwd(*prm, im.ranges, b.point_list, subpixel_offset, background, g.means2D, g.conic_opacity,
                                         color_ptr, g.depths, out_depth, out_acc, im.final_T, im.n_contrib,
                                         dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, stream), prm, stream);
+    MARK(1, "composite_bwd");
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;            // rasterizer_impl.cu:460
     STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16,
                                      dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir,
                                      stream), prm, stream);
+    MARK(1, "preprocess_bwd");
     return EX4D_OK;
+}
+
+void ex4d_profile_enable(int on) { g_prof.on = on != 0; }
+
+int ex4d_profile_read(int which, float *ms, const char **names, int max_stages)
+{
+    if (which < 0 || which > 1 || !g_prof.created) return 0;
+    const int n = g_prof.n[which] < max_stages ? g_prof.n[which] : max_stages;
+    if (n == 0) return 0;
+    if (hipEventSynchronize(g_prof.ev[which][g_prof.n[which]]) != hipSuccess) return 0;
+    for (int i = 0; i < n; i++) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_prof.ev[which][i], g_prof.ev[which][i + 1]);
+        ms[i] = t;
+        if (names) names[i] = g_prof.names[which][i];
+    }
+    return n;
 }
 
 int ex4d_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -1,0 +1,87 @@
+"""Multi-GPU layer of the hot path: frames/views shard embarrassingly across ranks (one process per GPU,
+Gaussian parameters replicated), and the only collective is the sum all-reduce of the per-frame gradients
+for the training step (the reference itself is single-process: utils/general_utils.py:161).
+
+Backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests (world_size 2).
+Gradients are packed into a few large flat buckets (one all-reduce per bucket keeps every xGMI link busy
+with large messages instead of 5-15 small tensors) and reduced asynchronously so the exchange of frame
+i overlaps the rasterization of frame i+1.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  No-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_views(num_views, rank, world_size):
+    """Views i with i % world_size == rank (round-robin over the shuffled stack)."""
+    return list(range(rank, num_views, world_size))
+
+
+class GradBuckets:
+    """Flat-bucket sum all-reduce of a fixed list of same-dtype tensors (e.g. the rasterizer-input grads).
+
+    launch(tensors) packs into persistent flat buffers and starts one async all-reduce per bucket on the
+    process group's own stream; wait() blocks the current stream until they finished and unpacks in place.
+    """
+
+    def __init__(self, shapes, dtype=torch.float32, device="cpu", bucket_bytes=256 << 20, group=None):
+        self.group = group
+        self.shapes = [tuple(s) for s in shapes]
+        self.numels = [int(torch.Size(s).numel()) for s in self.shapes]
+        esz = torch.empty(0, dtype=dtype).element_size()
+        self.assign = []           # (bucket index, offset) per tensor
+        sizes = []
+        for n in self.numels:
+            if not sizes or (sizes[-1] + n) * esz > bucket_bytes and sizes[-1] > 0:
+                sizes.append(0)
+            self.assign.append((len(sizes) - 1, sizes[-1]))
+            sizes[-1] += n
+        self.flat = [torch.zeros(max(s, 1), dtype=dtype, device=device) for s in sizes]
+        self.pending = []
+        self._tensors = None
+
+    def launch(self, tensors):
+        assert len(tensors) == len(self.shapes)
+        self.wait()
+        for t, (b, off), n in zip(tensors, self.assign, self.numels):
+            self.flat[b][off:off + n].copy_(t.reshape(-1))
+        self._tensors = list(tensors)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self.pending = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flat]
+        return self
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self._tensors is not None:
+            for t, (b, off), n in zip(self._tensors, self.assign, self.numels):
+                t.copy_(self.flat[b][off:off + n].view(t.shape))
+            self._tensors = None
+
+
+def allreduce_max_scalar(value, device="cpu"):
+    """max over ranks of a Python float (used for the max-over-ranks step time of bench.py)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -163,6 +163,12 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  * 0..2 dL_dmean2D.xyz, 3..5 dL_dconic.(x,y,w), 6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir */
 size_t ex4d_backward_scratch_acc_offset(int32_t P);
 
+/* Optional per-stage timing (hipEvents on the caller's stream, single host thread; used by bench.py).
+ * ex4d_profile_read(which = 0 forward / 1 backward) waits for the last recorded call of that kind and
+ * returns the number of stages written to ms[] / names[]. */
+void ex4d_profile_enable(int on);
+int ex4d_profile_read(int which, float *ms, const char **names, int max_stages);
+
 #ifdef __cplusplus
 }
 #endif

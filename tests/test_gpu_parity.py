@@ -1,0 +1,251 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Integers (cull, radii, tiles, depth keys, sort order, ranges, n_contrib,
+dominant index) bit-exact; pixels and gradients within 1e-5 (north_star), threshold-flip aware."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, subpixel=None, seed=3, **fwd_over):
+    from oracle import oracle
+    ins, st = h.scene_inputs(cfg, P=P, t=t, sh_degree=sh_degree)
+    st.update(fwd_over)
+    if mutate:
+        mutate(ins, st)
+    o = h.oracle_forward(ins, st, subpixel_offset=subpixel)
+    g = h.gpu_forward_raw(ins, st, subpixel_offset=subpixel)
+    rep = h.compare_forward(o, g)
+    H, W = st["image_height"], st["image_width"]
+    grads = list(h.upstream_grads(torch.from_numpy(o["acc"]), H, W, seed=seed, grad_acc_zero=grad_acc_zero))
+    solid = torch.from_numpy(o["fragile"] > 1e-4)
+    grads = [x * solid[None] for x in grads]          # a flipped pair changes the whole pixel: exclude fragile pixels
+    ob = oracle.backward(o, *grads)
+    gb = h.gpu_backward_raw(ins, g, grads)
+    rep.update(h.compare_backward(ob, gb, o))
+    # per-Gaussian backward stage in isolation: feed the GPU's own accumulators to the oracle's stage
+    acc = h.to_np(gb["acc16"])
+    res = {k: np.zeros_like(v) for k, v in ob.items() if isinstance(v, np.ndarray) and k.startswith("dL_")}
+    res["dL_dmeans2D"] = np.ascontiguousarray(acc[:, 0:3])
+    res["dL_dconic"] = np.ascontiguousarray(np.stack([acc[:, 3], acc[:, 4], np.zeros_like(acc[:, 3]), acc[:, 5]], -1))
+    res["dL_dcolors"] = np.ascontiguousarray(acc[:, 7:10])
+    oracle.preprocess_backward(o, res)
+    for k in ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        a, b = res[k], h.to_np(gb[k])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k}: per-Gaussian backward stage not bit-exact (max abs {np.abs(a - b).max()})"
+    assert np.array_equal(h.to_np(gb["dL_dmeans2D"]), acc[:, 0:3])
+    assert np.array_equal(h.to_np(gb["dL_dopacity"])[:, 0], acc[:, 6])
+    assert np.array_equal(h.to_np(gb["dL_ddir"]), acc[:, 10:13])
+    return o, g, ob, gb, rep
+
+
+def test_cfg1_forward_backward(hip_lib):
+    _fwd_bwd("cfg1")
+
+
+def test_cfg1_training_grads(hip_lib):
+    _fwd_bwd("cfg1", grad_acc_zero=True, seed=9)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_degrees(hip_lib, deg):
+    _fwd_bwd("cfg1", sh_degree=deg)
+
+
+def test_static_20k_full_resolution(hip_lib):
+    o, *_ = _fwd_bwd("cfg2", P=20000)
+    assert o["W"] == 1352 and o["H"] == 1014          # 1352 = 84*16+8, 1014 = 63*16+6: partial edge tiles
+
+
+@pytest.mark.parametrize("t", [0, 137, 299])
+def test_dynamic_keyframed_scene(hip_lib, t):
+    _fwd_bwd("cfg3", P=12000, t=t)
+
+
+def test_deep_overlap_offcentre_projection(hip_lib):
+    o, *_ = _fwd_bwd("cfg5", P=6000)
+    assert o["num_rendered"] / max(1, (o["radii"] > 0).sum()) > 10
+
+
+def test_subpixel_offsets_and_scale_modifier(hip_lib):
+    g = torch.Generator().manual_seed(5)
+    sub = (torch.rand(256, 256, 2, generator=g) - 0.5)
+    _fwd_bwd("cfg1", subpixel=sub, scale_modifier=1.3)
+
+
+def test_colors_precomp_and_cov3d_precomp_paths(hip_lib):
+    def mutate(ins, st):
+        P = ins["means3D"].shape[0]
+        g = torch.Generator().manual_seed(2)
+        ins["colors_precomp"] = torch.rand(P, 3, generator=g)
+        ins["shs"] = None
+        # cov3D from scale/rotation in numpy (R S^2 R^T, raw quaternion) -> the precomputed path
+        s, q = ins["scales"].numpy().astype(np.float64), ins["rotations"].numpy().astype(np.float64)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                      2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(P, 3, 3)
+        S = R * s[:, None, :]
+        Sig = S @ S.transpose(0, 2, 1)
+        ins["cov3D_precomp"] = torch.tensor(np.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], -1), dtype=torch.float32)
+        ins["scales"] = None
+        ins["rotations"] = None
+    _fwd_bwd("cfg1", mutate=mutate)
+
+
+def test_depth_ties_giant_gaussian_and_degenerates(hip_lib):
+    def mutate(ins, st):
+        m = ins["means3D"]
+        m[10:40, 2] = 12.5                          # 30 exact depth ties -> order must fall back to ascending id
+        m[10:40, :2] *= 0.2
+        ins["scales"][5] = torch.tensor([30.0, 30.0, 30.0])      # one Gaussian covering every tile
+        ins["scales"][6] = torch.tensor([1e-9, 1e-9, 1e-9])      # degenerate covariance -> coef == 0
+        ins["opacities"][7] = 0.0
+        ins["opacities"][8] = 1.0
+        ins["means3D"][9] = torch.tensor([0.0, 0.0, 4.6])
+        ins["scales"][9] = torch.tensor([0.5, 0.5, 0.5])         # large, opaque, close: alpha clamps at 0.99
+    o, g, *_ = _fwd_bwd("cfg1", mutate=mutate)
+    T = ((o["W"] + 15) // 16) * ((o["H"] + 15) // 16)
+    assert int(o["tiles_touched"][5]) == T
+
+
+def test_empty_and_invisible(hip_lib):
+    from ex4dgs_amd import _C
+    ins, st = h.scene_inputs("cfg1")
+    # P == 0 (DGR/rasterize_points.cu:90,189)
+    empty = {k: (v[:0] if v is not None else None) for k, v in ins.items()}
+    g = h.gpu_forward_raw(empty, st)
+    assert g["num_rendered"] == 0 and g["color"].shape == (3, 256, 256) and float(g["color"].abs().sum()) == 0.0
+    assert int((g["idx"] != -1).sum()) == 0
+    gb = h.gpu_backward_raw(empty, g, [torch.zeros(3, 256, 256), torch.zeros(1, 256, 256), torch.zeros(3, 256, 256), torch.zeros(1, 256, 256)])
+    assert gb["dL_dmeans3D"].shape == (0, 3) and gb["dL_dsh"].shape == (0, 0, 3)
+    # nothing visible: everything behind the near plane -> R == 0, image = background, depth = max_depth
+    ins2 = dict(ins); ins2["means3D"] = ins["means3D"].clone(); ins2["means3D"][:, 2] = 1.0
+    o = h.oracle_forward(ins2, st)
+    g = h.gpu_forward_raw(ins2, st)
+    assert o["num_rendered"] == 0 and g["num_rendered"] == 0
+    h.compare_forward(o, g)
+    assert torch.allclose(g["color"].cpu(), st["bg"].view(3, 1, 1).expand(3, 256, 256))
+    assert float(g["depth"].min()) == st["max_depth"]
+    gb = h.gpu_backward_raw(ins2, g, [torch.randn(3, 256, 256), torch.randn(1, 256, 256), torch.randn(3, 256, 256), torch.randn(1, 256, 256)])
+    for k, v in gb.items():
+        assert float(v.abs().sum()) == 0.0, k
+
+
+def test_mark_visible_and_errors(hip_lib):
+    from ex4dgs_amd import _C
+    from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizer
+    from oracle import oracle
+    ins, st = h.scene_inputs("cfg2", P=5000)
+    s = h.gpu_settings(st, "cuda")
+    r = GaussianRasterizer(s)
+    vis = r.markVisible(ins["means3D"].cuda())
+    ref = oracle.mark_visible(ins["means3D"], st["viewmatrix"], st["projmatrix"], st["min_depth"], st["max_depth"])
+    assert np.array_equal(vis.cpu().numpy(), ref)
+    d = {k: v.cuda() for k, v in ins.items()}
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(d["means3D"], None, d["dir3D"], d["opacities"], shs=None, colors_precomp=None, scales=d["scales"], rotations=d["rotations"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(d["means3D"], None, d["dir3D"], d["opacities"], shs=d["shs"], scales=d["scales"], rotations=d["rotations"], cov3D_precomp=torch.zeros(5000, 6).cuda())
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        r(d["means3D"].view(-1), None, d["dir3D"], d["opacities"], shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(ins["means3D"], None, ins["dir3D"], ins["opacities"], shs=ins["shs"], scales=ins["scales"], rotations=ins["rotations"])
+    # prefiltered=True with culled Gaussians: the reference traps on the device, here a RuntimeError
+    s2 = s._replace(prefiltered=True)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        GaussianRasterizer(s2)(d["means3D"], None, d["dir3D"], d["opacities"], shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+
+
+def test_autograd_surface_matches_raw_and_render_glue(hip_lib):
+    """GaussianRasterizer through torch autograd + the render() glue == the raw `_C` calls; debug mode works."""
+    from ex4dgs_amd.render import render
+    from ex4dgs_amd.scene import make_scene
+    dev = torch.device("cuda")
+    model, cam, bg = make_scene("cfg3", P=8000, device=dev)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    cam = cam.to(dev)
+    out = render(cam, model, None, bg, timestamp=137, near=4.0, far=300.0)
+    assert set(out) == {"render", "depth", "opticalflow", "acc", "viewspace_points", "viewspace_l1points", "dominent_idxs", "visibility_filter", "radii"}
+    H, W = cam.image_height, cam.image_width
+    grads = [x.to(dev) for x in h.upstream_grads(out["acc"].detach().cpu(), H, W, seed=1)]
+    torch.autograd.backward([out["render"], out["depth"], out["opticalflow"], out["acc"]], grads)
+    with torch.no_grad():
+        ins = dict(means3D=model.get_xyz_at_t(137), rotations=model.get_rotation_at_t(137), opacities=model.get_opacity_at_t(137),
+                   scales=model.get_scaling(), shs=model.get_features(), dir3D=torch.zeros(8000, 3, device=dev))
+    st = dict(bg=bg, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
+              image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=0.1,
+              sh_degree=3, min_depth=4.0, max_depth=300.0, scale_modifier=1.0, prefiltered=False)
+    g = h.gpu_forward_raw(ins, st)
+    assert torch.equal(g["color"], out["render"]) and torch.equal(g["radii"], out["radii"]) and torch.equal(g["idx"], out["dominent_idxs"])
+    gb = h.gpu_backward_raw(ins, g, grads)
+    # atomics make float sums order-dependent run to run: compare with a tolerance relative to the row scale
+    a, b = out["viewspace_points"].grad, gb["dL_dmeans2D"]
+    assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    assert float((out["viewspace_l1points"].grad - gb["dL_ddir"]).abs().max()) <= 1e-4 * max(1.0, float(gb["dL_ddir"].abs().max()))
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert (out["visibility_filter"] == (out["radii"] > 0)).all()
+    pipe = type("P", (), dict(convert_SHs_python=False, compute_cov3D_python=False, debug=True))()
+    out2 = render(cam, model, pipe, bg, timestamp=137, near=4.0, far=300.0)
+    assert torch.equal(out2["render"], out["render"])
+
+
+def test_forward_is_deterministic(hip_lib):
+    ins, st = h.scene_inputs("cfg2", P=30000)
+    a = h.gpu_forward_raw(ins, st)
+    b = h.gpu_forward_raw(ins, st)
+    for k in ("color", "depth", "acc", "flow", "idx", "radii", "point_list", "ranges", "n_contrib", "final_T"):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_full_size_properties_1M(hip_lib):
+    """BASELINE config 3 at full size (1.0M Gaussians, 1352x1014): size-independent invariants of the path."""
+    ins, st = h.scene_inputs("cfg3", t=137)
+    g = h.gpu_forward_raw(ins, st)
+    P, R = ins["means3D"].shape[0], g["num_rendered"]
+    H, W = st["image_height"], st["image_width"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    radii, tiles = g["radii"], g["tiles_touched"].long()
+    assert P == 1_000_000 and int(tiles.sum()) == R
+    assert bool(((radii > 0) == (tiles > 0)).all())
+    V = int((radii > 0).sum())
+    assert 4.0 <= R / V <= 10.0, R / V                 # SURVEY.md 8(d) acceptance window
+    tile_ids, plist, ranges = g["tile_ids"].long(), g["point_list"].long(), g["ranges"].long()
+    assert bool((tile_ids[1:] >= tile_ids[:-1]).all()), "instances not sorted by tile"
+    depth_of = g["depths"][plist]
+    same = tile_ids[1:] == tile_ids[:-1]
+    assert bool((depth_of[1:][same] >= depth_of[:-1][same]).all()), "not depth-sorted inside a tile"
+    tie = same & (depth_of[1:] == depth_of[:-1])
+    assert bool((plist[1:][tie] > plist[:-1][tie]).all()), "depth ties must keep ascending Gaussian id (stable sort)"
+    # ranges partition [0, R): counts per tile match a histogram of the tile ids
+    counts = torch.bincount(tile_ids, minlength=T)
+    assert torch.equal(ranges[:, 1] - ranges[:, 0], counts)
+    nz = counts > 0
+    assert torch.equal(ranges[nz][:, 0], (torch.cumsum(counts, 0) - counts)[nz])
+    # every Gaussian appears exactly tiles_touched times
+    assert torch.equal(torch.bincount(plist, minlength=P), tiles)
+    # per-pixel state
+    n_contrib = g["n_contrib"].long()
+    ty, tx = torch.meshgrid(torch.arange(H, device="cuda") // 16, torch.arange(W, device="cuda") // 16, indexing="ij")
+    assert bool((n_contrib <= counts[ty * ((W + 15) // 16) + tx]).all())
+    acc, fT = g["acc"][0], g["final_T"]
+    assert float((acc + fT - 1.0).abs().max()) < 2e-5, "acc + final_T == 1 (sum of alpha*T telescopes)"
+    assert bool(((g["idx"][0] >= 0) == (acc > 0)).all())
+    assert bool(torch.isfinite(g["color"]).all())
+    # linearity of the backward in the upstream gradient: bwd(g1 + g2) == bwd(g1) + bwd(g2)
+    gr1 = [x.cuda() for x in h.upstream_grads(acc.cpu(), H, W, seed=1)]
+    gr2 = [x.cuda() for x in h.upstream_grads(acc.cpu(), H, W, seed=2, grad_acc_zero=False)]
+    d = {k: v.cuda() for k, v in ins.items()}
+    b1 = h.gpu_backward_raw(d, g, gr1)["acc16"].clone()
+    b2 = h.gpu_backward_raw(d, g, gr2)["acc16"].clone()
+    b12 = h.gpu_backward_raw(d, g, [a + b for a, b in zip(gr1, gr2)])["acc16"].clone()
+    # dL_dopacity's grad_acc term compounds T (nonlinear in nothing else): everything is linear in the upstream grads
+    err = (b12 - (b1 + b2)).abs()
+    scale = b12.abs().max(0)[0].clamp_min(1.0)
+    assert float((err / scale).max()) < 1e-3
