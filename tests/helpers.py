@@ -107,7 +107,8 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4):
         vis = o["radii"] > 0
         assert np.array_equal(o["radii"], to_np(g["radii"])), "radii differ"
         assert np.array_equal(o["tiles_touched"].astype(np.int64), to_np(g["tiles_touched"]).astype(np.int64) & 0xFFFFFFFF), "tiles_touched differ"
-        for k in ("depths", "means2D", "conic_opacity", "cov3D"):
+        keys = ("depths", "means2D", "conic_opacity") + (("cov3D",) if o["_inputs"]["cov3D_precomp"] is None else ())
+        for k in keys:
             a, b = o[k][vis], to_np(g[k])[vis]
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k} not bit-exact (max abs {np.abs(a - b).max()})"
         if o["_inputs"]["colors_precomp"] is None:

@@ -157,8 +157,9 @@ def test_mark_visible_and_errors(hip_lib):
         r(ins["means3D"], None, ins["dir3D"], ins["opacities"], shs=ins["shs"], scales=ins["scales"], rotations=ins["rotations"])
     # prefiltered=True with culled Gaussians: the reference traps on the device, here a RuntimeError
     s2 = s._replace(prefiltered=True)
+    behind = d["means3D"].clone(); behind[:10, 2] = 1.0          # 10 Gaussians in front of the near plane -> culled
     with pytest.raises(RuntimeError, match="filtered although prefiltered"):
-        GaussianRasterizer(s2)(d["means3D"], None, d["dir3D"], d["opacities"], shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+        GaussianRasterizer(s2)(behind, None, d["dir3D"], d["opacities"], shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
 
 
 def test_autograd_surface_matches_raw_and_render_glue(hip_lib):
