@@ -26,8 +26,7 @@ class Ex4dParams(C.Structure):
 
 
 class GeomLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("depths", "means2D", "conic_opacity", "rgb", "cov3D", "clamped", "tiles_touched",
-                                          "depth_order", "sorted_offsets", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("records", "cov3D", "clamped", "tiles_touched", "depth_order", "sorted_offsets", "total")]
 
 
 class BinningLayout(C.Structure):
@@ -228,8 +227,8 @@ def geom_views(geomBuffer, P):
     load().ex4d_geom_layout(P, C.byref(lay))
     g = geomBuffer
     v = lambda off, n, dt: g[off: off + n * torch.empty(0, dtype=dt).element_size()].view(dt)
-    return dict(depths=v(lay.depths, P, torch.float32), means2D=v(lay.means2D, 2 * P, torch.float32).view(P, 2),
-                conic_opacity=v(lay.conic_opacity, 4 * P, torch.float32).view(P, 4), rgb=v(lay.rgb, 3 * P, torch.float32).view(P, 3),
+    rec = v(lay.records, 16 * P, torch.float32).view(P, 16)
+    return dict(records=rec, depths=rec[:, 8], means2D=rec[:, 0:2], conic_opacity=rec[:, 2:6], rgb=rec[:, 9:12], dir3D=rec[:, 12:15],
                 cov3D=v(lay.cov3D, 6 * P, torch.float32).view(P, 6), clamped=v(lay.clamped, P, torch.uint8),
                 tiles_touched=v(lay.tiles_touched, P, torch.int32), depth_order=v(lay.depth_order, P, torch.int32))
 

@@ -77,10 +77,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     Carver c(buf);
     GeomState g;
     Ex4dGeomLayout l;
-    l.depths = c.off;         g.depths = c.take<float>(P);
-    l.means2D = c.off;        g.means2D = c.take<float2>(P);
-    l.conic_opacity = c.off;  g.conic_opacity = c.take<float4>(P);
-    l.rgb = c.off;            g.rgb = c.take<float>(3 * (size_t)P);
+    l.records = c.off;        g.records = c.take<float4>(4 * (size_t)P);
     l.cov3D = c.off;          g.cov3D = c.take<float>(6 * (size_t)P);
     l.clamped = c.off;        g.clamped = c.take<uint8_t>(P);
     l.tiles_touched = c.off;  g.tiles_touched = c.take<uint32_t>(P);
@@ -194,11 +191,10 @@ int ex4d_forward(
     g_prof.begin(0, stream);
     HIP_TRY(hipMemsetAsync(g.total, 0, 2 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
-    STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+    STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, g, g.total + 1, stream), prm, stream);
     MARK(0, "preprocess_fwd");
-    // 2. order Gaussians by depth (stable; invisible ones last)
-    STAGE(ex4d_launch_depth_keys(P, radii, g.depths, g.sort_keys_a, g.depth_order, stream), prm, stream);
+    // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
     bool in_a = true;
     STAGE(ex4d_radix_sort_pairs(g.sort_keys_a, g.depth_order, g.sort_keys_b, g.sort_vals_b, (uint32_t)P, 32, g.sort_hist, &in_a, stream), prm, stream);
     // 4 passes: the result is back in the (a) pair = depth_order.  (end_bit 32 / 8 = even number of passes)
@@ -228,7 +224,7 @@ int ex4d_forward(
     uint32_t *k1 = (passes % 2 == 0) ? b.keys_tmp : b.tile_ids;
     uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
     if (R > 0) {
-        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, radii, g.means2D, k0, v0, stream), prm, stream);
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, radii, g.records, k0, v0, stream), prm, stream);
         MARK(0, "duplicate");
         bool res_a = true;
         STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);
@@ -237,9 +233,7 @@ int ex4d_forward(
     STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
     MARK(0, "tile_ranges");
     // 8. compositing
-    const float *features = colors_precomp ? colors_precomp : g.rgb;
-    STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.means2D, features, g.conic_opacity,
-                                    g.depths, dir3D, background, im.final_T, im.n_contrib,
+    STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
                                     out_color, out_depth, out_acc, out_flow, out_idx, stream), prm, stream);
     MARK(0, "composite_fwd");
     return EX4D_OK;
@@ -273,10 +267,10 @@ int ex4d_backward(
     g_prof.begin(1, stream);
     HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
     MARK(1, "zero_accumulators");
-    const float *color_ptr = colors_precomp ? colors_precomp : g.rgb;            // rasterizer_impl.cu:426
+    // colours (SH or precomputed, rasterizer_impl.cu:426) already sit in the records
     if (num_rendered > 0)
-        STAGE(ex4d_launch_composite_bwd(*prm, im.ranges, b.point_list, subpixel_offset, background, g.means2D, g.conic_opacity,
-                                        color_ptr, g.depths, out_depth, out_acc, im.final_T, im.n_contrib,
+        STAGE(ex4d_launch_composite_bwd(*prm, im.ranges, b.point_list, subpixel_offset, background, g.records,
+                                        out_depth, out_acc, im.final_T, im.n_contrib,
                                         dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, stream), prm, stream);
     MARK(1, "composite_bwd");
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;            // rasterizer_impl.cu:460

@@ -26,19 +26,6 @@ __device__ __forceinline__ int to_int_sat(float f)
     return (int)f;
 }
 
-// ---------------------------------------------------------------- depth keys
-// key = bit pattern of p_view.z for visible Gaussians (depth > min_depth >= 0 => unsigned order == numeric
-// order, the same bits the reference puts in the low key word, CR/rasterizer_impl.cu:106); invisible
-// Gaussians get 0xFFFFFFFF and end up behind every visible one.
-__global__ __launch_bounds__(256) void depth_keys_kernel(int P, const int32_t *__restrict__ radii,
-    const float *__restrict__ depths, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    keys[i] = (radii[i] > 0) ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
-}
-
 // ---------------------------------------------------------------- radix sort (8-bit digits, stable)
 // pass structure: histogram -> row scan -> scatter.  hist layout: [bin][block] followed by [bin] totals.
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift,
@@ -85,60 +72,108 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
     if (threadIdx.x == 0) hist[(size_t)RS_BINS * nblocks + blockIdx.x] = carry_s;
 }
 
+// Scatter pass.  A block owns RS_CHUNK consecutive items; wave w owns the w-th quarter of them and walks it in
+// rounds of 64 consecutive items, so the stable order inside the block is (wave, round, lane).
+//  phase 1  each wave ranks its items against its own running per-digit counters (wave-private LDS, wave64
+//           ballot match, no block barrier);
+//  phase 2  one barrier: per digit, exclusive scan over the 4 waves + block-local digit starts + global bases;
+//  phase 3  items go to their block-local sorted slot in LDS, one barrier, then the block streams the staged
+//           chunk out: neighbouring threads write neighbouring addresses of the same digit run (coalesced).
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-    uint32_t n, int shift, uint32_t mask, uint32_t nblocks, const uint32_t *__restrict__ hist)
+    uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t digit_base[RS_BINS];     // running global position of the next item of each digit for this block
-    __shared__ uint32_t wave_cnt[4][RS_BINS];    // per-round per-wave digit counts -> exclusive offsets
+    __shared__ uint32_t wave_cnt[4][RS_BINS];     // per-wave digit counts -> exclusive block-local offsets
+    __shared__ uint32_t local_start[RS_BINS];     // first block-local slot of each digit
+    __shared__ uint32_t global_base[RS_BINS];     // global position of this block's first item of each digit
+    __shared__ uint32_t scan_tmp[8];
+    __shared__ uint2 stage[RS_CHUNK];             // (key, value) in block-local sorted order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        // exclusive scan of the 256 bin totals (global digit offsets) + this block's row offset
-        const uint32_t tot = hist[(size_t)RS_BINS * nblocks + tid];
-        uint32_t x = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) wave_cnt[0][wave] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wave_cnt[0][w];
-        __syncthreads();
-        digit_base[tid] = woff + x - tot + hist[(size_t)tid * nblocks + blockIdx.x];
-    }
-    const uint32_t base = blockIdx.x * RS_CHUNK;
+    const uint32_t mask = (1u << nbits) - 1u;
+    const int nbins = 1 << nbits;
+    for (int i = lane; i < RS_BINS; i += 64) wave_cnt[wave][i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint32_t base = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int it = 0; it < RS_ITEMS; it++) {
-        const uint32_t i = base + it * RS_THREADS + tid;
-        const bool valid = i < n;
-        uint32_t key = 0, val = 0, d = 0;
-        if (valid) { key = keys_in[i]; val = vals_in[i]; d = (key >> shift) & mask; }
-        // lanes of this wave holding the same digit (wave64 match via 8 ballots)
-        uint64_t peers = __ballot(valid);
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], pos[RS_ITEMS];
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const uint32_t i = base + it * 64 + lane;
+        const bool valid = i < n;
+        key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[it] = valid ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const uint32_t i = base + it * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = (key[it] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; b++) {
             const uint64_t bal = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? bal : ~bal;
         }
         const uint32_t rank = __popcll(peers & lt);
-        const uint32_t cnt = __popcll(peers);
-        wave_cnt[wave][tid & 63] = 0; wave_cnt[wave][64 + (tid & 63)] = 0; wave_cnt[wave][128 + (tid & 63)] = 0; wave_cnt[wave][192 + (tid & 63)] = 0;
-        __syncthreads();
-        if (valid && rank == 0) wave_cnt[wave][d] = cnt;
-        __syncthreads();
-        {
-            // thread tid owns digit tid: turn the 4 per-wave counts into exclusive offsets, advance digit_base
-            const uint32_t c0 = wave_cnt[0][tid], c1 = wave_cnt[1][tid], c2 = wave_cnt[2][tid], c3 = wave_cnt[3][tid];
-            const uint32_t b0 = digit_base[tid];
-            wave_cnt[0][tid] = b0; wave_cnt[1][tid] = b0 + c0; wave_cnt[2][tid] = b0 + c0 + c1; wave_cnt[3][tid] = b0 + c0 + c1 + c2;
-            digit_base[tid] = b0 + c0 + c1 + c2 + c3;
+        const int leader = __ffsll((long long)peers) - 1;
+        uint32_t before = 0;
+        if (valid && rank == 0) {                 // one lane per distinct digit: no two leaders share an address
+            before = wave_cnt[wave][d];
+            wave_cnt[wave][d] = before + (uint32_t)__popcll(peers);
         }
+        before = __shfl(before, leader < 0 ? 0 : leader, 64);
+        pos[it] = before + rank;                  // index among this wave's items of digit d
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    {
+        // thread d: exclusive scan over waves for digit d, then exclusive scan over digits of the block totals
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (tid < nbins) { c0 = wave_cnt[0][tid]; c1 = wave_cnt[1][tid]; c2 = wave_cnt[2][tid]; c3 = wave_cnt[3][tid]; }
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) scan_tmp[wave] = x;
+        // exclusive scan of the global digit totals gives the digit's global start
+        const uint32_t gtot = (tid < nbins) ? hist[(size_t)RS_BINS * nblocks + tid] : 0;
+        uint32_t gx = gtot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(gx, o, 64); if (lane >= o) gx += y; }
+        if (lane == 63) scan_tmp[4 + wave] = gx;
         __syncthreads();
-        if (valid) {
-            const uint32_t pos = wave_cnt[wave][d] + rank;
-            keys_out[pos] = key;
-            vals_out[pos] = val;
+        uint32_t woff = 0, gwoff = 0;
+        for (int w = 0; w < wave; w++) { woff += scan_tmp[w]; gwoff += scan_tmp[4 + w]; }
+        if (tid < nbins) {
+            const uint32_t ls = woff + x - tot;
+            local_start[tid] = ls;
+            global_base[tid] = gwoff + gx - gtot + hist[(size_t)tid * nblocks + blockIdx.x];
+            wave_cnt[0][tid] = ls; wave_cnt[1][tid] = ls + c0; wave_cnt[2][tid] = ls + c0 + c1; wave_cnt[3][tid] = ls + c0 + c1 + c2;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const uint32_t i = base + it * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[it] >> shift) & mask;
+            stage[wave_cnt[wave][d] + pos[it]] = make_uint2(key[it], val[it]);
+        }
+    }
+    __syncthreads();
+    const uint32_t block_first = blockIdx.x * RS_CHUNK;
+    const uint32_t count = (n - block_first) < RS_CHUNK ? (n - block_first) : RS_CHUNK;
+#pragma unroll 4
+    for (uint32_t p = tid; p < count; p += RS_THREADS) {
+        const uint2 kv = stage[p];
+        const uint32_t d = (kv.x >> shift) & mask;
+        const uint32_t dst = global_base[d] + (p - local_start[d]);
+        keys_out[dst] = kv.x;
+        vals_out[dst] = kv.y;
     }
 }
 
@@ -203,48 +238,59 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(int nblocks, uint3
 }
 
 // ---------------------------------------------------------------- duplication
-// One lane per Gaussian (in depth order).  Small rects are written by the owning lane; rects larger than
-// a wave-width are expanded cooperatively by the whole wave (coalesced stores, no long serial tails).
+// The 64 Gaussians of a wave are consecutive in depth order, so their instances form ONE contiguous output
+// range.  The wave walks that range 64 outputs at a time: every lane finds the Gaussian owning its output
+// slot (6-step search over the lanes' offsets), derives the tile from the rect, and the wave issues fully
+// coalesced stores -- no serial per-Gaussian loops, no tail behind large rects.
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
-    const int32_t *__restrict__ radii, const float2 *__restrict__ means2D,
+    const int32_t *__restrict__ radii, const float4 *__restrict__ records,
     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t gid = 0, off = 0, count = 0;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    int x0 = 0, y0 = 0, w = 1;
     if (k < P) {
         gid = order[k];
+        // exclusive offset = inclusive scan value of the previous element (+ its block's base)
+        off = (k == 0) ? 0u : (sorted_offsets[k - 1] + block_sums[(k - 1) / SCAN_CHUNK]);
         const int r = radii[gid];
         if (r > 0) {
-            const float2 p = means2D[gid];
+            const float2 p = *reinterpret_cast<const float2 *>(records + 4 * (size_t)gid);
             // getRect, CR/auxiliary.h:46-56
             x0 = min(gx, max(0, to_int_sat((p.x - (float)r) / (float)EX4D_TILE)));
             y0 = min(gy, max(0, to_int_sat((p.y - (float)r) / (float)EX4D_TILE)));
-            x1 = min(gx, max(0, to_int_sat((p.x + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
-            y1 = min(gy, max(0, to_int_sat((p.y + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
-            count = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
-            // exclusive offset = inclusive scan value of the previous element (+ its block's base)
-            off = (k == 0) ? 0u : (sorted_offsets[k - 1] + block_sums[(k - 1) / SCAN_CHUNK]);
+            const int x1 = min(gx, max(0, to_int_sat((p.x + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
+            const int y1 = min(gy, max(0, to_int_sat((p.y + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
+            w = x1 - x0;
+            count = (uint32_t)w * (uint32_t)(y1 - y0);
+            if (w <= 0) w = 1;
         }
     }
-    const bool big = count > 32;
-    if (count > 0 && !big) {
-        uint32_t o = off;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) { tile_keys[o] = (uint32_t)(y * gx + x); vals[o] = gid; o++; }
-    }
-    uint64_t todo = __ballot(big);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t s_gid = __shfl(gid, src, 64), s_off = __shfl(off, src, 64), s_cnt = __shfl(count, src, 64);
-        const int s_x0 = __shfl(x0, src, 64), s_y0 = __shfl(y0, src, 64), s_w = __shfl(x1 - x0, src, 64);
-        for (uint32_t t = lane; t < s_cnt; t += 64) {
-            const int ty = s_y0 + (int)(t / (uint32_t)s_w), tx = s_x0 + (int)(t % (uint32_t)s_w);
-            tile_keys[s_off + t] = (uint32_t)(ty * gx + tx);
-            vals[s_off + t] = s_gid;
+    // lanes past P take the end of the wave's range as offset so the search below never selects them
+    uint32_t end = off + count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(end, o, 64); end = t > end ? t : end; }
+    if (k >= P) off = end;
+    const uint32_t start = __shfl(off, 0, 64);
+    for (uint32_t tb = start; tb < end; tb += 64) {       // wave-uniform trip count: every lane takes part in the shuffles
+        const uint32_t t = tb + lane;
+        // largest lane i with off_i <= t (zero-count lanes share their successor's offset, so this is the owner)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const int probe = lo + step;
+            const uint32_t v = __shfl(off, probe, 64);
+            if (v <= t) lo = probe;
+        }
+        const uint32_t o_off = __shfl(off, lo, 64), o_gid = __shfl(gid, lo, 64);
+        const int o_x0 = __shfl(x0, lo, 64), o_y0 = __shfl(y0, lo, 64), o_w = __shfl(w, lo, 64);
+        const uint32_t local = t - o_off;
+        const int ty = o_y0 + (int)(local / (uint32_t)o_w), tx = o_x0 + (int)(local % (uint32_t)o_w);
+        if (t < end) {
+            tile_keys[t] = (uint32_t)(ty * gx + tx);
+            vals[t] = o_gid;
         }
     }
 }
@@ -284,17 +330,11 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(rs_histogram_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_BINS), dim3(256), 0, stream, nb, hist);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, mask, nb, hist);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
         *result_in_a = !*result_in_a;
     }
-    return hipGetLastError();
-}
-
-hipError_t ex4d_launch_depth_keys(int P, const int32_t *radii, const float *depths, uint32_t *keys, uint32_t *vals, hipStream_t stream)
-{
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii, depths, keys, vals);
     return hipGetLastError();
 }
 
@@ -308,11 +348,11 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint32_t *tiles_touched, const ui
 }
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const int32_t *radii, const float2 *means2D, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream)
+    const uint32_t *block_sums, const int32_t *radii, const float4 *records, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        radii, means2D, tile_keys, vals);
+        radii, records, tile_keys, vals);
     return hipGetLastError();
 }
 

@@ -6,26 +6,28 @@
 // MI355X design (not the reference's 256-thread cooperative block):
 //   * a 16x16 tile is handled by 4 INDEPENDENT wave64s, one per 8x8 pixel quadrant -- no block barrier
 //     anywhere, a quadrant stops as soon as ITS 64 pixels are done;
+//   * every visible Gaussian has ONE 64-byte record (ex4d_internal.h: SplatRecord) written by the
+//     preprocess kernel, so a gather touches exactly one cache line instead of five arrays;
 //   * each wave streams the tile's depth-sorted list 64 entries at a time: one coalesced load of ids, a
-//     gather of the 24-byte (mean, conic, opacity) record, an exact conservative ellipse-vs-quadrant test
-//     (can the Gaussian reach alpha >= 1/255 anywhere in this quadrant?), wave64 ballot + prefix popcount
-//     compaction of the survivors into the wave's private LDS slice (order preserved, original list
-//     position kept so n_contrib keeps the reference's meaning);
-//   * the 64 lanes then walk the compacted list with wave-uniform LDS broadcasts; colour / depth / flow
-//     attributes are staged in LDS too (the reference re-reads them from global per contributing pair);
+//     gather of the first 24 record bytes, an exact conservative ellipse-vs-quadrant test (can this
+//     Gaussian reach alpha >= 1/255 anywhere in the quadrant?), wave64 ballot + prefix-popcount compaction
+//     of the survivors into the wave's private LDS slice (order preserved; the original list position is
+//     kept so n_contrib keeps the reference's meaning);
+//   * the 64 lanes then walk the compacted list with wave-uniform LDS broadcasts, one flat predicate per
+//     pair (no nested divergent branches: SALU mask traffic costs as much issue bandwidth as VALU here);
 //   * backward: same traversal in reverse, starting at the quadrant's deepest contributor instead of the
-//     list end; the 13 per-Gaussian partials of the 64 pixels are combined with a wave64 reduce-scatter
-//     butterfly (17 cross-lane adds instead of 13 x 64 float atomics) and leave the wave as ONE
-//     16-lane atomic instruction onto a 64-byte accumulator row.
+//     list end; the 13 per-Gaussian partials of the 64 pixels are combined by a wave64 reduce-scatter
+//     (v_permlane32_swap / v_permlane16_swap / DPP row ops: 35 cross-lane ops instead of 13 x 64 float
+//     atomics) and leave the wave as ONE 13-lane atomic instruction onto a 64-byte accumulator row.
+// Tiles are assigned to workgroups XCD-aware: workgroup b runs on XCD b % 8, so each XCD gets a
+// contiguous band of the screen and neighbouring tiles (which share Gaussians) hit the same L2.
 // Arithmetic follows the reference's expressions; FMA contraction is allowed here (results are compared
 // to the oracle within 1e-5, not bit-exactly) and exp() is the hardware v_exp_f32.
 #include "ex4d_internal.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <cstdlib>
 
 namespace {
-
-struct alignas(16) StageA { float x, y, depth; uint32_t id; };        // mean2D, depth, Gaussian id
-struct alignas(16) StageC { float r, g, b; uint32_t orig; };           // colour, position in the tile list
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -58,9 +60,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // alpha = w*exp(-q(d)), q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  =>  needs  min_box q <= ln(255 w).
 // Conservative (never culls a pair the per-pixel test would accept): slack of 1% in alpha plus a
 // rounding allowance proportional to the magnitude of the terms; anything not provably convex is kept.
-__device__ __forceinline__ bool quadrant_cull(float mx, float my, float4 co, float bx0, float bx1, float by0, float by1)
+__device__ __forceinline__ bool quadrant_cull(float mx, float my, float A, float B, float C, float w,
+                                              float bx0, float bx1, float by0, float by1)
 {
-    const float A = co.x, B = co.y, C = co.z, w = co.w;
     if (w < (1.0f / 255.0f)) return true;                  // exp(power) <= 1 => alpha < 1/255 everywhere
     if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return false;
     const float dxc = fminf(fmaxf(mx, bx0), bx1) - mx;     // nearest box point - mean (0 if inside the slab)
@@ -101,24 +103,33 @@ __device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int gx, int W, int 
     return p;
 }
 
+// workgroup -> tile, XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs, so XCD x gets
+// the contiguous tile band [x*chunk, (x+1)*chunk)
+__device__ __forceinline__ int tile_of_block(int num_tiles)
+{
+    const int chunk = (num_tiles + 7) >> 3;
+    return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-    const float *__restrict__ subpixel_offset, const float2 *__restrict__ means2D,
-    const float *__restrict__ features, const float4 *__restrict__ conic_opacity,
-    const float *__restrict__ depths, const float *__restrict__ dir3D, const float *__restrict__ bg,
-    float max_depth,
+    const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
+    const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx)
 {
-    __shared__ StageA s_a[4][64];
-    __shared__ float4 s_con[4][64];
-    __shared__ StageC s_c[4][64];
-    __shared__ float4 s_dir[4][64];
+    __shared__ float4 s_q0[4][64];      // x, y, A, B
+    __shared__ float2 s_q1[4][64];      // C, w
+    __shared__ float4 s_q2[4][64];      // depth, r, g, b
+    __shared__ float4 s_q3[4][64];      // dir xyz
+    __shared__ uint32_t s_id[4][64];
+    __shared__ uint32_t s_orig[4][64];
 
-    const int tile = blockIdx.x;
+    const int tile = tile_of_block(num_tiles);
+    if (tile >= num_tiles) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const PixelGeom p = pixel_of_lane(tile, gx, W, H, subpixel_offset);
     const uint2 range = ranges[tile];
@@ -135,57 +146,58 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
         if (__ballot(!done) == 0) break;
         const int k = base + lane;
         bool keep = false;
-        uint32_t id = 0; float2 xy = make_float2(0.f, 0.f); float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t id = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 q1 = make_float2(0.f, 0.f);
         if (k < n) {
             id = point_list[range.x + k];
-            xy = means2D[id];
-            co = conic_opacity[id];
-            keep = !quadrant_cull(xy.x, xy.y, co, bx0, bx1, by0, by1);
+            const float4 *r = records + 4 * (size_t)id;
+            q0 = r[0];
+            q1 = *reinterpret_cast<const float2 *>(r + 1);
+            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, bx0, bx1, by0, by1);
         }
         const uint64_t mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
             const int slot = __popcll(mask & lt);
-            StageA a; a.x = xy.x; a.y = xy.y; a.depth = depths[id]; a.id = id;
-            s_a[wave][slot] = a;
-            s_con[wave][slot] = co;
-            StageC c; c.r = features[3 * (size_t)id]; c.g = features[3 * (size_t)id + 1]; c.b = features[3 * (size_t)id + 2]; c.orig = (uint32_t)k;
-            s_c[wave][slot] = c;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (dir3D) { d.x = dir3D[3 * (size_t)id]; d.y = dir3D[3 * (size_t)id + 1]; d.z = dir3D[3 * (size_t)id + 2]; }
-            s_dir[wave][slot] = d;
+            const float4 *r = records + 4 * (size_t)id;
+            s_q0[wave][slot] = q0;
+            s_q1[wave][slot] = q1;
+            s_q2[wave][slot] = r[2];
+            s_q3[wave][slot] = r[3];
+            s_id[wave][slot] = id;
+            s_orig[wave][slot] = (uint32_t)k;
         }
         wave_lds_sync();
+        int last_j = -1, best_j = -1;
         for (int j = 0; j < cnt; j++) {
             if (__ballot(!done) == 0) break;
-            const StageA a = s_a[wave][j];
-            const float4 con_o = s_con[wave][j];
-            if (!done) {
-                // CR/forward.cu:368-423
-                const float dx = a.x - p.fx, dy = a.y - p.fy;
-                const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;
-                if (power <= 0.0f) {
-                    const float alpha = fminf(0.99f, con_o.w * __expf(power));
-                    if (!(alpha < 1.0f / 255.0f)) {
-                        const float test_T = T * (1 - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const StageC c = s_c[wave][j];
-                            const float4 dir = s_dir[wave][j];
-                            const float wgt = alpha * T;
-                            C0 += c.r * wgt; C1 += c.g * wgt; C2 += c.b * wgt;
-                            Dm += a.depth * wgt;
-                            acc += wgt;
-                            F0 += dir.x * wgt; F1 += dir.y * wgt; F2 += dir.z * wgt;
-                            if (wgt > max_vis) { max_vis = wgt; best = (int32_t)a.id; }
-                            T = test_T;
-                            last_contributor = c.orig + 1;
-                        }
-                    }
-                }
+            const float4 g0 = s_q0[wave][j];
+            const float2 g1 = s_q1[wave][j];
+            // CR/forward.cu:368-387, as one flat predicate
+            const float dx = g0.x - p.fx, dy = g0.y - p.fy;
+            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
+            const float alpha = fminf(0.99f, g1.y * __expf(power));
+            const float test_T = T * (1.f - alpha);
+            const bool ok = !done && (power <= 0.0f) && !(alpha < 1.0f / 255.0f);
+            const bool stop = ok && (test_T < 0.0001f);
+            done = done || stop;
+            if (ok && !stop) {
+                // CR/forward.cu:389-422
+                const float4 g2 = s_q2[wave][j];
+                const float4 g3 = s_q3[wave][j];
+                const float wgt = alpha * T;
+                C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
+                Dm += g2.x * wgt;
+                acc += wgt;
+                F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt;
+                if (wgt > max_vis) { max_vis = wgt; best_j = j; }
+                T = test_T;
+                last_j = j;
             }
         }
+        if (last_j >= 0) last_contributor = s_orig[wave][last_j] + 1;
+        if (best_j >= 0) best = (int32_t)s_id[wave][best_j];
         wave_lds_sync();
     }
     if (p.inside) {
@@ -207,55 +219,68 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave64 reduce-scatter of 16 per-lane values: afterwards lane l (all four lanes of its quad) holds the
-// wave-wide sum of value number  ((l>>5)&1)*8 + ((l>>4)&1)*4 + ((l>>3)&1)*2 + ((l>>2)&1).
+// wave64 reduce-scatter of 16 per-lane values.  Afterwards every lane l holds the wave-wide sum of value
+//   which(l) = ((l>>5)&1)*8 + ((l>>4)&1)*4 + ((l>>3)&1)*2 + ((l>>2)&1)
+// (all four lanes of a quad hold the same sum).
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane)
 {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
     float w8[8], w4[4], w2[2];
+    // halves: v_permlane32_swap exchanges a[32..63] <-> b[0..31]; then a+b = per-half sums, value i low / i+8 high
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float send = b5 ? v[i] : v[i + 8];
-        const float keep = b5 ? v[i + 8] : v[i];
-        w8[i] = keep + __shfl_xor(send, 32, 64);
+        const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+        w8[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
+    // 16-lane rows: v_permlane16_swap exchanges a.odd_rows <-> b.even_rows
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float send = b4 ? w8[i] : w8[i + 4];
-        const float keep = b4 ? w8[i + 4] : w8[i];
-        w4[i] = keep + __shfl_xor(send, 16, 64);
+        const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w8[i]), __float_as_uint(w8[i + 4]), false, false);
+        w4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
+    const bool b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 2; i++) {      // 8-lane halves of a row: rotate the row by 8 (DPP row_ror:8)
         const float send = b3 ? w4[i] : w4[i + 2];
         const float keep = b3 ? w4[i + 2] : w4[i];
-        w2[i] = keep + __shfl_xor(send, 8, 64);
+        w2[i] = keep + dpp_mov<0x128>(send);
     }
+    // 4-lane halves of an 8-lane group: DPP row_half_mirror pairs lane l with lane 7-l (bit 2 differs)
     const float send = b2 ? w2[0] : w2[1];
     const float keep = b2 ? w2[1] : w2[0];
-    float r = keep + __shfl_xor(send, 4, 64);
-    r += __shfl_xor(r, 2, 64);
-    r += __shfl_xor(r, 1, 64);
+    float r = keep + dpp_mov<0x141>(send);
+    r += dpp_mov<0xB1>(r);       // quad_perm [1,0,3,2]
+    r += dpp_mov<0x4E>(r);       // quad_perm [2,3,0,1]
     return r;
 }
 
+template <int EXPERIMENT>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(
-    int W, int H, int gx,
+    int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float *__restrict__ subpixel_offset, const float *__restrict__ bg,
-    const float2 *__restrict__ means2D, const float4 *__restrict__ conic_opacity,
-    const float *__restrict__ colors, const float *__restrict__ depths,
+    const float4 *__restrict__ records,
     const float *__restrict__ depth_acc, const float *__restrict__ weight_acc, float min_depth,
     const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpixels, const float *__restrict__ dL_ddepths,
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
     float *__restrict__ acc16)
 {
-    __shared__ StageA s_a[4][64];
-    __shared__ float4 s_con[4][64];
-    __shared__ StageC s_c[4][64];
+    __shared__ float4 s_q0[4][64];      // x, y, A, B
+    __shared__ float2 s_q1[4][64];      // C, w
+    __shared__ float4 s_q2[4][64];      // depth, r, g, b
+    __shared__ uint32_t s_id[4][64];
+    __shared__ uint32_t s_orig[4][64];
 
-    const int tile = blockIdx.x;
+    const int tile = tile_of_block(num_tiles);
+    if (tile >= num_tiles) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const PixelGeom p = pixel_of_lane(tile, gx, W, H, subpixel_offset);
     const uint2 range = ranges[tile];
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             gacc = dL_daccs[p.pix_id];
         }
     }
-    const float bg_dot_dpixel = bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2;
+    const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
@@ -285,80 +310,93 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     if (deepest == 0) return;
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
+    const int which = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const bool writer = ((lane & 3) == 0) && (which < 13);
 
     for (int base = 0; base < (int)deepest; base += 64) {
         const int k = (int)deepest - 1 - base - lane;            // descending list position
         bool keep = false;
-        uint32_t id = 0; float2 xy = make_float2(0.f, 0.f); float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t id = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 q1 = make_float2(0.f, 0.f);
         if (k >= 0) {
             id = point_list[range.x + k];
-            xy = means2D[id];
-            co = conic_opacity[id];
-            keep = !quadrant_cull(xy.x, xy.y, co, bx0, bx1, by0, by1);
+            const float4 *r = records + 4 * (size_t)id;
+            q0 = r[0];
+            q1 = *reinterpret_cast<const float2 *>(r + 1);
+            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, bx0, bx1, by0, by1);
         }
         const uint64_t mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
             const int slot = __popcll(mask & lt);
-            StageA a; a.x = xy.x; a.y = xy.y; a.depth = depths[id]; a.id = id;
-            s_a[wave][slot] = a;
-            s_con[wave][slot] = co;
-            StageC c; c.r = colors[3 * (size_t)id]; c.g = colors[3 * (size_t)id + 1]; c.b = colors[3 * (size_t)id + 2]; c.orig = (uint32_t)k;
-            s_c[wave][slot] = c;
+            s_q0[wave][slot] = q0;
+            s_q1[wave][slot] = q1;
+            s_q2[wave][slot] = records[4 * (size_t)id + 2];
+            s_id[wave][slot] = id;
+            s_orig[wave][slot] = (uint32_t)k;
         }
         wave_lds_sync();
         for (int j = 0; j < cnt; j++) {
-            const StageA a = s_a[wave][j];
-            const float4 con_o = s_con[wave][j];
-            const StageC c = s_c[wave][j];
-            // CR/backward.cu:575-590
-            bool contributes = p.inside && (c.orig < last_contributor);
-            const float dx = a.x - p.fx, dy = a.y - p.fy;
-            const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;
+            const float4 g0 = s_q0[wave][j];
+            const float2 g1 = s_q1[wave][j];
+            const uint32_t orig = s_orig[wave][j];
+            // CR/backward.cu:575-590, one flat predicate
+            const float dx = g0.x - p.fx, dy = g0.y - p.fy;
+            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
             const float G = __expf(power);
-            const float alpha = fminf(0.99f, con_o.w * G);
-            contributes = contributes && (power <= 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(contributes) == 0) continue;
+            const float alpha = fminf(0.99f, g1.y * G);
+            const bool ok = p.inside && (orig < last_contributor) && (power <= 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__ballot(ok) == 0) continue;
 
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = 0.f;
-            if (contributes) {
+            if (ok) {
                 // CR/backward.cu:592-679
-                T = T * __builtin_amdgcn_rcpf(1.f - alpha);
+                const float4 g2 = s_q2[wave][j];
+                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv1ma;
                 const float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.0f;
-                if ((a.depth > min_depth) & (dchannel_dcolor > 0.0f)) {
+                if ((g2.x > min_depth) & (dchannel_dcolor > 0.0f)) {
                     v[2] = gdepth * dchannel_dcolor;
-                    dL_dalpha += (final_depth - a.depth) * gdepth * T;
+                    dL_dalpha = (final_depth - g2.x) * gdepth * T;
                 }
-                rec0 = last_alpha * lc0 + (1.f - last_alpha) * rec0; lc0 = c.r;
-                rec1 = last_alpha * lc1 + (1.f - last_alpha) * rec1; lc1 = c.g;
-                rec2 = last_alpha * lc2 + (1.f - last_alpha) * rec2; lc2 = c.b;
-                dL_dalpha += (c.r - rec0) * gp0;
-                dL_dalpha += (c.g - rec1) * gp1;
-                dL_dalpha += (c.b - rec2) * gp2;
+                rec0 = last_alpha * lc0 + (1.f - last_alpha) * rec0; lc0 = g2.y;
+                rec1 = last_alpha * lc1 + (1.f - last_alpha) * rec1; lc1 = g2.z;
+                rec2 = last_alpha * lc2 + (1.f - last_alpha) * rec2; lc2 = g2.w;
+                dL_dalpha += (g2.y - rec0) * gp0;
+                dL_dalpha += (g2.z - rec1) * gp1;
+                dL_dalpha += (g2.w - rec2) * gp2;
                 v[7] = dchannel_dcolor * gp0; v[8] = dchannel_dcolor * gp1; v[9] = dchannel_dcolor * gp2;
                 v[10] = dchannel_dcolor * gflow0; v[11] = dchannel_dcolor * gflow1; v[12] = dchannel_dcolor * gflow2;
                 dL_dalpha *= T;
                 gacc *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(1.f - alpha)) * bg_dot_dpixel;
-                const float dL_dG = con_o.w * dL_dalpha;
+                dL_dalpha += bgT * inv1ma;
+                const float dL_dG = g1.y * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * con_o.x - gdy * con_o.y;
-                const float dG_ddely = -gdy * con_o.z - gdx * con_o.y;
+                const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
+                const float dG_ddely = -gdy * g1.x - gdx * g0.w;
                 v[0] = dL_dG * dG_ddelx * ddelx_dx;
                 v[1] = dL_dG * dG_ddely * ddely_dy;
-                v[3] = -0.5f * gdx * dx * dL_dG;
-                v[4] = -0.5f * gdx * dy * dL_dG;
-                v[5] = -0.5f * gdy * dy * dL_dG;
-                v[6] = G * dL_dalpha + G * gacc;
+                const float h = -0.5f * dL_dG;
+                v[3] = h * gdx * dx;
+                v[4] = h * gdx * dy;
+                v[5] = h * gdy * dy;
+                v[6] = G * (dL_dalpha + gacc);
             }
-            const float r = reduce_scatter16(v, lane);
-            if ((lane & 3) == 0) {
-                const int which = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                if (which < 13) unsafeAtomicAdd(&acc16[16 * (size_t)a.id + which], r);
+            if (EXPERIMENT == 2) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 13; i++) t += v[i];
+                if (t == 123.456f) acc16[lane] = t;
+            } else {
+                const float r = reduce_scatter16(v, lane);
+                if (EXPERIMENT == 1) { if (r == 123.456f) acc16[lane] = r; }
+                else if (EXPERIMENT == 3) { if (writer) acc16[16 * (size_t)s_id[wave][j] + which] = r; }
+                else if (writer) unsafeAtomicAdd(&acc16[16 * (size_t)s_id[wave][j] + which], r);
             }
         }
         wave_lds_sync();
@@ -368,26 +406,28 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
 }  // namespace
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
-    const float *subpixel_offset, const float2 *means2D, const float *features, const float4 *conic_opacity,
-    const float *depths, const float *dir3D, const float *bg, float *final_T, uint32_t *n_contrib,
+    const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(gx * gy), dim3(256), 0, stream,
-        prm.W, prm.H, gx, gx * gy, ranges, point_list, subpixel_offset, means2D, features, conic_opacity, depths, dir3D, bg,
+    const int T = gx * gy;
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
+        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
         prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
     return hipGetLastError();
 }
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
-    const float *subpixel_offset, const float *bg, const float2 *means2D, const float4 *conic_opacity,
-    const float *colors, const float *depths, const float *out_depth, const float *out_acc,
+    const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
     const float *dL_dflow, const float *dL_dacc, float *acc16, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(gx * gy), dim3(256), 0, stream,
-        prm.W, prm.H, gx, ranges, point_list, subpixel_offset, bg, means2D, conic_opacity, colors, depths,
-        out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16);
+    const int T = gx * gy;
+    static const int experiment = getenv("EX4D_EXPERIMENT") ? atoi(getenv("EX4D_EXPERIMENT")) : 0;
+#define LAUNCH_BWD(E) hipLaunchKernelGGL(composite_bwd_kernel<E>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, \
+        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, \
+        out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16)
+    if (experiment == 1) LAUNCH_BWD(1); else if (experiment == 2) LAUNCH_BWD(2); else if (experiment == 3) LAUNCH_BWD(3); else LAUNCH_BWD(0);
     return hipGetLastError();
 }

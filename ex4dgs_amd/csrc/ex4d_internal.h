@@ -10,11 +10,16 @@
 static inline size_t ex4d_align_up(size_t x) { return (x + (EX4D_ALIGN - 1)) & ~(size_t)(EX4D_ALIGN - 1); }
 
 // Typed views over the three opaque scratch buffers (layouts reported by ex4d_*_layout()).
+// One 64-byte record per Gaussian, written by preprocess_fwd for visible Gaussians, gathered by the
+// compositing kernels (one cache line per gather):
+//   float4 #0: mean2D.x, mean2D.y, conic.x (A), conic.y (B)
+//   float4 #1: conic.z (C), opacity*coef (w), 0, 0
+//   float4 #2: depth (p_view.z), r, g, b          (SH colour or colors_precomp)
+//   float4 #3: dir3D.x, dir3D.y, dir3D.z, 0       (per-Gaussian "flow" channel, zeros if absent)
+#define EX4D_RECORD_FLOATS 16
+
 struct GeomState {
-    float *depths;
-    float2 *means2D;
-    float4 *conic_opacity;
-    float *rgb;
+    float4 *records;          // [P][4]
     float *cov3D;
     uint8_t *clamped;
     uint32_t *tiles_touched;
@@ -48,7 +53,7 @@ struct ImgState {
 static inline uint32_t rs_num_blocks(uint32_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK; }
 
 // ---- launchers (each launches on `stream`, returns hipGetLastError()) -------------------------
-hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *scales,
+hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, hipStream_t stream);
@@ -68,20 +73,17 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
     uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream);
 size_t ex4d_radix_hist_words(uint32_t n);
 
-hipError_t ex4d_launch_depth_keys(int P, const int32_t *radii, const float *depths, uint32_t *keys, uint32_t *vals, hipStream_t stream);
 hipError_t ex4d_launch_scan_tiles(int P, const uint32_t *tiles_touched, const uint32_t *order, uint32_t *sorted_offsets,
     uint32_t *block_sums, uint32_t *total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const int32_t *radii, const float2 *means2D, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
+    const uint32_t *block_sums, const int32_t *radii, const float4 *records, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
-    const float *subpixel_offset, const float2 *means2D, const float *features, const float4 *conic_opacity,
-    const float *depths, const float *dir3D, const float *bg, float *final_T, uint32_t *n_contrib,
+    const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
-    const float *subpixel_offset, const float *bg, const float2 *means2D, const float4 *conic_opacity,
-    const float *colors, const float *depths, const float *out_depth, const float *out_acc,
+    const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
     const float *dL_dflow, const float *dL_dacc, float *acc16, hipStream_t stream);

@@ -132,15 +132,15 @@ __device__ __forceinline__ void cov2d_common(float3 mean, float fx, float fy, fl
 
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int D, int M,
-    const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
     const float *__restrict__ cov3D_precomp, const float *__restrict__ colors_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos,
     int W, int H, float tanx, float tany, float fx, float fy, float kernel_size, float min_depth, float max_depth,
     int prefiltered, uint32_t *__restrict__ prefilter_violation,
-    int32_t *__restrict__ radii, float *__restrict__ depths, float2 *__restrict__ means2D,
-    float4 *__restrict__ conic_opacity, float *__restrict__ rgb, float *__restrict__ cov3Ds,
-    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched)
+    int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
+    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched,
+    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 
     int out_radius = 0;
     uint32_t out_tiles = 0;
+    uint32_t depth_key = 0xFFFFFFFFu;   // invisible Gaussians sort behind every visible one
     do {
         const float3 p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
         float3 p_view; float ndc_x, ndc_y;
@@ -203,13 +204,15 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
         if (area == 0) break;
 
-        if (!colors_precomp) {
+        float res[3];
+        if (colors_precomp) {
+            res[0] = colors_precomp[3 * (size_t)idx]; res[1] = colors_precomp[3 * (size_t)idx + 1]; res[2] = colors_precomp[3 * (size_t)idx + 2];
+        } else {
             // SH -> RGB, CR/forward.cu:20-71.  48 floats per Gaussian read as 12 x 16 B.
             float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             const float x = dx / len, y = dy / len, z = dz / len;
             const float *sh = shs + (size_t)idx * M * 3;
-            float res[3];
             uint8_t clamp_bits = 0;
             const int ncoef = (D + 1) * (D + 1);
             float coefv[16][3];
@@ -261,17 +264,24 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 if (result < 0) clamp_bits |= (uint8_t)(1u << ch);
                 res[ch] = fmaxf(result, 0.0f);
             }
-            rgb[3 * (size_t)idx] = res[0]; rgb[3 * (size_t)idx + 1] = res[1]; rgb[3 * (size_t)idx + 2] = res[2];
             clamped[idx] = clamp_bits;
         }
-        depths[idx] = p_view.z;
-        means2D[idx] = make_float2(pix_x, pix_y);
-        conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, opacities[idx] * coef);
+        float4 *rec = records + 4 * (size_t)idx;
+        rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
+        rec[1] = make_float4(conic.z, opacities[idx] * coef, 0.f, 0.f);
+        rec[2] = make_float4(p_view.z, res[0], res[1], res[2]);
+        rec[3] = dir3D ? make_float4(dir3D[3 * (size_t)idx], dir3D[3 * (size_t)idx + 1], dir3D[3 * (size_t)idx + 2], 0.f)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
         out_radius = ri;
         out_tiles = area;
+        // depth > min_depth >= 0 => unsigned order of the bit pattern == numeric order: the same bits the
+        // reference puts in the low key word (CR/rasterizer_impl.cu:106)
+        depth_key = __float_as_uint(p_view.z);
     } while (0);
     radii[idx] = out_radius;
     tiles_touched[idx] = out_tiles;
+    depth_keys[idx] = depth_key;
+    depth_vals[idx] = (uint32_t)idx;
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 }  // namespace
 
-hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *scales,
+hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, hipStream_t stream)
@@ -529,10 +539,10 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float fx = prm.W / (2.0f * prm.tanfovx);
     const int blocks = (prm.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+        prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.depths, g.means2D, g.conic_opacity, g.rgb, g.cov3D, g.clamped, g.tiles_touched);
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.sort_keys_a, g.depth_order);
     return hipGetLastError();
 }
 

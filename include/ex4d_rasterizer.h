@@ -134,15 +134,14 @@ size_t ex4d_img_bytes(int32_t W, int32_t H);
 /* Byte offsets of the internal arrays inside the opaque buffers -- for parity tests only.
  * (reference counterparts: GeometryState / BinningState / ImageState, rasterizer_impl.h:29-65) */
 typedef struct Ex4dGeomLayout {
-    size_t depths;          /* float[P]            p_view.z */
-    size_t means2D;         /* float2[P]           pixel-space mean */
-    size_t conic_opacity;   /* float4[P]           (conic.x, conic.y, conic.z, opacity*coef) */
-    size_t rgb;             /* float[3P]           SH colour (unused when colors_precomp given) */
+    size_t records;         /* float[P][16]        one 64-byte record per Gaussian:
+                                                   [0..1] mean2D, [2..4] conic.xyz, [5] opacity*coef, [8] depth (p_view.z),
+                                                   [9..11] rgb (SH colour or colors_precomp), [12..14] dir3D */
     size_t cov3D;           /* float[6P] */
     size_t clamped;         /* uint8[P]            bit c set <=> channel c clamped at 0 (forward.cu:67-69) */
     size_t tiles_touched;   /* uint32[P] */
     size_t depth_order;     /* uint32[P]           Gaussian ids, stable-sorted by depth key (visible first) */
-    size_t sorted_offsets;  /* uint32[P]           inclusive scan of tiles_touched in depth order */
+    size_t sorted_offsets;  /* uint32[P]           block-local inclusive scan of tiles_touched in depth order */
     size_t total;
 } Ex4dGeomLayout;
 typedef struct Ex4dBinningLayout {

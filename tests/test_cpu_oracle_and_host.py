@@ -242,7 +242,7 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     # size / layout queries are pure host code
     P = 1000
     lay = _C.GeomLayout(); l.ex4d_geom_layout(P, ctypes.byref(lay))
-    assert lay.total == l.ex4d_geom_bytes(P) and lay.means2D >= 4 * P and lay.conic_opacity % 256 == 0
+    assert lay.total == l.ex4d_geom_bytes(P) and lay.cov3D >= 64 * P and lay.cov3D % 256 == 0 and lay.records == 0
     assert l.ex4d_binning_bytes(0, 64, 64) > 0 and l.ex4d_img_bytes(1352, 1014) >= 1352 * 1014 * 8 + 5440 * 8
     assert l.ex4d_backward_scratch_bytes(P) >= P * 64
     assert ctypes.sizeof(_C.Ex4dParams) == 13 * 4
