@@ -85,14 +85,17 @@ __device__ __forceinline__ bool quadrant_cull(float mx, float my, float A, float
     return qmin > tau + 1e-5f * mag;
 }
 
+__constant__ const float kHalfLog2e = -0.5f * 1.4426950408889634f;   // -1/2 log2(e)
+__constant__ const float kNegLog2e = -1.4426950408889634f;
+
 struct PixelGeom { int px, py; bool inside; float fx, fy; uint32_t pix_id; };
 
-__device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int gx, int W, int H, const float *__restrict__ subpixel_offset)
+__device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int quad, int gx, int W, int H, const float *__restrict__ subpixel_offset)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     PixelGeom p;
-    p.px = (tile % gx) * EX4D_TILE + (wave & 1) * 8 + (lane & 7);
-    p.py = (tile / gx) * EX4D_TILE + (wave >> 1) * 8 + (lane >> 3);
+    p.px = (tile % gx) * EX4D_TILE + (quad & 1) * 8 + (lane & 7);
+    p.py = (tile / gx) * EX4D_TILE + (quad >> 1) * 8 + (lane >> 3);
     p.inside = p.px < W && p.py < H;
     p.pix_id = (uint32_t)(W * p.py + p.px);
     p.fx = (float)p.px; p.fy = (float)p.py;
@@ -105,14 +108,19 @@ __device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int gx, int W, int 
 
 // workgroup -> tile, XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs, so XCD x gets
 // the contiguous tile band [x*chunk, (x+1)*chunk)
-__device__ __forceinline__ int tile_of_block(int num_tiles)
+// WPB = waves (quadrants) per workgroup: 4 -> one workgroup per tile, 1 -> one workgroup per quadrant
+template <int WPB>
+__device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &quad)
 {
     const int chunk = (num_tiles + 7) >> 3;
-    return (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    const int i = (int)(blockIdx.x >> 3);
+    if (WPB == 4) { tile = (int)(blockIdx.x & 7) * chunk + i; quad = threadIdx.x >> 6; }
+    else { tile = (int)(blockIdx.x & 7) * chunk + (i >> 2); quad = i & 3; }
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void composite_fwd_kernel(
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
@@ -121,17 +129,18 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx)
 {
-    __shared__ float4 s_q0[4][64];      // x, y, A, B
-    __shared__ float2 s_q1[4][64];      // C, w
-    __shared__ float4 s_q2[4][64];      // depth, r, g, b
-    __shared__ float4 s_q3[4][64];      // dir xyz
-    __shared__ uint32_t s_id[4][64];
-    __shared__ uint32_t s_orig[4][64];
+    __shared__ float4 s_q0[WPB][64];      // x, y, A, B
+    __shared__ float2 s_q1[WPB][64];      // C, w
+    __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
+    __shared__ float4 s_q3[WPB][64];      // dir xyz
+    __shared__ uint32_t s_id[WPB][64];
+    __shared__ uint32_t s_orig[WPB][64];
 
-    const int tile = tile_of_block(num_tiles);
+    int tile, quad;
+    tile_of_block<WPB>(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const PixelGeom p = pixel_of_lane(tile, gx, W, H, subpixel_offset);
+    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
+    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
@@ -161,8 +170,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
         if (keep) {
             const int slot = __popcll(mask & lt);
             const float4 *r = records + 4 * (size_t)id;
-            s_q0[wave][slot] = q0;
-            s_q1[wave][slot] = q1;
+            // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
+            s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
+            s_q1[wave][slot] = make_float2(q1.x * kHalfLog2e, q1.y);
             s_q2[wave][slot] = r[2];
             s_q3[wave][slot] = r[3];
             s_id[wave][slot] = id;
@@ -174,12 +184,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             if (__ballot(!done) == 0) break;
             const float4 g0 = s_q0[wave][j];
             const float2 g1 = s_q1[wave][j];
-            // CR/forward.cu:368-387, as one flat predicate
+            // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
             const float dx = g0.x - p.fx, dy = g0.y - p.fy;
-            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-            const float alpha = fminf(0.99f, g1.y * __expf(power));
+            const float power2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;
+            const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(power2));
             const float test_T = T * (1.f - alpha);
-            const bool ok = !done && (power <= 0.0f) && !(alpha < 1.0f / 255.0f);
+            const bool ok = !done && (power2 <= 0.0f) && !(alpha < 1.0f / 255.0f);
             const bool stop = ok && (test_T < 0.0001f);
             done = done || stop;
             if (ok && !stop) {
@@ -261,8 +271,8 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane)
     return r;
 }
 
-template <int EXPERIMENT>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(
+template <int WPB, int EXPERIMENT>
+__global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float *__restrict__ subpixel_offset, const float *__restrict__ bg,
@@ -273,16 +283,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
     float *__restrict__ acc16)
 {
-    __shared__ float4 s_q0[4][64];      // x, y, A, B
-    __shared__ float2 s_q1[4][64];      // C, w
-    __shared__ float4 s_q2[4][64];      // depth, r, g, b
-    __shared__ uint32_t s_id[4][64];
-    __shared__ uint32_t s_orig[4][64];
+    __shared__ float4 s_q0[WPB][64];      // x, y, a' = -A/2 log2e, b' = -B log2e
+    __shared__ float4 s_q1[WPB][64];      // c' = -C/2 log2e, w
+    __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
+    __shared__ uint32_t s_id[WPB][64];
+    __shared__ uint32_t s_orig[WPB][64];
 
-    const int tile = tile_of_block(num_tiles);
+    int tile, quad;
+    tile_of_block<WPB>(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const PixelGeom p = pixel_of_lane(tile, gx, W, H, subpixel_offset);
+    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
+    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
     const uint2 range = ranges[tile];
     const size_t HW = (size_t)H * W;
 
@@ -303,7 +314,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         }
     }
     const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
 
     const uint32_t deepest = wave_max_u32(last_contributor);     // nothing behind it touches this quadrant
@@ -330,8 +340,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         const int cnt = __popcll(mask);
         if (keep) {
             const int slot = __popcll(mask & lt);
-            s_q0[wave][slot] = q0;
-            s_q1[wave][slot] = q1;
+            s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
+            s_q1[wave][slot] = make_float4(q1.x * kHalfLog2e, q1.y, 0.f, 0.f);
             s_q2[wave][slot] = records[4 * (size_t)id + 2];
             s_id[wave][slot] = id;
             s_orig[wave][slot] = (uint32_t)k;
@@ -339,14 +349,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         wave_lds_sync();
         for (int j = 0; j < cnt; j++) {
             const float4 g0 = s_q0[wave][j];
-            const float2 g1 = s_q1[wave][j];
+            const float4 g1 = s_q1[wave][j];
             const uint32_t orig = s_orig[wave][j];
-            // CR/backward.cu:575-590, one flat predicate
+            // CR/backward.cu:575-590, one flat predicate (same arithmetic as the forward kernel: identical decisions)
             const float dx = g0.x - p.fx, dy = g0.y - p.fy;
-            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, g1.y * G);
-            const bool ok = p.inside && (orig < last_contributor) && (power <= 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float adx = g0.z * dx, bdy = g0.w * dy, cdy = g1.x * dy;
+            const float power2 = dx * (adx + bdy) + cdy * dy;
+            const float G = __builtin_amdgcn_exp2f(power2);                   // exp(power)
+            const float araw = g1.y * G;
+            const float alpha = fminf(0.99f, araw);
+            const bool ok = p.inside && (orig < last_contributor) && (power2 <= 0.0f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(ok) == 0) continue;
 
             float v[16];
@@ -375,16 +387,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
                 gacc *= T;
                 last_alpha = alpha;
                 dL_dalpha += bgT * inv1ma;
-                const float dL_dG = g1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-                const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-                v[0] = dL_dG * dG_ddelx * ddelx_dx;
-                v[1] = dL_dG * dG_ddely * ddely_dy;
-                const float h = -0.5f * dL_dG;
-                v[3] = h * gdx * dx;
-                v[4] = h * gdx * dy;
-                v[5] = h * gdy * dy;
+                // with s = dL_dG * G = w G dL_dalpha:  dL_dmean2D.x = s (-(A dx + B dy)) W/2 = s (2 a' dx + b' dy) (ln2 W/2),
+                // dL_dconic.x = -s dx^2 / 2, ...; the constant factors (ln2 W/2, ln2 H/2, -1/2) are applied once per
+                // Gaussian by the preprocess backward kernel instead of once per pair here
+                const float sG = araw * dL_dalpha;
+                v[0] = sG * (2.f * adx + bdy);
+                v[1] = sG * (2.f * cdy + g0.w * dx);
+                const float sdx = sG * dx;
+                v[3] = sdx * dx;
+                v[4] = sdx * dy;
+                v[5] = (sG * dy) * dy;
                 v[6] = G * (dL_dalpha + gacc);
             }
             if (EXPERIMENT == 2) {
@@ -411,9 +423,15 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
-        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
+    static const int wpb = getenv("EX4D_WPB") ? atoi(getenv("EX4D_WPB")) : 4;
+    if (wpb == 1)
+        hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(32 * ((T + 7) / 8)), dim3(64), 0, stream,
+            prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
+            prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
+    else
+        hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
+            prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
+            prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
     return hipGetLastError();
 }
 
@@ -425,7 +443,14 @@ hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges,
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
     static const int experiment = getenv("EX4D_EXPERIMENT") ? atoi(getenv("EX4D_EXPERIMENT")) : 0;
-#define LAUNCH_BWD(E) hipLaunchKernelGGL(composite_bwd_kernel<E>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, \
+    static const int wpb = getenv("EX4D_WPB") ? atoi(getenv("EX4D_WPB")) : 4;
+    if (wpb == 1) {
+        hipLaunchKernelGGL((composite_bwd_kernel<1, 0>), dim3(32 * ((T + 7) / 8)), dim3(64), 0, stream,
+            prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records,
+            out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16);
+        return hipGetLastError();
+    }
+#define LAUNCH_BWD(E) hipLaunchKernelGGL((composite_bwd_kernel<4, E>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, \
         prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, \
         out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16)
     if (experiment == 1) LAUNCH_BWD(1); else if (experiment == 2) LAUNCH_BWD(2); else if (experiment == 3) LAUNCH_BWD(3); else LAUNCH_BWD(0);

@@ -130,6 +130,48 @@ __device__ __forceinline__ void cov2d_common(float3 mean, float fx, float fy, fl
     c.cov = mul(TV, c.T);
 }
 
+// ---- wave-cooperative SH staging -------------------------------------------------------------------
+// The SH block of the 64 Gaussians of a wave is one contiguous 12 KB span ([P,16,3] floats).  A lane reading
+// "its" 48 floats directly issues 12 loads whose 64 lanes are 192 B apart (64 cache lines per instruction);
+// instead the wave copies the span with fully coalesced 16-byte accesses through a padded LDS slice
+// (row stride 52 floats: conflict-free ds_read/write_b128 for 8-lane groups) and each lane then reads its row.
+#define SH_ROW 52
+#define SH_LDS_FLOATS_PER_WAVE (64 * SH_ROW)
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// rows (Gaussians) whose bit is set in `need` are loaded; nvec = float4s needed per Gaussian (<= 12)
+__device__ __forceinline__ void wave_load_sh(const float *__restrict__ shs_wave, float *lds, uint64_t need, int nvec, int lane)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane;
+        const int g = q / 12, v = q - 12 * g;
+        if (((need >> g) & 1ull) && v < nvec)
+            *reinterpret_cast<float4 *>(lds + g * SH_ROW + 4 * v) = src[q];
+    }
+    wave_sync_lds();
+}
+
+// rows of the first `nrows` Gaussians are stored (all 12 float4 each)
+__device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, const float *lds, int nrows, int lane)
+{
+    wave_sync_lds();
+    float4 *dst = reinterpret_cast<float4 *>(dst_wave);
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane;
+        const int g = q / 12, v = q - 12 * g;
+        if (g < nrows) dst[q] = *reinterpret_cast<const float4 *>(lds + g * SH_ROW + 4 * v);
+    }
+}
+
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
@@ -142,8 +184,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals)
 {
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_range = idx < P;
     // the 2x16 camera floats are wave-uniform: they live in SGPRs / the scalar cache
     float vm[16], pm[16];
 #pragma unroll
@@ -152,8 +196,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t depth_key = 0xFFFFFFFFu;   // invisible Gaussians sort behind every visible one
-    do {
-        const float3 p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    bool visible = false;
+    float3 p = make_float3(0.f, 0.f, 0.f), conic = make_float3(0.f, 0.f, 0.f);
+    float pix_x = 0.f, pix_y = 0.f, depth = 0.f, coef = 0.f;
+    if (in_range) do {
+        p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
         float3 p_view; float ndc_x, ndc_y;
         if (!frustum_test(p, vm, pm, min_depth, max_depth, p_view, ndc_x, ndc_y)) {
             if (prefiltered) atomicOr(prefilter_violation, 1u);
@@ -183,56 +230,70 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         // anti-aliasing coefficient, CR/forward.cu:112-118 (float products, double max / sqrt / compare)
         const float det_0 = (float)fmax(1e-6, (double)(c.cov.m[0][0] * c.cov.m[1][1] - c.cov.m[0][1] * c.cov.m[0][1]));
         const float det_1 = (float)fmax(1e-6, (double)((c.cov.m[0][0] + kernel_size) * (c.cov.m[1][1] + kernel_size) - c.cov.m[0][1] * c.cov.m[0][1]));
-        float coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+        coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
         if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = 0.0f;
         const float ca = c.cov.m[0][0] + kernel_size, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + kernel_size;
 
         const float det = ca * cc - cb * cb;
         if (det == 0.0f) break;
         const float det_inv = 1.f / det;
-        const float3 conic = make_float3(cc * det_inv, -cb * det_inv, ca * det_inv);
+        conic = make_float3(cc * det_inv, -cb * det_inv, ca * det_inv);
         const float mid = 0.5f * (ca + cc);
         const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
         const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
         const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-        const float pix_x = (float)((((double)ndc_x + 1.0) * (double)W - 1.0) * 0.5);   // ndc2Pix, CR/auxiliary.h:41-44
-        const float pix_y = (float)((((double)ndc_y + 1.0) * (double)H - 1.0) * 0.5);
+        pix_x = (float)((((double)ndc_x + 1.0) * (double)W - 1.0) * 0.5);   // ndc2Pix, CR/auxiliary.h:41-44
+        pix_y = (float)((((double)ndc_y + 1.0) * (double)H - 1.0) * 0.5);
         const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
         const int ri = to_int_sat(my_radius);
         int x0, y0, x1, y1;
         tile_rect(pix_x, pix_y, ri, gx, gy, x0, y0, x1, y1);
         const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
         if (area == 0) break;
+        visible = true;
+        depth = p_view.z;
+        out_radius = ri;
+        out_tiles = area;
+        // depth > min_depth >= 0 => unsigned order of the bit pattern == numeric order: the same bits the
+        // reference puts in the low key word (CR/rasterizer_impl.cu:106)
+        depth_key = __float_as_uint(p_view.z);
+    } while (0);
 
+    // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
+    const int ncoef = (D + 1) * (D + 1);
+    float coefv[16][3];
+    const bool staged = (shs != nullptr) && (M == 16);
+    if (staged) {
+        float *lds = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
+        const uint64_t need = __ballot(visible);
+        wave_load_sh(shs + (size_t)(blockIdx.x * 256 + wave * 64) * 48, lds, need, (ncoef * 3 + 3) / 4, lane);
+        const float4 *row = reinterpret_cast<const float4 *>(lds + lane * SH_ROW);
+        float tmp[48];
+        const int nvec = (ncoef * 3 + 3) / 4;
+#pragma unroll
+        for (int v = 0; v < 12; v++) {
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (visible && v < nvec) t4 = row[v];
+            tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { coefv[k][0] = tmp[3 * k]; coefv[k][1] = tmp[3 * k + 1]; coefv[k][2] = tmp[3 * k + 2]; }
+    } else if (shs && visible) {
+        const float *sh = shs + (size_t)idx * M * 3;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) coefv[k][ch] = (k < ncoef && k < M) ? sh[3 * k + ch] : 0.f;
+    }
+    if (visible) {
         float res[3];
         if (colors_precomp) {
             res[0] = colors_precomp[3 * (size_t)idx]; res[1] = colors_precomp[3 * (size_t)idx + 1]; res[2] = colors_precomp[3 * (size_t)idx + 2];
         } else {
-            // SH -> RGB, CR/forward.cu:20-71.  48 floats per Gaussian read as 12 x 16 B.
             float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             const float x = dx / len, y = dy / len, z = dz / len;
-            const float *sh = shs + (size_t)idx * M * 3;
             uint8_t clamp_bits = 0;
-            const int ncoef = (D + 1) * (D + 1);
-            float coefv[16][3];
-            if (M == 16) {
-                const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
-                float tmp[48];
-                const int nvec = (ncoef * 3 + 3) / 4;
-#pragma unroll
-                for (int v = 0; v < 12; v++) {
-                    if (v < nvec) { float4 t4 = sh4[v]; tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w; }
-                    else { tmp[4 * v] = tmp[4 * v + 1] = tmp[4 * v + 2] = tmp[4 * v + 3] = 0.f; }
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) { coefv[k][0] = tmp[3 * k]; coefv[k][1] = tmp[3 * k + 1]; coefv[k][2] = tmp[3 * k + 2]; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) coefv[k][ch] = (k < ncoef && k < M) ? sh[3 * k + ch] : 0.f;
-            }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
 #define SHK(k) coefv[k][ch]
@@ -269,19 +330,16 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         float4 *rec = records + 4 * (size_t)idx;
         rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
         rec[1] = make_float4(conic.z, opacities[idx] * coef, 0.f, 0.f);
-        rec[2] = make_float4(p_view.z, res[0], res[1], res[2]);
+        rec[2] = make_float4(depth, res[0], res[1], res[2]);
         rec[3] = dir3D ? make_float4(dir3D[3 * (size_t)idx], dir3D[3 * (size_t)idx + 1], dir3D[3 * (size_t)idx + 2], 0.f)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        out_radius = ri;
-        out_tiles = area;
-        // depth > min_depth >= 0 => unsigned order of the bit pattern == numeric order: the same bits the
-        // reference puts in the low key word (CR/rasterizer_impl.cu:106)
-        depth_key = __float_as_uint(p_view.z);
-    } while (0);
-    radii[idx] = out_radius;
-    tiles_touched[idx] = out_tiles;
-    depth_keys[idx] = depth_key;
-    depth_vals[idx] = (uint32_t)idx;
+    }
+    if (in_range) {
+        radii[idx] = out_radius;
+        tiles_touched[idx] = out_tiles;
+        depth_keys[idx] = depth_key;
+        depth_vals[idx] = (uint32_t)idx;
+    }
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -310,28 +368,38 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const uint8_t *__restrict__ clamped, const float *__restrict__ scales, const float *__restrict__ rotations,
     float scale_modifier, const float *__restrict__ cov3Ds, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos,
-    float fx, float fy, float tanx, float tany, float kernel_size,
+    int W, int H, float fx, float fy, float tanx, float tany, float kernel_size,
     const float *__restrict__ acc16,
     float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir)
 {
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_range = idx < P;
+    const bool visible = in_range && (radii[idx] > 0);
+    const bool staged = (shs != nullptr) && (M == 16);
+    float *lds_row_base = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
+    const int wave_first = blockIdx.x * 256 + wave * 64;
+    if (staged)
+        wave_load_sh(shs + (size_t)wave_first * 48, lds_row_base, __ballot(visible), ((D + 1) * (D + 1) * 3 + 3) / 4, lane);
     float g_mean2D[3] = { 0, 0, 0 }, g_color[3] = { 0, 0, 0 }, g_dir[3] = { 0, 0, 0 }, g_opacity = 0;
     float g_mean3D[3] = { 0, 0, 0 }, g_cov[6] = { 0, 0, 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_rot[4] = { 0, 0, 0, 0 };
     float g_sh[16][3];
 #pragma unroll
     for (int k = 0; k < 16; k++) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
 
-    if (radii[idx] > 0) {
+    if (visible) {
         float vm[16], pm[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
         const float4 *row = reinterpret_cast<const float4 *>(acc16 + 16 * (size_t)idx);
         const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-        g_mean2D[0] = r0.x; g_mean2D[1] = r0.y; g_mean2D[2] = r0.z;
-        const float gA = r0.w, gB = r1.x, gC = r1.y;
+        // factors the compositing backward defers to here (ex4d_composite.hip): ln2 W/2, ln2 H/2 (CR/backward.cu:548-549,
+        // :669-670) and -1/2 (:673-675)
+        g_mean2D[0] = r0.x * (0.6931471805599453f * (0.5f * W)); g_mean2D[1] = r0.y * (0.6931471805599453f * (0.5f * H)); g_mean2D[2] = r0.z;
+        const float gA = -0.5f * r0.w, gB = -0.5f * r1.x, gC = -0.5f * r1.y;
         g_opacity = r1.z;
         g_color[0] = r1.w; g_color[1] = r2.x; g_color[2] = r2.y;
         g_dir[0] = r2.z; g_dir[1] = r2.w; g_dir[2] = r3.x;
@@ -380,7 +448,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             const float3 dir_orig = make_float3(mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]);
             const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
             const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-            const float *sh = shs + (size_t)idx * M * 3;
+            const float *sh = staged ? (lds_row_base + lane * SH_ROW) : (shs + (size_t)idx * M * 3);
             const uint8_t cl = clamped[idx];
             float dRGB[3];
 #pragma unroll
@@ -500,6 +568,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         }
     }
     // every output row written exactly once (replaces the ten torch::zeros of DGR/rasterize_points.cu:178-187)
+    if (M == 16) {
+        // dL_dsh of the wave = one contiguous 12 KB span: stage the rows in LDS, store fully coalesced
+        wave_sync_lds();                       // all lanes finished reading their SH rows
+        float4 *row = reinterpret_cast<float4 *>(lds_row_base + lane * SH_ROW);
+#pragma unroll
+        for (int v = 0; v < 12; v++) {
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
+            row[v] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        const int nrows = (P - wave_first) < 64 ? (P - wave_first) : 64;
+        wave_store_sh(dL_dsh + (size_t)wave_first * 48, lds_row_base, nrows, lane);
+    }
+    if (!in_range) return;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         dL_dmeans2D[3 * (size_t)idx + k] = g_mean2D[k];
@@ -512,16 +595,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = g_cov[k];
     reinterpret_cast<float4 *>(dL_drotations)[idx] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]);
-    if (M == 16) {
-        float4 *o = reinterpret_cast<float4 *>(dL_dsh + (size_t)idx * 48);
-#pragma unroll
-        for (int v = 0; v < 12; v++) {
-            float t[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
-            o[v] = make_float4(t[0], t[1], t[2], t[3]);
-        }
-    } else {
+    if (M != 16) {
         for (int k = 0; k < M; k++)
             for (int ch = 0; ch < 3; ch++)
                 dL_dsh[((size_t)idx * M + k) * 3 + ch] = (k < 16) ? g_sh[k][ch] : 0.f;
@@ -564,7 +638,7 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
     const float fx = prm.W / (2.0f * prm.tanfovx);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
         prm.P, prm.D, prm.M, means3D, radii, shs, g.clamped, scales, rotations, prm.scale_modifier, cov3D_ptr,
-        viewmatrix, projmatrix, campos, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16,
+        viewmatrix, projmatrix, campos, prm.W, prm.H, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16,
         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir);
     return hipGetLastError();
 }

@@ -526,8 +526,12 @@ void ex4d_oracle_render_bwd(
     const int gx = (W + BLOCK_X - 1) / BLOCK_X;
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
-#define ACC(ptr, k, val) do { float v_ = (val); *(ptr) += v_; \
-        if (sum13) { sum13[13 * (size_t)global_id + (k)] += (double)v_; abs13[13 * (size_t)global_id + (k)] += fabs((double)v_); } } while (0)
+    /* abs13 accumulates |term| x cond, cond = 1 + sum|terms of power| (conditioning of exp(power) for elongated
+     * conics; for the mean gradient also the cancellation inside -(A dx + B dy)): the magnitude against which any two
+     * float evaluations of the same formula can be expected to agree */
+#define ACCM(ptr, k, val, mag) do { float v_ = (val); *(ptr) += v_; \
+        if (sum13) { sum13[13 * (size_t)global_id + (k)] += (double)v_; abs13[13 * (size_t)global_id + (k)] += (double)(mag) * cond; } } while (0)
+#define ACC(ptr, k, val) ACCM(ptr, k, val, fabs((double)v_))
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             const uint32_t pix_id = (uint32_t)(W * py + px);
@@ -574,6 +578,7 @@ void ex4d_oracle_render_bwd(
                 const float G = expf(power);
                 const float alpha = fminf(0.99f, con_o[3] * G);
                 if (alpha < 1.0f / 255.0f) continue;
+                const double cond = 1.0 + 0.5 * (fabs((double)con_o[0] * dx * dx) + fabs((double)con_o[2] * dy * dy)) + fabs((double)con_o[1] * dx * dy);
 
                 T = T / (1.f - alpha);
                 const float dchannel_dcolor = alpha * T;
@@ -610,8 +615,10 @@ void ex4d_oracle_render_bwd(
                 const float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
                 const float dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
 
-                ACC(&dL_dmean2D[3 * (size_t)global_id + 0], 0, dL_dG * dG_ddelx * ddelx_dx);
-                ACC(&dL_dmean2D[3 * (size_t)global_id + 1], 1, dL_dG * dG_ddely * ddely_dy);
+                ACCM(&dL_dmean2D[3 * (size_t)global_id + 0], 0, dL_dG * dG_ddelx * ddelx_dx,
+                     fabs((double)dL_dG) * (fabs((double)gdx * con_o[0]) + fabs((double)gdy * con_o[1])) * ddelx_dx);
+                ACCM(&dL_dmean2D[3 * (size_t)global_id + 1], 1, dL_dG * dG_ddely * ddely_dy,
+                     fabs((double)dL_dG) * (fabs((double)gdy * con_o[2]) + fabs((double)gdx * con_o[1])) * ddely_dy);
                 ACC(&dL_dconic2D[4 * (size_t)global_id + 0], 3, -0.5f * gdx * dx * dL_dG);
                 ACC(&dL_dconic2D[4 * (size_t)global_id + 1], 4, -0.5f * gdx * dy * dL_dG);
                 ACC(&dL_dconic2D[4 * (size_t)global_id + 3], 5, -0.5f * gdy * dy * dL_dG);
@@ -620,6 +627,7 @@ void ex4d_oracle_render_bwd(
             }
         }
 #undef ACC
+#undef ACCM
 }
 
 /* CR/backward.cu:20-139 (SH backward): writes dL_dsh[idx,:,:], adds the direction path into dL_dmeans[idx] */

@@ -93,6 +93,17 @@ def gpu_backward_raw(ins, fwd, grads, device="cuda"):
     return res
 
 
+def acc16_in_reference_units(acc16, W, H):
+    """The compositing backward accumulates dL_dmean2D.xy and dL_dconic without their constant factors
+    (ln2*W/2, ln2*H/2, -1/2); the per-Gaussian backward kernel applies them in float32 exactly like this."""
+    a = np.array(to_np(acc16), dtype=np.float32, copy=True)
+    ln2 = np.float32(0.6931471805599453)
+    a[:, 0] = a[:, 0] * (ln2 * (np.float32(0.5) * np.float32(W)))
+    a[:, 1] = a[:, 1] * (ln2 * (np.float32(0.5) * np.float32(H)))
+    a[:, 3:6] = np.float32(-0.5) * a[:, 3:6]
+    return a
+
+
 def to_np(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
@@ -156,7 +167,7 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0):
     if P == 0:
         return rep
     eps = 2.0 ** -24
-    acc = to_np(gb["acc16"])[:, :13].astype(np.float64)
+    acc = acc16_in_reference_units(gb["acc16"], fwd_o["W"], fwd_o["H"])[:, :13].astype(np.float64)
     tol = atol + k_eps * eps * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
     err = np.abs(acc - ob["sum13"])
     rep["acc16_worst_ratio"] = float((err / tol).max())

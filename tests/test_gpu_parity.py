@@ -25,11 +25,18 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     grads = list(h.upstream_grads(torch.from_numpy(o["acc"]), H, W, seed=seed, grad_acc_zero=grad_acc_zero))
     solid = torch.from_numpy(o["fragile"] > 1e-4)
     grads = [x * solid[None] for x in grads]          # a flipped pair changes the whole pixel: exclude fragile pixels
-    ob = oracle.backward(o, *grads)
+    # The backward consumes the forward's per-pixel state (out_depth, out_acc, final_T, n_contrib).  dL_dalpha contains
+    # (final_depth - depth) * dL_ddepth, a difference of nearly equal depths, so a 1e-6 relative difference in out_depth
+    # (forward rounding, already checked above) would be amplified ~1e2-1e3x into the gradients.  To test the BACKWARD
+    # kernels in isolation the oracle backward therefore runs on the GPU forward's state.
+    ob_state = dict(o)
+    ob_state.update(depth=h.to_np(g["depth"]), acc=h.to_np(g["acc"]), final_T=np.ascontiguousarray(h.to_np(g["final_T"])),
+                    n_contrib=np.ascontiguousarray(h.to_np(g["n_contrib"]).astype(np.uint32)))
+    ob = oracle.backward(ob_state, *grads)
     gb = h.gpu_backward_raw(ins, g, grads)
     rep.update(h.compare_backward(ob, gb, o))
     # per-Gaussian backward stage in isolation: feed the GPU's own accumulators to the oracle's stage
-    acc = h.to_np(gb["acc16"])
+    acc = h.acc16_in_reference_units(gb["acc16"], o["W"], o["H"])
     res = {k: np.zeros_like(v) for k, v in ob.items() if isinstance(v, np.ndarray) and k.startswith("dL_")}
     res["dL_dmeans2D"] = np.ascontiguousarray(acc[:, 0:3])
     res["dL_dconic"] = np.ascontiguousarray(np.stack([acc[:, 3], acc[:, 4], np.zeros_like(acc[:, 3]), acc[:, 5]], -1))
