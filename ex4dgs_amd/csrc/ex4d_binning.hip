@@ -28,15 +28,16 @@ __device__ __forceinline__ int to_int_sat(float f)
 
 // ---------------------------------------------------------------- radix sort (8-bit digits, stable)
 // pass structure: histogram -> row scan -> scatter.  hist layout: [bin][block] followed by [bin] totals.
+template <int ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift,
     uint32_t mask, uint32_t nblocks, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t h[RS_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * RS_CHUNK;
+    const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
 #pragma unroll 4
-    for (int it = 0; it < RS_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * RS_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
 //  phase 2  one barrier: per digit, exclusive scan over the 4 waves + block-local digit starts + global bases;
 //  phase 3  items go to their block-local sorted slot in LDS, one barrier, then the block streams the staged
 //           chunk out: neighbouring threads write neighbouring addresses of the same digit run (coalesced).
+template <int ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist)
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __shared__ uint32_t local_start[RS_BINS];     // first block-local slot of each digit
     __shared__ uint32_t global_base[RS_BINS];     // global position of this block's first item of each digit
     __shared__ uint32_t scan_tmp[8];
-    __shared__ uint2 stage[RS_CHUNK];             // (key, value) in block-local sorted order
+    __shared__ uint2 stage[RS_THREADS * ITEMS];             // (key, value) in block-local sorted order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
     const int nbins = 1 << nbits;
@@ -96,18 +98,19 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const uint32_t base = blockIdx.x * RS_CHUNK + wave * (RS_CHUNK / 4);
+    constexpr uint32_t CHUNK = RS_THREADS * ITEMS;
+    const uint32_t base = blockIdx.x * CHUNK + wave * (CHUNK / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], pos[RS_ITEMS];
+    uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
         const bool valid = i < n;
         key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[it] = valid ? vals_in[i] : 0u;
     }
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = (key[it] >> shift) & mask;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
         if (i < n) {
             const uint32_t d = (key[it] >> shift) & mask;
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         }
     }
     __syncthreads();
-    const uint32_t block_first = blockIdx.x * RS_CHUNK;
-    const uint32_t count = (n - block_first) < RS_CHUNK ? (n - block_first) : RS_CHUNK;
+    const uint32_t block_first = blockIdx.x * CHUNK;
+    const uint32_t count = (n - block_first) < CHUNK ? (n - block_first) : CHUNK;
 #pragma unroll 4
     for (uint32_t p = tid; p < count; p += RS_THREADS) {
         const uint2 kv = stage[p];
@@ -316,21 +319,28 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint
 
 }  // namespace
 
-size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)RS_BINS * rs_num_blocks(n) + RS_BINS; }
+// small inputs (the per-Gaussian depth sort) use 1024-item chunks so that every CU gets several workgroups;
+// large ones (the per-instance tile sort) 4096-item chunks
+static inline int rs_items_for(uint32_t n) { return n <= (2u << 20) ? 4 : RS_ITEMS; }
+static inline uint32_t rs_blocks_for(uint32_t n) { const uint32_t c = RS_THREADS * rs_items_for(n); return (n + c - 1) / c; }
+size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)RS_BINS * rs_blocks_for(n) + RS_BINS; }
 
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
     uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream)
 {
     *result_in_a = true;
     if (n == 0) return hipSuccess;
-    const uint32_t nb = rs_num_blocks(n);
+    const uint32_t nb = rs_blocks_for(n);
+    const bool small = rs_items_for(n) == 4;
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
     for (int shift = 0; shift < end_bit; shift += 8) {
         const int nbits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
         const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(rs_histogram_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+        if (small) hipLaunchKernelGGL(rs_histogram_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+        else hipLaunchKernelGGL(rs_histogram_kernel<RS_ITEMS>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_BINS), dim3(256), 0, stream, nb, hist);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+        if (small) hipLaunchKernelGGL(rs_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+        else hipLaunchKernelGGL(rs_scatter_kernel<RS_ITEMS>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
         *result_in_a = !*result_in_a;
