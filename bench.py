@@ -113,17 +113,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=250_000)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
+    ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
-    rank, world, local = xdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the rasterizer has no CPU fallback")
-    hip_build.build()
-    _C.load()
+    if args.share_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = xdist.init_from_env(backend=args.backend)
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if rank == 0:
+        hip_build.build()            # one builder; the other ranks wait and then only dlopen
+    if world > 1:
+        torch.distributed.barrier()
+    _C.load()
 
     cfg = CONFIGS[args.config]
     model, cam, bg = make_scene(args.config, P=args.points)

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
         }
     }
     const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
-    float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f;
 
     const uint32_t deepest = wave_max_u32(last_contributor);     // nothing behind it touches this quadrant
     if (deepest == 0) return;
@@ -361,44 +361,45 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             const bool ok = p.inside && (orig < last_contributor) && (power2 <= 0.0f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(ok) == 0) continue;
 
+            // CR/backward.cu:592-679 for all 64 lanes at once, without a divergent branch: lanes that do not
+            // contribute run the same arithmetic with alpha = G = 0, which makes every partial exactly 0 and leaves
+            // T (x 1/(1-0)), the colour recurrence (R = 0*c + 1*R) and dL_dacc (x 1) unchanged.
+            const float alpha_m = ok ? alpha : 0.f;
+            const float G_m = ok ? G : 0.f;
+            const float4 g2 = s_q2[wave][j];
+            const float one_m = 1.f - alpha_m;
+            const float inv1ma = __builtin_amdgcn_rcpf(one_m);
+            T = T * inv1ma;
+            const float dcc = alpha_m * T;                          // dchannel_dcolor
             float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = 0.f;
-            if (ok) {
-                // CR/backward.cu:592-679
-                const float4 g2 = s_q2[wave][j];
-                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = T * inv1ma;
-                const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.0f;
-                if ((g2.x > min_depth) & (dchannel_dcolor > 0.0f)) {
-                    v[2] = gdepth * dchannel_dcolor;
-                    dL_dalpha = (final_depth - g2.x) * gdepth * T;
-                }
-                rec0 = last_alpha * lc0 + (1.f - last_alpha) * rec0; lc0 = g2.y;
-                rec1 = last_alpha * lc1 + (1.f - last_alpha) * rec1; lc1 = g2.z;
-                rec2 = last_alpha * lc2 + (1.f - last_alpha) * rec2; lc2 = g2.w;
-                dL_dalpha += (g2.y - rec0) * gp0;
-                dL_dalpha += (g2.z - rec1) * gp1;
-                dL_dalpha += (g2.w - rec2) * gp2;
-                v[7] = dchannel_dcolor * gp0; v[8] = dchannel_dcolor * gp1; v[9] = dchannel_dcolor * gp2;
-                v[10] = dchannel_dcolor * gflow0; v[11] = dchannel_dcolor * gflow1; v[12] = dchannel_dcolor * gflow2;
-                dL_dalpha *= T;
-                gacc *= T;
-                last_alpha = alpha;
-                dL_dalpha += bgT * inv1ma;
-                // with s = dL_dG * G = w G dL_dalpha:  dL_dmean2D.x = s (-(A dx + B dy)) W/2 = s (2 a' dx + b' dy) (ln2 W/2),
-                // dL_dconic.x = -s dx^2 / 2, ...; the constant factors (ln2 W/2, ln2 H/2, -1/2) are applied once per
-                // Gaussian by the preprocess backward kernel instead of once per pair here
-                const float sG = araw * dL_dalpha;
-                v[0] = sG * (2.f * adx + bdy);
-                v[1] = sG * (2.f * cdy + g0.w * dx);
-                const float sdx = sG * dx;
-                v[3] = sdx * dx;
-                v[4] = sdx * dy;
-                v[5] = (sG * dy) * dy;
-                v[6] = G * (dL_dalpha + gacc);
-            }
+            v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
+            const bool dep_ok = (g2.x > min_depth) & (dcc > 0.0f);
+            const float gdep = dep_ok ? gdepth : 0.f;
+            v[2] = gdep * dcc;
+            float dL_dalpha = (final_depth - g2.x) * gdep * T;
+            // accum_rec of the reference == colour accumulated behind this Gaussian; R is advanced after use
+            dL_dalpha += (g2.y - rec0) * gp0;
+            dL_dalpha += (g2.z - rec1) * gp1;
+            dL_dalpha += (g2.w - rec2) * gp2;
+            rec0 = alpha_m * g2.y + one_m * rec0;
+            rec1 = alpha_m * g2.z + one_m * rec1;
+            rec2 = alpha_m * g2.w + one_m * rec2;
+            v[7] = dcc * gp0; v[8] = dcc * gp1; v[9] = dcc * gp2;
+            v[10] = dcc * gflow0; v[11] = dcc * gflow1; v[12] = dcc * gflow2;
+            dL_dalpha *= T;
+            gacc *= (ok ? T : 1.f);
+            dL_dalpha += bgT * inv1ma;
+            // with s = dL_dG * G = w G dL_dalpha:  dL_dmean2D.x = s (-(A dx + B dy)) W/2 = s (2 a' dx + b' dy) (ln2 W/2),
+            // dL_dconic.x = -s dx^2 / 2, ...; the constant factors (ln2 W/2, ln2 H/2, -1/2) are applied once per
+            // Gaussian by the preprocess backward kernel instead of once per pair here
+            const float sG = (g1.y * G_m) * dL_dalpha;
+            v[0] = sG * (2.f * adx + bdy);
+            v[1] = sG * (2.f * cdy + g0.w * dx);
+            const float sdx = sG * dx;
+            v[3] = sdx * dx;
+            v[4] = sdx * dy;
+            v[5] = (sG * dy) * dy;
+            v[6] = G_m * (dL_dalpha + gacc);
             if (EXPERIMENT == 2) {
                 float t = 0.f;
 #pragma unroll

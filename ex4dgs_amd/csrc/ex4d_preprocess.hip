@@ -130,6 +130,28 @@ __device__ __forceinline__ void cov2d_common(float3 mean, float fx, float fy, fl
     c.cov = mul(TV, c.T);
 }
 
+// ---- wave-cooperative stores of narrow per-Gaussian rows -----------------------------------------------
+// A [P,3] / [P,6] gradient tensor written one row per lane makes every store instruction touch 64 partial
+// lines (measured: 2.3x HBM write amplification in the backward).  The wave's 64 rows are contiguous in
+// memory, so they are transposed through LDS and written as W fully coalesced 256-byte stores.
+template <int W>
+__device__ __forceinline__ void wave_store_rows(float *__restrict__ dst_wave, const float (&vals)[W], float *lds, int nrows, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < W; i++) lds[lane * W + i] = vals[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const int e = i * 64 + lane;
+        if (e < nrows * W) dst_wave[e] = lds[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- wave-cooperative SH staging -------------------------------------------------------------------
 // The SH block of the 64 Gaussians of a wave is one contiguous 12 KB span ([P,16,3] floats).  A lane reading
 // "its" 48 floats directly issues 12 loads whose 64 lanes are 192 B apart (64 cache lines per instruction);
@@ -579,21 +601,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
             row[v] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        const int nrows = (P - wave_first) < 64 ? (P - wave_first) : 64;
-        wave_store_sh(dL_dsh + (size_t)wave_first * 48, lds_row_base, nrows, lane);
+        wave_store_sh(dL_dsh + (size_t)wave_first * 48, lds_row_base, (P - wave_first) < 64 ? (P - wave_first) : 64, lane);
+        wave_sync_lds();
+    }
+    {
+        const int nrows = (P - wave_first) < 64 ? (P - wave_first) : 64;    // <= 0 for waves past the end
+        wave_store_rows<3>(dL_dmeans2D + 3 * (size_t)wave_first, g_mean2D, lds_row_base, nrows, lane);
+        wave_store_rows<3>(dL_dcolors + 3 * (size_t)wave_first, g_color, lds_row_base, nrows, lane);
+        wave_store_rows<3>(dL_dmeans3D + 3 * (size_t)wave_first, g_mean3D, lds_row_base, nrows, lane);
+        wave_store_rows<3>(dL_dscales + 3 * (size_t)wave_first, g_scale, lds_row_base, nrows, lane);
+        wave_store_rows<3>(dL_ddir + 3 * (size_t)wave_first, g_dir, lds_row_base, nrows, lane);
+        wave_store_rows<6>(dL_dcov3D + 6 * (size_t)wave_first, g_cov, lds_row_base, nrows, lane);
     }
     if (!in_range) return;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        dL_dmeans2D[3 * (size_t)idx + k] = g_mean2D[k];
-        dL_dcolors[3 * (size_t)idx + k] = g_color[k];
-        dL_dmeans3D[3 * (size_t)idx + k] = g_mean3D[k];
-        dL_dscales[3 * (size_t)idx + k] = g_scale[k];
-        dL_ddir[3 * (size_t)idx + k] = g_dir[k];
-    }
     dL_dopacity[idx] = g_opacity;
-#pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = g_cov[k];
     reinterpret_cast<float4 *>(dL_drotations)[idx] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]);
     if (M != 16) {
         for (int k = 0; k < M; k++)

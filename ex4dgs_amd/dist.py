@@ -36,21 +36,29 @@ def shard_views(num_views, rank, world_size):
 
 
 class GradBuckets:
-    """Flat-bucket sum all-reduce of a fixed list of same-dtype tensors (e.g. the rasterizer-input grads).
+    """Sum all-reduce of a fixed list of same-dtype gradient tensors, asynchronous.
 
-    launch(tensors) packs into persistent flat buffers and starts one async all-reduce per bucket on the
-    process group's own stream; wait() blocks the current stream until they finished and unpacks in place.
+    Large tensors (>= inplace_bytes, e.g. the [P,16,3] SH gradient: 192 MB at 1M Gaussians) are reduced IN PLACE,
+    one collective each -- no packing copies, which would cost as much HBM traffic as a rasterizer stage.  Small
+    ones are packed into flat buckets (one collective per bucket instead of many tiny ones).
+    launch(tensors) first waits for the previous exchange, then starts the collectives on the process group's own
+    stream; wait() blocks until they finished and unpacks the bucketed ones.  The caller must leave the tensors
+    untouched between launch() and wait().
     """
 
-    def __init__(self, shapes, dtype=torch.float32, device="cpu", bucket_bytes=256 << 20, group=None):
+    def __init__(self, shapes, dtype=torch.float32, device="cpu", bucket_bytes=64 << 20, inplace_bytes=4 << 20, group=None):
         self.group = group
         self.shapes = [tuple(s) for s in shapes]
         self.numels = [int(torch.Size(s).numel()) for s in self.shapes]
         esz = torch.empty(0, dtype=dtype).element_size()
-        self.assign = []           # (bucket index, offset) per tensor
+        self.inplace = [n * esz >= inplace_bytes for n in self.numels]
+        self.assign = []           # (bucket index, offset) per bucketed tensor, None for in-place ones
         sizes = []
-        for n in self.numels:
-            if not sizes or (sizes[-1] + n) * esz > bucket_bytes and sizes[-1] > 0:
+        for n, ip in zip(self.numels, self.inplace):
+            if ip:
+                self.assign.append(None)
+                continue
+            if not sizes or ((sizes[-1] + n) * esz > bucket_bytes and sizes[-1] > 0):
                 sizes.append(0)
             self.assign.append((len(sizes) - 1, sizes[-1]))
             sizes[-1] += n
@@ -58,14 +66,22 @@ class GradBuckets:
         self.pending = []
         self._tensors = None
 
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
     def launch(self, tensors):
         assert len(tensors) == len(self.shapes)
         self.wait()
-        for t, (b, off), n in zip(tensors, self.assign, self.numels):
-            self.flat[b][off:off + n].copy_(t.reshape(-1))
         self._tensors = list(tensors)
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        for t, a, n in zip(tensors, self.assign, self.numels):
+            if a is not None:
+                self.flat[a[0]][a[1]:a[1] + n].copy_(t.reshape(-1))
+        if self._active():
             self.pending = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flat]
+            for t, a in zip(tensors, self.assign):
+                if a is None:
+                    assert t.is_contiguous()
+                    self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return self
 
     def wait(self):
@@ -73,8 +89,9 @@ class GradBuckets:
             w.wait()
         self.pending = []
         if self._tensors is not None:
-            for t, (b, off), n in zip(self._tensors, self.assign, self.numels):
-                t.copy_(self.flat[b][off:off + n].view(t.shape))
+            for t, a, n in zip(self._tensors, self.assign, self.numels):
+                if a is not None:
+                    t.copy_(self.flat[a[0]][a[1]:a[1] + n].view(t.shape))
             self._tensors = None
 
 

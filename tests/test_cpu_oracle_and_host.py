@@ -281,8 +281,8 @@ g = torch.Generator().manual_seed(100 + rank)
 mine = [torch.randn(*s, generator=g) for s in shapes]
 g0, g1 = torch.Generator().manual_seed(100), torch.Generator().manual_seed(101)
 want = [torch.randn(*s, generator=g0) + torch.randn(*s, generator=g1) for s in shapes]
-b = xd.GradBuckets(shapes, bucket_bytes=4096)      # forces several buckets
-assert len(b.flat) > 1
+b = xd.GradBuckets(shapes, bucket_bytes=2048, inplace_bytes=9000)      # several buckets + one in-place tensor ([50,16,3])
+assert len(b.flat) > 1 and b.inplace == [False, True, False, False, False]
 b.launch(mine); b.wait()
 for a, w in zip(mine, want):
     assert torch.allclose(a, w, atol=1e-6), (a - w).abs().max()
