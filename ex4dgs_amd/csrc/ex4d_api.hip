@@ -61,6 +61,29 @@ struct StageProfiler {
 };
 StageProfiler g_prof;
 
+// pinned host word + event for the instance-count read-back (one per host thread, created on first use)
+struct Readback {
+    uint32_t *host = nullptr;
+    size_t words = 0;
+    hipEvent_t ev;
+    bool have_ev = false;
+    bool init(size_t need_words)
+    {
+        if (!have_ev) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+            have_ev = true;
+        }
+        if (need_words > words) {
+            if (host) (void)hipHostFree(host);
+            host = nullptr; words = 0;
+            if (hipHostMalloc((void **)&host, need_words * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return false;
+            words = need_words;
+        }
+        return true;
+    }
+};
+thread_local Readback g_readback;
+
 struct Carver {
     char *base; size_t off;
     explicit Carver(void *b) : base((char *)b), off(0) {}
@@ -88,7 +111,8 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_vals_b = c.take<uint32_t>(P);
     g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
-    g.total = c.take<uint32_t>(64);       // [0] instance count, [1] prefilter violation flag
+    g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-workgroup instance counts
+    g.block_totals = c.take<uint32_t>((P + 255) / 256);
     l.total = c.off;
     if (lay) *lay = l;
     if (total) *total = c.off;
@@ -194,6 +218,14 @@ int ex4d_forward(
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, g, g.total + 1, stream), prm, stream);
     MARK(0, "preprocess_fwd");
+    // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
+    // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
+    // (g.total[0..63] and the per-workgroup counts are adjacent in the geometry buffer: one copy)
+    const size_t nblk = (size_t)(P + 255) / 256;
+    const size_t rb_words = (size_t)(g.block_totals - g.total) + nblk;
+    if (!g_readback.init(rb_words)) return fail(EX4D_ERR_HIP, "pinned read-back buffer allocation failed");
+    HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(g_readback.ev, stream));
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
     bool in_a = true;
     STAGE(ex4d_radix_sort_pairs(g.sort_keys_a, g.depth_order, g.sort_keys_b, g.sort_vals_b, (uint32_t)P, 32, g.sort_hist, &in_a, stream), prm, stream);
@@ -203,10 +235,11 @@ int ex4d_forward(
     // 3. instance offsets in depth order + total
     STAGE(ex4d_launch_scan_tiles(P, g.tiles_touched, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.total, stream), prm, stream);
     MARK(0, "scan_tiles");
-    // 4. the one blocking read-back the reference also has (rasterizer_impl.cu:298-299)
-    uint32_t host_total[2] = { 0, 0 };
-    HIP_TRY(hipMemcpyAsync(host_total, g.total, sizeof(host_total), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
+    HIP_TRY(hipEventSynchronize(g_readback.ev));
+    uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
+    for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
+    const uint32_t host_total[2] = { instance_sum, g_readback.host[1] };
     if (prm->prefiltered && host_total[1])
         return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     const uint32_t R = host_total[0];

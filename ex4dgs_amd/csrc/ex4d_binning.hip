@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(int nblocks, uint3
         if (threadIdx.x == 255) carry_s = carry + woff + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry_s;
+    (void)total;
 }
 
 // ---------------------------------------------------------------- duplication

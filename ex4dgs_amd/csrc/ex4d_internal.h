@@ -29,7 +29,8 @@ struct GeomState {
     uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
-    uint32_t *total;                                     // [1] number of instances (device copy of num_rendered)
+    uint32_t *total;                                     // [0] unused, [1] prefilter violation flag
+    uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
 };
 struct BinState {
     uint32_t *point_list;     // final sorted Gaussian ids

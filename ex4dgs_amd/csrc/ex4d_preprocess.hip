@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int prefiltered, uint32_t *__restrict__ prefilter_violation,
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched,
-    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals)
+    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t *__restrict__ total_instances)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -362,6 +362,18 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         depth_keys[idx] = depth_key;
         depth_vals[idx] = (uint32_t)idx;
     }
+    // number of tile instances (the reference's num_rendered = last element of the inclusive scan,
+    // CR/rasterizer_impl.cu:295-299): it does not depend on the depth order, so it is summed here and read back by the
+    // host WHILE the depth sort runs -- the blocking read-back no longer leaves the GPU idle.
+    // (one plain store per workgroup; the host adds the few thousand partial sums -- a single atomic counter would
+    // serialise ~12 ns per arrival)
+    __shared__ uint32_t wave_totals[4];
+    uint32_t wave_sum = out_tiles;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_sum += __shfl_xor(wave_sum, o, 64);
+    if (lane == 0) wave_totals[wave] = wave_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) total_instances[blockIdx.x] = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -637,7 +649,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.sort_keys_a, g.depth_order);
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.sort_keys_a, g.depth_order, g.block_totals);
     return hipGetLastError();
 }
 
