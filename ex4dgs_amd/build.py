@@ -13,11 +13,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libex4d_hip.so")
 ARCH = "gfx950"
 
-# per-file flags: the per-Gaussian preprocess must not fuse multiply-adds (bit-exact integer decisions)
+# per-file flags: the per-Gaussian preprocess must not fuse multiply-adds (bit-exact integer decisions);
+# the compositing kernels are VALU-issue bound and v_pk_*_f32 is slower than two scalar ops there (measured:
+# -fno-slp-vectorize = -5 % kernel time), so the SLP vectoriser is off for that file
 SOURCES = {
     "ex4d_preprocess.hip": ["-ffp-contract=off"],
     "ex4d_binning.hip": [],
-    "ex4d_composite.hip": ["-ffp-contract=fast", "-munsafe-fp-atomics"],
+    "ex4d_composite.hip": ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"] + os.environ.get("EX4D_COMPOSITE_FLAGS", "").split(),
     "ex4d_api.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

@@ -255,17 +255,19 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane)
         const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w8[i]), __float_as_uint(w8[i + 4]), false, false);
         w4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-    const bool b3 = lane & 8, b2 = lane & 4;
+    (void)lane;
+    // 8-lane halves of a row (DPP row_ror:8 pairs lane l with l^8): x + ror8(x) is the pair sum in BOTH lanes; the
+    // DPP bank mask then keeps value i in banks 0-1 (lanes 0-7 of the row) and value i+2 in banks 2-3 -- no v_cndmask
 #pragma unroll
-    for (int i = 0; i < 2; i++) {      // 8-lane halves of a row: rotate the row by 8 (DPP row_ror:8)
-        const float send = b3 ? w4[i] : w4[i + 2];
-        const float keep = b3 ? w4[i + 2] : w4[i];
-        w2[i] = keep + dpp_mov<0x128>(send);
+    for (int i = 0; i < 2; i++) {
+        const float lo = w4[i] + dpp_mov<0x128>(w4[i]);
+        const float hi = w4[i + 2] + dpp_mov<0x128>(w4[i + 2]);
+        w2[i] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0xE4 /* quad_perm identity */, 0xf, 0xC, false));
     }
     // 4-lane halves of an 8-lane group: DPP row_half_mirror pairs lane l with lane 7-l (bit 2 differs)
-    const float send = b2 ? w2[0] : w2[1];
-    const float keep = b2 ? w2[1] : w2[0];
-    float r = keep + dpp_mov<0x141>(send);
+    const float lo = w2[0] + dpp_mov<0x141>(w2[0]);
+    const float hi = w2[1] + dpp_mov<0x141>(w2[1]);
+    float r = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0xE4, 0xf, 0xA, false));
     r += dpp_mov<0xB1>(r);       // quad_perm [1,0,3,2]
     r += dpp_mov<0x4E>(r);       // quad_perm [2,3,0,1]
     return r;
@@ -378,12 +380,13 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             v[2] = gdep * dcc;
             float dL_dalpha = (final_depth - g2.x) * gdep * T;
             // accum_rec of the reference == colour accumulated behind this Gaussian; R is advanced after use
-            dL_dalpha += (g2.y - rec0) * gp0;
-            dL_dalpha += (g2.z - rec1) * gp1;
-            dL_dalpha += (g2.w - rec2) * gp2;
-            rec0 = alpha_m * g2.y + one_m * rec0;
-            rec1 = alpha_m * g2.z + one_m * rec1;
-            rec2 = alpha_m * g2.w + one_m * rec2;
+            const float df0 = g2.y - rec0, df1 = g2.z - rec1, df2 = g2.w - rec2;
+            dL_dalpha += df0 * gp0;
+            dL_dalpha += df1 * gp1;
+            dL_dalpha += df2 * gp2;
+            rec0 += alpha_m * df0;          // == alpha c + (1 - alpha) rec
+            rec1 += alpha_m * df1;
+            rec2 += alpha_m * df2;
             v[7] = dcc * gp0; v[8] = dcc * gp1; v[9] = dcc * gp2;
             v[10] = dcc * gflow0; v[11] = dcc * gflow1; v[12] = dcc * gflow2;
             dL_dalpha *= T;
