@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
         wave_lds_sync();
         int last_j = -1, best_j = -1;
         for (int j = 0; j < cnt; j++) {
-            if (__ballot(!done) == 0) break;
+            // the all-done vote costs two VALU slots: take it every 8th entry only (a finished quadrant idles <= 7 entries)
+            if ((j & 7) == 0 && __ballot(!done) == 0) break;
             const float4 g0 = s_q0[wave][j];
             const float2 g1 = s_q1[wave][j];
             // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)

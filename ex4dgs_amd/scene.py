@@ -227,7 +227,7 @@ CONFIGS = {
     "cfg3": SceneConfig("cfg3: 1.0M static+dynamic (K=35), 1352x1014", 1_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=3),
     "cfg4": SceneConfig("cfg4: 2.0M static+dynamic x 300 frames, 1352x1014", 2_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=4),
     "cfg5": SceneConfig("cfg5: 1.0M deep-overlap, 2048x1088 off-centre", 1_000_000, 2048, 1088, 1100.0, min_depth=0.01,
-                        z_lo=0.5, z_hi=40.0, sigma_px_med=6.0, sigma_px_logstd=0.8, cxr=0.02, cyr=-0.01, seed=5),
+                        z_lo=0.5, z_hi=40.0, sigma_px_med=5.5, sigma_px_logstd=0.8, cxr=0.02, cyr=-0.01, seed=5),
 }
 
 
