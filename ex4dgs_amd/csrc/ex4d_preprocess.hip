@@ -11,6 +11,7 @@
 // (CR/auxiliary.h:43, :284; CR/forward.cu:112-116) are kept.  One thread per Gaussian, 256-thread
 // blocks (4 wave64); the kernels are HBM-bound (SH read / SH-grad write of 192 B per Gaussian).
 #include "ex4d_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -629,9 +630,15 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     dL_dopacity[idx] = g_opacity;
     reinterpret_cast<float4 *>(dL_drotations)[idx] = make_float4(g_rot[0], g_rot[1], g_rot[2], g_rot[3]);
     if (M != 16) {
-        for (int k = 0; k < M; k++)
-            for (int ch = 0; ch < 3; ch++)
-                dL_dsh[((size_t)idx * M + k) * 3 + ch] = (k < 16) ? g_sh[k][ch] : 0.f;
+        // constant indices only: a runtime-indexed g_sh[][] would push the whole array into scratch memory
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < M) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) dL_dsh[((size_t)idx * M + k) * 3 + ch] = g_sh[k][ch];
+            }
+        for (int k = 16; k < M; k++)
+            for (int ch = 0; ch < 3; ch++) dL_dsh[((size_t)idx * M + k) * 3 + ch] = 0.f;
     }
 }
 
