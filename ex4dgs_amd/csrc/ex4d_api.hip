@@ -104,6 +104,8 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     l.cov3D = c.off;          g.cov3D = c.take<float>(6 * (size_t)P);
     l.clamped = c.off;        g.clamped = c.take<uint8_t>(P);
     l.tiles_touched = c.off;  g.tiles_touched = c.take<uint32_t>(P);
+    g.rects = c.take<uint2>(P);
+    g.sorted_rects = c.take<uint2>(P);
     l.depth_order = c.off;    g.depth_order = c.take<uint32_t>(P);
     l.sorted_offsets = c.off; g.sorted_offsets = c.take<uint32_t>(P);
     g.sort_keys_a = c.take<uint32_t>(P);
@@ -233,7 +235,7 @@ int ex4d_forward(
     if (!in_a) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
     MARK(0, "depth_sort");
     // 3. instance offsets in depth order + total
-    STAGE(ex4d_launch_scan_tiles(P, g.tiles_touched, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.total, stream), prm, stream);
+    STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, stream), prm, stream);
     MARK(0, "scan_tiles");
     // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
     HIP_TRY(hipEventSynchronize(g_readback.ev));
@@ -257,7 +259,7 @@ int ex4d_forward(
     uint32_t *k1 = (passes % 2 == 0) ? b.keys_tmp : b.tile_ids;
     uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
     if (R > 0) {
-        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, radii, g.records, k0, v0, stream), prm, stream);
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, k0, v0, stream), prm, stream);
         MARK(0, "duplicate");
         bool res_a = true;
         STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);

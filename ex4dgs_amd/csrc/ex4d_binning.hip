@@ -181,22 +181,29 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 }
 
 // ---------------------------------------------------------------- scan of tiles_touched in depth order
-__global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint32_t *__restrict__ tiles_touched,
-    const uint32_t *__restrict__ order, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums)
+__global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint2 *__restrict__ rects,
+    const uint32_t *__restrict__ order, uint2 *__restrict__ sorted_rects, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums)
 {
-    // each thread scans 8 consecutive items (blocked arrangement), then wave + block scan of the thread totals
+    // coalesced (striped) global accesses, blocked scan: counts go through LDS; each thread scans 8 consecutive items,
+    // then wave + block scan of the thread totals
+    __shared__ uint32_t cnt[SCAN_CHUNK];
     __shared__ uint32_t wave_sums[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int first = blockIdx.x * SCAN_CHUNK + threadIdx.x * 8;
+    const int block_first = blockIdx.x * SCAN_CHUNK;
+#pragma unroll
+    for (int it = 0; it < SCAN_CHUNK / 256; it++) {
+        const int i = block_first + it * 256 + threadIdx.x;
+        // the only random gather of the binning stage: the rect of the i-th Gaussian in depth order (8 bytes), written
+        // back in that order so that the duplication kernel streams it
+        uint2 rc = make_uint2(0u, 0u);
+        if (i < P) { rc = rects[order[i]]; sorted_rects[i] = rc; }
+        cnt[it * 256 + threadIdx.x] = (rc.y & 0xFFFFu) * (rc.y >> 16);
+    }
+    __syncthreads();
     uint32_t v[8];
     uint32_t run = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int i = first + k;
-        v[k] = (i < P) ? tiles_touched[order[i]] : 0;
-        run += v[k];
-        v[k] = run;
-    }
+    for (int k = 0; k < 8; k++) { run += cnt[threadIdx.x * 8 + k]; v[k] = run; }
     uint32_t x = run;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
@@ -206,9 +213,12 @@ __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint
     for (int w = 0; w < wave; w++) woff += wave_sums[w];
     const uint32_t excl = woff + x - run;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int i = first + k;
-        if (i < P) out[i] = excl + v[k];
+    for (int k = 0; k < 8; k++) cnt[threadIdx.x * 8 + k] = excl + v[k];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SCAN_CHUNK / 256; it++) {
+        const int i = block_first + it * 256 + threadIdx.x;
+        if (i < P) out[i] = cnt[it * 256 + threadIdx.x];
     }
     if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + x;
 }
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(int nblocks, uint3
 // coalesced stores -- no serial per-Gaussian loops, no tail behind large rects.
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
-    const int32_t *__restrict__ radii, const float4 *__restrict__ records,
+    const uint2 *__restrict__ sorted_rects,
     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -258,18 +268,11 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
         gid = order[k];
         // exclusive offset = inclusive scan value of the previous element (+ its block's base)
         off = (k == 0) ? 0u : (sorted_offsets[k - 1] + block_sums[(k - 1) / SCAN_CHUNK]);
-        const int r = radii[gid];
-        if (r > 0) {
-            const float2 p = *reinterpret_cast<const float2 *>(records + 4 * (size_t)gid);
-            // getRect, CR/auxiliary.h:46-56
-            x0 = min(gx, max(0, to_int_sat((p.x - (float)r) / (float)EX4D_TILE)));
-            y0 = min(gy, max(0, to_int_sat((p.y - (float)r) / (float)EX4D_TILE)));
-            const int x1 = min(gx, max(0, to_int_sat((p.x + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
-            const int y1 = min(gy, max(0, to_int_sat((p.y + (float)r + (float)EX4D_TILE - 1.0f) / (float)EX4D_TILE)));
-            w = x1 - x0;
-            count = (uint32_t)w * (uint32_t)(y1 - y0);
-            if (w <= 0) w = 1;
-        }
+        const uint2 rc = sorted_rects[k];                 // getRect (CR/auxiliary.h:46-56) was evaluated once, by the preprocess kernel
+        x0 = (int)(rc.x & 0xFFFFu); y0 = (int)(rc.x >> 16);
+        w = (int)(rc.y & 0xFFFFu);
+        count = (uint32_t)w * (rc.y >> 16);
+        if (w <= 0) w = 1;
     }
     // lanes past P take the end of the wave's range as offset so the search below never selects them
     uint32_t end = off + count;
@@ -348,21 +351,21 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
     return hipGetLastError();
 }
 
-hipError_t ex4d_launch_scan_tiles(int P, const uint32_t *tiles_touched, const uint32_t *order, uint32_t *sorted_offsets,
-    uint32_t *block_sums, uint32_t *total, hipStream_t stream)
+hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
+    uint32_t *block_sums, hipStream_t stream)
 {
     const int nb = (P + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, tiles_touched, order, sorted_offsets, block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(256), 0, stream, nb, block_sums, total);
+    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, rects, order, sorted_rects, sorted_offsets, block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(256), 0, stream, nb, block_sums, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const int32_t *radii, const float4 *records, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream)
+    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        radii, records, tile_keys, vals);
+        sorted_rects, tile_keys, vals);
     return hipGetLastError();
 }
 

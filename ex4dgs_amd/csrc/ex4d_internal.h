@@ -23,6 +23,8 @@ struct GeomState {
     float *cov3D;
     uint8_t *clamped;
     uint32_t *tiles_touched;
+    uint2 *rects;             // [P] tile rect of every Gaussian: .x = x0 | y0 << 16, .y = w | h << 16 (w*h == tiles_touched)
+    uint2 *sorted_rects;      // [P] the same in depth order (gathered once by the scan kernel, streamed by duplicate)
     uint32_t *depth_order;
     uint32_t *sorted_offsets;
     // scratch used only inside forward (not needed by backward)
@@ -74,10 +76,10 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
     uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream);
 size_t ex4d_radix_hist_words(uint32_t n);
 
-hipError_t ex4d_launch_scan_tiles(int P, const uint32_t *tiles_touched, const uint32_t *order, uint32_t *sorted_offsets,
-    uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
+    uint32_t *block_sums, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const int32_t *radii, const float4 *records, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
+    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int W, int H, float tanx, float tany, float fx, float fy, float kernel_size, float min_depth, float max_depth,
     int prefiltered, uint32_t *__restrict__ prefilter_violation,
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
-    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched,
+    uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t *__restrict__ total_instances)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t depth_key = 0xFFFFFFFFu;   // invisible Gaussians sort behind every visible one
+    uint2 rect = make_uint2(0u, 0u);
     bool visible = false;
     float3 p = make_float3(0.f, 0.f, 0.f), conic = make_float3(0.f, 0.f, 0.f);
     float pix_x = 0.f, pix_y = 0.f, depth = 0.f, coef = 0.f;
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         tile_rect(pix_x, pix_y, ri, gx, gy, x0, y0, x1, y1);
         const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
         if (area == 0) break;
+        rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
         visible = true;
         depth = p_view.z;
         out_radius = ri;
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     if (in_range) {
         radii[idx] = out_radius;
         tiles_touched[idx] = out_tiles;
+        rects[idx] = rect;
         depth_keys[idx] = depth_key;
         depth_vals[idx] = (uint32_t)idx;
     }
@@ -656,7 +659,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.sort_keys_a, g.depth_order, g.block_totals);
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, g.sort_keys_a, g.depth_order, g.block_totals);
     return hipGetLastError();
 }
 
