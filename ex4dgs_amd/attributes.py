@@ -1,0 +1,108 @@
+"""Fused per-frame attribute evaluation: one HIP forward + one HIP backward instead of the
+reference's five Python getters and their autograd graph
+(scene/c_gaussian_model.py:170-215, :330-375; utils/interpolations.py:33-93; paths under /root/reference).
+
+`evaluate_attributes(params, t, ...)` is a torch.autograd.Function over the 15 parameter tensors of the model and
+returns `(means3D[N,3], rotations[N,4], opacities[N,1], scales[N,3], shs[N,16,3])`, static rows first -- exactly the
+five tensors gaussian_renderer.render() feeds to the rasterizer.  It calls the C ABI of include/ex4d_attributes.h
+(libex4d_hip.so); no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+
+PARAM_ORDER = ("_xyz", "_xyz_disp", "_rotation", "_opacity", "_scaling", "_features_dc", "_features_rest",
+               "_xyz_motion", "_rotation_motion", "_opacity_motion", "_opacity_duration_center",
+               "_opacity_duration_var", "_scaling_motion", "_features_dc_motion", "_features_rest_motion")
+
+EXPORTS = ("ex4d_attributes_forward", "ex4d_attributes_backward", "ex4d_attributes_last_error")
+
+
+class Ex4dAttrParams(C.Structure):
+    _fields_ = [("Ns", C.c_int32), ("Nd", C.c_int32), ("K", C.c_int32), ("k", C.c_int32), ("t", C.c_float), ("duration", C.c_float),
+                ("delta", C.c_float), ("h00", C.c_float), ("h10", C.c_float), ("h01", C.c_float), ("h11", C.c_float),
+                ("tau", C.c_float), ("var_min", C.c_float)]
+
+
+def time_scalars(t, Ns, Nd, K, duration, interval, time_shift, var_pad):
+    """The Python-number arithmetic of c_gaussian_model.py:184-186, :364 and interpolations.py:83-86 (double precision)."""
+    tp = t + time_shift
+    k = int(tp // interval)
+    d = (tp % interval) / interval
+    h00 = 2 * d ** 3 - 3 * d ** 2 + 1
+    h10 = d ** 3 - 2 * d ** 2 + d
+    h01 = -2 * d ** 3 + 3 * d ** 2
+    h11 = d ** 3 - d ** 2
+    return Ex4dAttrParams(Ns, Nd, K, k, float(t), float(max(duration, 1)), d, h00, h10, h01, h11, tp / interval, var_pad / interval)
+
+
+def _lib():
+    lib = _C.load()
+    if not getattr(lib, "_attr_ready", False):
+        lib.ex4d_attributes_last_error.restype = C.c_char_p
+        lib.ex4d_attributes_forward.restype = C.c_int
+        lib.ex4d_attributes_backward.restype = C.c_int
+        lib.ex4d_attributes_forward.argtypes = [C.POINTER(Ex4dAttrParams)] + [C.c_void_p] * 21
+        lib.ex4d_attributes_backward.argtypes = [C.POINTER(Ex4dAttrParams)] + [C.c_void_p] * 28
+        lib._attr_ready = True
+    return lib
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+class _EvaluateAttributes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scal, *params):
+        lib = _lib()
+        p = [x.contiguous() for x in params]
+        dev = p[0].device
+        if not p[0].is_cuda:
+            raise RuntimeError(f"parameters are on {dev}: the fused attribute evaluation only runs on a ROCm GPU (no CPU fallback)")
+        for x in p:
+            if x.dtype != torch.float32 or x.device != dev:
+                raise RuntimeError("all model parameters must be float32 tensors on the same ROCm device")
+        N = scal.Ns + scal.Nd
+        f32 = dict(dtype=torch.float32, device=dev)
+        outs = [torch.empty(N, 3, **f32), torch.empty(N, 4, **f32), torch.empty(N, 1, **f32), torch.empty(N, 3, **f32), torch.empty(N, 16, 3, **f32)]
+        with torch.cuda.device(dev):
+            rc = lib.ex4d_attributes_forward(C.byref(scal), *[_ptr(x) for x in p], *[_ptr(o) for o in outs],
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc:
+            raise RuntimeError(lib.ex4d_attributes_last_error().decode())
+        ctx.scal = scal
+        ctx.save_for_backward(*p)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_means3D, g_rotations, g_opacities, g_scales, g_shs):
+        lib = _lib()
+        p = ctx.saved_tensors
+        scal = ctx.scal
+        dev = p[0].device
+        N = scal.Ns + scal.Nd
+        f32 = dict(dtype=torch.float32, device=dev)
+        shapes = ((N, 3), (N, 4), (N, 1), (N, 3), (N, 16, 3))
+        gin = [(torch.zeros(*s, **f32) if g is None else g.contiguous()) for g, s in zip((g_means3D, g_rotations, g_opacities, g_scales, g_shs), shapes)]
+        gout = [torch.empty_like(x) for x in p]
+        byname = dict(zip(PARAM_ORDER, p))
+        with torch.cuda.device(dev):
+            rc = lib.ex4d_attributes_backward(
+                C.byref(scal), *[_ptr(byname[n]) for n in ("_opacity", "_scaling", "_rotation_motion", "_opacity_motion",
+                                                           "_opacity_duration_center", "_opacity_duration_var", "_scaling_motion")],
+                *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc:
+            raise RuntimeError(lib.ex4d_attributes_last_error().decode())
+        return (None,) + tuple(gout)
+
+
+def evaluate_attributes(params, t, duration=300, interval=10, time_shift=12, var_pad=3):
+    """params: mapping with the 15 CGaussianModel parameter tensors (PARAM_ORDER).  Returns the five boundary tensors."""
+    p = [params[n] for n in PARAM_ORDER]
+    Ns, Nd = p[0].shape[0], p[7].shape[0]
+    K = p[7].shape[1] if Nd > 0 else 0
+    scal = time_scalars(t, Ns, Nd, K, duration, interval, time_shift, var_pad)
+    return _EvaluateAttributes.apply(scal, *p)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/ex4d_rasterizer.h"
+#include "../../include/ex4d_attributes.h"
 
 #define EX4D_ALIGN 256
 

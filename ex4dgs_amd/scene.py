@@ -130,9 +130,14 @@ class DynamicGaussians:
                    "_xyz_motion", "_rotation_motion", "_opacity_motion", "_opacity_duration_center",
                    "_opacity_duration_var", "_scaling_motion", "_features_dc_motion", "_features_rest_motion")
 
-    def __init__(self, params, duration=300, interval=10, time_pad=2, var_pad=3, kernel_size=0.1, sh_degree=3):
+    def __init__(self, params, duration=300, interval=10, time_pad=2, var_pad=3, kernel_size=0.1, sh_degree=3, fused=False):
         for n in self.PARAM_NAMES:
             setattr(self, n, params[n])
+        # fused=True: the five getters are served by ONE fused HIP evaluation per (timestamp, parameter version)
+        # (ex4dgs_amd.attributes) instead of ~15 torch kernels + 3 torch.cat copies
+        self.fused = fused
+        self._fused_key = None
+        self._fused_out = None
         self.duration = max(duration, 1)
         self.interval = interval
         self.time_pad = time_pad
@@ -162,7 +167,21 @@ class DynamicGaussians:
         t = t + self.time_shift
         return int(t // self.interval), (t % self.interval) / self.interval
 
+    def evaluate_at_t(self, t):
+        """(means3D, rotations, opacities, scales, shs) through the fused HIP op; cached per (t, parameter versions) so the
+        reference's render(), which calls the five getters one after the other, triggers a single evaluation."""
+        from .attributes import evaluate_attributes
+        key = (t, torch.is_grad_enabled()) + tuple((p.data_ptr(), p._version, p.requires_grad) for p in self.parameters())
+        self._last_t = t
+        if key != self._fused_key:
+            self._fused_out = evaluate_attributes({n: getattr(self, n) for n in self.PARAM_NAMES}, t, duration=self.duration,
+                                                  interval=self.interval, time_shift=self.time_shift, var_pad=self.var_pad)
+            self._fused_key = key
+        return self._fused_out
+
     def get_xyz_at_t(self, t):
+        if self.fused:
+            return self.evaluate_at_t(t)[0]
         static = self._xyz + self._xyz_disp * t / self.duration               # :180
         if self.num_dynamic == 0:
             return static
@@ -172,6 +191,8 @@ class DynamicGaussians:
         return torch.cat([static, dyn], dim=0).contiguous()
 
     def get_rotation_at_t(self, t):
+        if self.fused:
+            return self.evaluate_at_t(t)[1]
         if self.num_dynamic == 0:
             return self._rotation                                             # :198 (raw, un-normalised)
         k, d = self._tk(t)
@@ -179,6 +200,8 @@ class DynamicGaussians:
         return torch.cat([self._rotation, _quat_slerp(y[:, k, :], y[:, k + 1, :], d)], dim=0).contiguous()
 
     def get_opacity_at_t(self, t):
+        if self.fused:
+            return self.evaluate_at_t(t)[2]
         static = torch.sigmoid(self._opacity)
         if self.num_dynamic == 0:
             return static
@@ -187,12 +210,20 @@ class DynamicGaussians:
                              var_min=self.var_pad / self.interval) * torch.sigmoid(self._opacity_motion)
         return torch.cat([static, o], dim=0).contiguous()
 
+    def _fused_time_independent(self, index):
+        # scales / features do not depend on t: reuse the evaluation of the timestamp the other getters asked for
+        return self.evaluate_at_t(getattr(self, "_last_t", 0))[index]
+
     def get_scaling(self):
+        if self.fused:
+            return self._fused_time_independent(3)
         if self.num_dynamic == 0:
             return torch.exp(self._scaling)
         return torch.exp(torch.cat([self._scaling, self._scaling_motion], dim=0))   # :335
 
     def get_features(self):
+        if self.fused:
+            return self._fused_time_independent(4)
         s = torch.cat((self._features_dc, self._features_rest), dim=1)
         if self.num_dynamic == 0:
             return s
@@ -231,7 +262,7 @@ CONFIGS = {
 }
 
 
-def make_scene(cfg, P=None, device="cpu", duration=300):
+def make_scene(cfg, P=None, device="cpu", duration=300, fused=False):
     """Returns (DynamicGaussians, Camera, bg[3]).  Distributions: SURVEY.md 8(d)."""
     if isinstance(cfg, str):
         cfg = CONFIGS[cfg]
@@ -267,7 +298,7 @@ def make_scene(cfg, P=None, device="cpu", duration=300):
         _opacity_duration_center=centers, _opacity_duration_var=N(Nd, 2, 1), _scaling_motion=torch.log(scale[Ns:]),
         _features_dc_motion=f_dc[Ns:], _features_rest_motion=f_rest[Ns:])
     params = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in params.items()}
-    model = DynamicGaussians(params, duration=duration)
+    model = DynamicGaussians(params, duration=duration, fused=fused)
     cam = focal_camera(cfg.width, cfg.height, cfg.focal, znear=0.01, zfar=100.0, cxr=cfg.cxr, cyr=cfg.cyr).to(device)
     bg = U(3).to(device)
     return model, cam, bg

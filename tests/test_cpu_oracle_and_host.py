@@ -210,6 +210,31 @@ def test_wrapper_marshalling_matches_reference_golden(monkeypatch):
     assert {k: (None if v.grad is None else float(v.grad.reshape(-1)[0])) for k, v in ins.items()} == gold["input_grad_tags"]
 
 
+def test_model_oracle_matches_reference_golden():
+    """oracle/model_oracle.py (numpy restatement of the getters + hand-derived backward) vs the reference's outputs and autograd grads."""
+    from oracle import model_oracle as mo
+    from ex4dgs_amd.scene import DynamicGaussians
+    z = np.load(os.path.join(GOLD, "model_getters.npz"))
+    shapes = {"_xyz_motion": (0, 35, 3), "_rotation_motion": (0, 35, 4), "_opacity_motion": (0, 1), "_opacity_duration_center": (0, 2, 1),
+              "_opacity_duration_var": (0, 2, 1), "_scaling_motion": (0, 3), "_features_dc_motion": (0, 1, 3), "_features_rest_motion": (0, 15, 3)}
+    for tag in ("small", "staticonly"):
+        p = {}
+        for n in DynamicGaussians.PARAM_NAMES:
+            a = z[f"{tag}/param/{n}"].astype(np.float32)
+            p[n] = a if a.size else np.zeros(shapes[n], np.float32)
+        w = dict(means3D=z[f"{tag}/weight/xyz"], rotations=z[f"{tag}/weight/rot"], opacities=z[f"{tag}/weight/opa"],
+                 scales=z[f"{tag}/weight/scl"], shs=z[f"{tag}/weight/fea"])
+        for t in (0, 7, 137, 290, 299):
+            o = mo.forward(p, t)
+            for k, a in (("xyz", "means3D"), ("rot", "rotations"), ("opa", "opacities"), ("scl", "scales"), ("fea", "shs")):
+                assert np.abs(o[a] - z[f"{tag}/t{t}/{k}"]).max() <= 1e-6, (tag, t, k)
+            g = mo.backward(p, t, w)
+            for n in DynamicGaussians.PARAM_NAMES:
+                key = f"{tag}/t{t}/grad/{n}"
+                if key in z.files:
+                    assert np.abs(g[n] - z[key]).max() <= 1e-5 * max(1.0, np.abs(z[key]).max()), (tag, t, n)
+
+
 def test_scene_generator_is_deterministic_and_in_spec():
     from ex4dgs_amd.scene import make_scene, CONFIGS
     a, cam, bg = make_scene("cfg3", P=5000)
@@ -234,6 +259,12 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     body = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", body)) - {"ex4d_alloc_fn"}
     assert declared == set(_C.EXPORTS), declared ^ set(_C.EXPORTS)
+    from ex4dgs_amd import attributes
+    hdr2 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_attributes.h")).read(), flags=re.S)
+    declared2 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr2))
+    assert declared2 == set(attributes.EXPORTS), declared2 ^ set(attributes.EXPORTS)
+    assert ctypes.sizeof(attributes.Ex4dAttrParams) == 13 * 4
+    declared |= declared2
     handle = ctypes.CDLL(lib)
     for name in declared:
         assert hasattr(handle, name), name
