@@ -103,6 +103,37 @@ def cpu_torch_baseline():
             "sample": f"cfg1: 256 static Gaussians, 256x256, oracle/oracle_torch.py dense pixels x Gaussians, fwd {1e3 * (t1 - t0):.0f} ms + autograd bwd {1e3 * (t2 - t1):.0f} ms"}
 
 
+def model_step_timing(cfg_name, dev, grads, steps=20, warmup=5, points=None):
+    """End-to-end training-step core on one GPU: per-frame attribute evaluation + rasterizer forward +
+    backward down to the model parameters, with the reference's torch getters vs the fused HIP op."""
+    from ex4dgs_amd.render import render
+    cfg = CONFIGS[cfg_name]
+    out = {}
+    for mode in ("torch_getters", "fused_getters"):
+        model, cam, bg = make_scene(cfg_name, P=points, device=dev, fused=(mode == "fused_getters"))
+        cam = cam.to(dev); bg = bg.to(dev)
+        for p in model.parameters():
+            p.requires_grad_(True)
+        stamps = [0, 137, 299]
+
+        def step(i):
+            for p in model.parameters():
+                p.grad = None
+            o = render(cam, model, None, bg, timestamp=stamps[i % 3], near=cfg.min_depth, far=cfg.max_depth, sync=False)
+            torch.autograd.backward([o["render"], o["depth"], o["opticalflow"], o["acc"]], grads)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        out[mode + "_ms_per_frame"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+        del model
+    out["what"] = "getters (xyz/rotation/opacity/scaling/features at t) + rasterizer fwd+bwd to the model parameters, 1 GPU"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +281,11 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + ("" if world == 1 else (" + async RCCL grad all-reduce" if buckets is not None else " (no collective)"))},
             "roofline": roof,
         }
+        if world == 1:
+            try:
+                line["model_step"] = model_step_timing(args.config, dev, grads, points=args.points)
+            except Exception as e:
+                line["model_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, P), my_stamps[0])
