@@ -228,7 +228,7 @@ def geom_views(geomBuffer, P):
     g = geomBuffer
     v = lambda off, n, dt: g[off: off + n * torch.empty(0, dtype=dt).element_size()].view(dt)
     rec = v(lay.records, 16 * P, torch.float32).view(P, 16)
-    return dict(records=rec, depths=rec[:, 8], means2D=rec[:, 0:2], conic_opacity=rec[:, 2:6], rgb=rec[:, 9:12], dir3D=rec[:, 12:15],
+    return dict(records=rec, depths=rec[:, 8], means2D=rec[:, 0:2], conic_opacity=rec[:, [2, 3, 4, 15]], rgb=rec[:, 9:12], dir3D=rec[:, 12:15],
                 cov3D=v(lay.cov3D, 6 * P, torch.float32).view(P, 6), clamped=v(lay.clamped, P, torch.uint8),
                 tiles_touched=v(lay.tiles_touched, P, torch.int32), depth_order=v(lay.depth_order, P, torch.int32))
 

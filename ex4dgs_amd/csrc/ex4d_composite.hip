@@ -57,27 +57,25 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 }
 
 // Can this Gaussian reach alpha >= 1/255 at ANY sample position inside [bx0,bx1]x[by0,by1]?
-// alpha = w*exp(-q(d)), q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  =>  needs  min_box q <= ln(255 w).
-// Conservative (never culls a pair the per-pixel test would accept): slack of 1% in alpha plus a
-// rounding allowance proportional to the magnitude of the terms; anything not provably convex is kept.
-__device__ __forceinline__ bool quadrant_cull(float mx, float my, float A, float B, float C, float w,
+// alpha = w*exp(-q(d)), q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  =>  needs  min_box q <= ln(255 w) =: tau.
+// Conservative (never culls a pair the per-pixel test would accept): tau carries a slack of 1% in alpha, plus a
+// rounding allowance proportional to the magnitude of the terms.  tau, k1 = -B/C and k2 = -B/A come precomputed
+// from the preprocess kernel (tau = -inf: w < 1/255, cull always; tau = +inf: conic not provably convex, keep).
+__device__ __forceinline__ bool quadrant_cull(float mx, float my, float A, float B, float C, float tau, float k1, float k2,
                                               float bx0, float bx1, float by0, float by1)
 {
-    if (w < (1.0f / 255.0f)) return true;                  // exp(power) <= 1 => alpha < 1/255 everywhere
-    if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return false;
     const float dxc = fminf(fmaxf(mx, bx0), bx1) - mx;     // nearest box point - mean (0 if inside the slab)
     const float dyc = fminf(fmaxf(my, by0), by1) - my;
-    if (dxc == 0.f && dyc == 0.f) return false;
-    const float tau = __logf(255.0f * w) + 0.01f;
+    if (dxc == 0.f && dyc == 0.f) return tau < -3.0e38f;   // mean inside the box: only a never-visible Gaussian is culled
     float qmin = 3.0e38f, mag = 0.f;
     if (dxc != 0.f) {       // facing vertical edge: minimise over dy
-        const float dy = fminf(fmaxf(-B * dxc / C, by0 - my), by1 - my);
+        const float dy = fminf(fmaxf(k1 * dxc, by0 - my), by1 - my);
         const float t1 = 0.5f * A * dxc * dxc, t2 = 0.5f * C * dy * dy, t3 = B * dxc * dy;
         const float q = t1 + t2 + t3;
         if (q < qmin) { qmin = q; mag = fabsf(t1) + fabsf(t2) + fabsf(t3); }
     }
     if (dyc != 0.f) {       // facing horizontal edge: minimise over dx
-        const float dx = fminf(fmaxf(-B * dyc / A, bx0 - mx), bx1 - mx);
+        const float dx = fminf(fmaxf(k2 * dyc, bx0 - mx), bx1 - mx);
         const float t1 = 0.5f * A * dx * dx, t2 = 0.5f * C * dyc * dyc, t3 = B * dx * dyc;
         const float q = t1 + t2 + t3;
         if (q < qmin) { qmin = q; mag = fabsf(t1) + fabsf(t2) + fabsf(t3); }
@@ -157,24 +155,25 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
         bool keep = false;
         uint32_t id = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 q1 = make_float2(0.f, 0.f);
+        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < n) {
             id = point_list[range.x + k];
             const float4 *r = records + 4 * (size_t)id;
             q0 = r[0];
-            q1 = *reinterpret_cast<const float2 *>(r + 1);
-            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, bx0, bx1, by0, by1);
+            q1 = r[1];
+            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
         }
         const uint64_t mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
             const int slot = __popcll(mask & lt);
             const float4 *r = records + 4 * (size_t)id;
+            const float4 q3 = r[3];
             // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
             s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
-            s_q1[wave][slot] = make_float2(q1.x * kHalfLog2e, q1.y);
+            s_q1[wave][slot] = make_float2(q1.x * kHalfLog2e, q3.w);
             s_q2[wave][slot] = r[2];
-            s_q3[wave][slot] = r[3];
+            s_q3[wave][slot] = q3;
             s_id[wave][slot] = id;
             s_orig[wave][slot] = (uint32_t)k;
         }
@@ -331,20 +330,20 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
         bool keep = false;
         uint32_t id = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 q1 = make_float2(0.f, 0.f);
+        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k >= 0) {
             id = point_list[range.x + k];
             const float4 *r = records + 4 * (size_t)id;
             q0 = r[0];
-            q1 = *reinterpret_cast<const float2 *>(r + 1);
-            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, bx0, bx1, by0, by1);
+            q1 = r[1];
+            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
         }
         const uint64_t mask = __ballot(keep);
         const int cnt = __popcll(mask);
         if (keep) {
             const int slot = __popcll(mask & lt);
             s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
-            s_q1[wave][slot] = make_float4(q1.x * kHalfLog2e, q1.y, 0.f, 0.f);
+            s_q1[wave][slot] = make_float4(q1.x * kHalfLog2e, records[4 * (size_t)id + 3].w, 0.f, 0.f);
             s_q2[wave][slot] = records[4 * (size_t)id + 2];
             s_id[wave][slot] = id;
             s_orig[wave][slot] = (uint32_t)k;

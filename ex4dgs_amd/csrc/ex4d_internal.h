@@ -14,9 +14,9 @@ static inline size_t ex4d_align_up(size_t x) { return (x + (EX4D_ALIGN - 1)) & ~
 // One 64-byte record per Gaussian, written by preprocess_fwd for visible Gaussians, gathered by the
 // compositing kernels (one cache line per gather):
 //   float4 #0: mean2D.x, mean2D.y, conic.x (A), conic.y (B)
-//   float4 #1: conic.z (C), opacity*coef (w), 0, 0
+//   float4 #1: conic.z (C), tau, k1 = -B/C, k2 = -B/A   (cull constants: tau = ln(255 w) + 0.01, +-inf = never / always cull)
 //   float4 #2: depth (p_view.z), r, g, b          (SH colour or colors_precomp)
-//   float4 #3: dir3D.x, dir3D.y, dir3D.z, 0       (per-Gaussian "flow" channel, zeros if absent)
+//   float4 #3: dir3D.x, dir3D.y, dir3D.z, w       (per-Gaussian "flow" channel, zeros if absent; w = opacity*coef)
 #define EX4D_RECORD_FLOATS 16
 
 struct GeomState {

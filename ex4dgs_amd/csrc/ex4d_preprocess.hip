@@ -352,12 +352,21 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             }
             clamped[idx] = clamp_bits;
         }
+        // per-Gaussian constants of the compositing kernels' quadrant cull (ex4d_composite.hip), evaluated once here
+        // instead of once per (Gaussian, tile, quadrant): tau = ln(255 w) + 1 % slack is the largest value of the quadratic
+        // form q(d) that still reaches alpha >= 1/255; -inf = never contributes (w < 1/255), +inf = never cull (conic
+        // not provably positive definite); k1, k2 = minimisers of q along a vertical / horizontal box edge
+        const float w_op = opacities[idx] * coef;
+        float tau;
+        if (w_op < (1.0f / 255.0f)) tau = -__builtin_inff();
+        else if (!(conic.x > 0.f && conic.z > 0.f && conic.x * conic.z - conic.y * conic.y > 0.f)) tau = __builtin_inff();
+        else tau = logf(255.0f * w_op) + 0.01f;
         float4 *rec = records + 4 * (size_t)idx;
         rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
-        rec[1] = make_float4(conic.z, opacities[idx] * coef, 0.f, 0.f);
+        rec[1] = make_float4(conic.z, tau, -conic.y / conic.z, -conic.y / conic.x);
         rec[2] = make_float4(depth, res[0], res[1], res[2]);
-        rec[3] = dir3D ? make_float4(dir3D[3 * (size_t)idx], dir3D[3 * (size_t)idx + 1], dir3D[3 * (size_t)idx + 2], 0.f)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[3] = dir3D ? make_float4(dir3D[3 * (size_t)idx], dir3D[3 * (size_t)idx + 1], dir3D[3 * (size_t)idx + 2], w_op)
+                       : make_float4(0.f, 0.f, 0.f, w_op);
     }
     if (in_range) {
         radii[idx] = out_radius;

@@ -135,8 +135,8 @@ size_t ex4d_img_bytes(int32_t W, int32_t H);
  * (reference counterparts: GeometryState / BinningState / ImageState, rasterizer_impl.h:29-65) */
 typedef struct Ex4dGeomLayout {
     size_t records;         /* float[P][16]        one 64-byte record per Gaussian:
-                                                   [0..1] mean2D, [2..4] conic.xyz, [5] opacity*coef, [8] depth (p_view.z),
-                                                   [9..11] rgb (SH colour or colors_precomp), [12..14] dir3D */
+                                                   [0..1] mean2D, [2..4] conic.xyz, [5..7] cull constants, [8] depth (p_view.z),
+                                                   [9..11] rgb (SH colour or colors_precomp), [12..14] dir3D, [15] opacity*coef */
     size_t cov3D;           /* float[6P] */
     size_t clamped;         /* uint8[P]            bit c set <=> channel c clamped at 0 (forward.cu:67-69) */
     size_t tiles_touched;   /* uint32[P] */
