@@ -256,10 +256,18 @@ def main():
     if dom == "tile_sort" or dom == "depth_sort":
         dom_bytes = stage_bytes["sort"]
     roof = None
+    traffic = None
+    try:   # HBM bytes per launch from the PMC passes committed under profiles/ (collected with tools/pmc.sh, not in this run)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
+            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if dom is not None and dom_bytes:
         achieved = dom_bytes / (agg[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel_ms": round(agg[dom], 4), "algorithmic_bytes": int(dom_bytes),
                 "frame": {"A_fwd_bytes": int(A_fwd), "A_bwd_bytes": int(A_bwd), "A_bytes": int(A),
                           "achieved_GBps_walltime": round(A / (ms_per_step * 1e-3) / 1e9, 1),

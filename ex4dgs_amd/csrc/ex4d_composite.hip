@@ -25,7 +25,6 @@
 // to the oracle within 1e-5, not bit-exactly) and exp() is the hardware v_exp_f32.
 #include "ex4d_internal.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
-#include <cstdlib>
 
 namespace {
 
@@ -273,7 +272,7 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane)
     return r;
 }
 
-template <int WPB, int EXPERIMENT>
+template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -403,17 +402,8 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             v[4] = sdx * dy;
             v[5] = (sG * dy) * dy;
             v[6] = G_m * (dL_dalpha + gacc);
-            if (EXPERIMENT == 2) {
-                float t = 0.f;
-#pragma unroll
-                for (int i = 0; i < 13; i++) t += v[i];
-                if (t == 123.456f) acc16[lane] = t;
-            } else {
-                const float r = reduce_scatter16(v, lane);
-                if (EXPERIMENT == 1) { if (r == 123.456f) acc16[lane] = r; }
-                else if (EXPERIMENT == 3) { if (writer) acc16[16 * (size_t)s_id[wave][j] + which] = r; }
-                else if (writer) unsafeAtomicAdd(&acc16[16 * (size_t)s_id[wave][j] + which], r);
-            }
+            const float r = reduce_scatter16(v, lane);
+            if (writer) unsafeAtomicAdd(&acc16[16 * (size_t)s_id[wave][j] + which], r);
         }
         wave_lds_sync();
     }
@@ -427,15 +417,9 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    static const int wpb = getenv("EX4D_WPB") ? atoi(getenv("EX4D_WPB")) : 4;
-    if (wpb == 1)
-        hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(32 * ((T + 7) / 8)), dim3(64), 0, stream,
-            prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-            prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
-    else
-        hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
-            prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-            prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
+    hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
+        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
+        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
     return hipGetLastError();
 }
 
@@ -446,17 +430,8 @@ hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges,
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    static const int experiment = getenv("EX4D_EXPERIMENT") ? atoi(getenv("EX4D_EXPERIMENT")) : 0;
-    static const int wpb = getenv("EX4D_WPB") ? atoi(getenv("EX4D_WPB")) : 4;
-    if (wpb == 1) {
-        hipLaunchKernelGGL((composite_bwd_kernel<1, 0>), dim3(32 * ((T + 7) / 8)), dim3(64), 0, stream,
-            prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records,
-            out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16);
-        return hipGetLastError();
-    }
-#define LAUNCH_BWD(E) hipLaunchKernelGGL((composite_bwd_kernel<4, E>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, \
-        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, \
-        out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16)
-    if (experiment == 1) LAUNCH_BWD(1); else if (experiment == 2) LAUNCH_BWD(2); else if (experiment == 3) LAUNCH_BWD(3); else LAUNCH_BWD(0);
+    hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
+        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records,
+        out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16);
     return hipGetLastError();
 }
