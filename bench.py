@@ -129,8 +129,30 @@ def model_step_timing(cfg_name, dev, grads, steps=20, warmup=5, points=None):
             step(i)
         torch.cuda.synchronize()
         out[mode + "_ms_per_frame"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+
+        # the loss-driven iteration of train.py:126-153: getters -> render -> L1+SSIM loss (+ error maps) -> backward
+        from ex4dgs_amd.loss import l1_ssim_loss, l1_ssim_loss_unfused
+        loss_fn = l1_ssim_loss if mode == "fused_getters" else l1_ssim_loss_unfused
+        gt = torch.rand(3, cfg.height, cfg.width, device=dev)
+
+        def train_iter(i):
+            for p in model.parameters():
+                p.grad = None
+            o = render(cam, model, None, bg, timestamp=stamps[i % 3], near=cfg.min_depth, far=cfg.max_depth, sync=False)
+            loss, _l1e, _sse = loss_fn(o["render"], gt, 0.2)
+            loss.backward()
+        for i in range(warmup):
+            train_iter(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            train_iter(i)
+        torch.cuda.synchronize()
+        out[("fused" if mode == "fused_getters" else "torch") + "_host_side_train_iter_ms"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
         del model
-    out["what"] = "getters (xyz/rotation/opacity/scaling/features at t) + rasterizer fwd+bwd to the model parameters, 1 GPU"
+    out["what"] = ("*_getters_ms_per_frame: getters (xyz/rotation/opacity/scaling/features at t) + rasterizer fwd+bwd to the model "
+                   "parameters; *_train_iter_ms: the same plus the L1+SSIM loss and error maps of train.py:144-151 "
+                   "(torch = the reference's op composition, fused = ex4d_attributes + ex4d_l1_ssim); 1 GPU, same HIP rasterizer in both")
     return out
 
 

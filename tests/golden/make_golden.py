@@ -5,6 +5,7 @@ What is captured:
   model_getters.npz  CGaussianModel per-frame getters (scene/c_gaussian_model.py:170-215,330-375) + autograd grads
   sh_eval.npz        utils/sh_utils.eval_sh outputs (independent check of the SH->RGB restatement)
   cameras.npz        getWorld2View2 / getProjectionMatrix / getProjectionMatrixCV / Cameravideo matrix block
+  loss_l1_ssim.npz   utils/loss_utils.l1_loss + ssim (train.py:144-151 combination) outputs + autograd grads
   marshalling.json   positional-argument order the reference wrapper hands to _C (DGR/py:64-89, :120-149)
 
 Run:  python tests/golden/make_golden.py      (needs /root/reference; third-party deps are stubbed)
@@ -119,6 +120,36 @@ def golden_cameras():
     return len(out)
 
 
+def golden_loss():
+    from utils.loss_utils import l1_loss, ssim
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = {"noise": (3, 37, 53), "smooth": (3, 48, 40), "tiny": (3, 7, 9)}
+    for name, (Cn, H, W) in cases.items():
+        if name == "smooth":                      # low-variance image: the C2-stabilised branch of the SSIM ratio
+            yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+            gt = np.stack([0.5 + 0.3 * np.sin(3 * xx + c) * np.cos(2 * yy) for c in range(Cn)]).astype(np.float32)
+            img = (gt + 0.02 * rng.standard_normal(gt.shape)).astype(np.float32)
+        else:
+            gt = rng.random((Cn, H, W), dtype=np.float32)
+            img = np.clip(gt + 0.2 * rng.standard_normal(gt.shape), 0, 1).astype(np.float32)
+        for lam in (0.2, 0.5):
+            x = torch.tensor(img, requires_grad=True)
+            y = torch.tensor(gt)
+            Ll1 = l1_loss(x, y)
+            loss = (1.0 - lam) * Ll1 + lam * (1.0 - ssim(x, y))              # train.py:144-145
+            loss.backward()
+            with torch.no_grad():
+                l1e = (x - y).abs().mean(dim=0)                              # train.py:149
+                sse = ssim(x, y, reduce=False).mean(dim=0)                   # train.py:150
+            k = f"{name}/lam{lam}/"
+            out[k + "loss"] = np.float32(loss.item()); out[k + "Ll1"] = np.float32(Ll1.item())
+            out[k + "grad"] = x.grad.numpy().copy(); out[k + "l1_errors"] = l1e.numpy(); out[k + "ssim_errors"] = sse.numpy()
+        out[name + "/image"] = img; out[name + "/gt"] = gt
+    np.savez_compressed(os.path.join(OUT, "loss_l1_ssim.npz"), **out)
+    return len(out)
+
+
 def golden_marshalling():
     """Drive the reference's autograd wrapper with a recording stub `_C` and store which input lands in
     which positional slot (by tagging each tensor with a unique first element)."""
@@ -185,4 +216,5 @@ if __name__ == "__main__":
     print("model_getters:", golden_model_getters())
     print("sh_eval:", golden_sh())
     print("cameras:", golden_cameras())
+    print("loss:", golden_loss())
     print("marshalling:", golden_marshalling())

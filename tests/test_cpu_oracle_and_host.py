@@ -250,6 +250,34 @@ def test_scene_generator_is_deterministic_and_in_spec():
     assert abs(float(a.get_rotation_at_t(299)[4000:].norm(dim=-1).mean()) - 1.0) < 1e-5       # slerp output is normalised
 
 
+# ------------------------------------------------------------------ 8f-2: L1 + SSIM loss oracle pinned by reference goldens
+def test_loss_oracle_matches_reference_goldens():
+    from oracle import loss_oracle
+    from ex4dgs_amd import loss as loss_mod
+    g = np.load(os.path.join(h.ROOT, "tests", "golden", "loss_l1_ssim.npz"))
+    assert np.array_equal(loss_mod.gaussian_window(), loss_oracle.window_1d().numpy())
+    for name in ("noise", "smooth", "tiny"):
+        for lam in (0.2, 0.5):
+            k = f"{name}/lam{lam}/"
+            # float32 evaluation of the oracle = the reference's arithmetic: tight; float64 = what the GPU is held to
+            r32 = loss_oracle.l1_ssim(g[name + "/image"], g[name + "/gt"], lam, dtype=torch.float32)
+            r64 = loss_oracle.l1_ssim(g[name + "/image"], g[name + "/gt"], lam)
+            assert abs(r32["loss"] - g[k + "loss"]) < 2e-7
+            np.testing.assert_allclose(r32["grad"], g[k + "grad"], rtol=0, atol=1e-8 + 1e-5 * np.abs(g[k + "grad"]).max())
+            np.testing.assert_allclose(r32["l1_errors"], g[k + "l1_errors"], rtol=0, atol=1e-7)
+            np.testing.assert_allclose(r32["ssim_errors"], g[k + "ssim_errors"], rtol=0, atol=2e-5)
+            # the reference's own float32 rounding against exact arithmetic: SSIM in flat regions is ill-conditioned (1/C2)
+            assert abs(r64["loss"] - g[k + "loss"]) < 2e-6
+            np.testing.assert_allclose(r64["grad"], g[k + "grad"], rtol=0, atol=1e-3 * np.abs(g[k + "grad"]).max())
+            np.testing.assert_allclose(r64["ssim_errors"], g[k + "ssim_errors"], rtol=0, atol=5e-4)
+
+
+def test_loss_refuses_cpu_tensors():
+    from ex4dgs_amd.loss import l1_ssim_loss
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        l1_ssim_loss(torch.zeros(3, 8, 8), torch.zeros(3, 8, 8), 0.2)
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
@@ -264,7 +292,11 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     declared2 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr2))
     assert declared2 == set(attributes.EXPORTS), declared2 ^ set(attributes.EXPORTS)
     assert ctypes.sizeof(attributes.Ex4dAttrParams) == 13 * 4
-    declared |= declared2
+    from ex4dgs_amd import loss as loss_mod
+    hdr3 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_loss.h")).read(), flags=re.S)
+    declared3 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr3))
+    assert declared3 == set(loss_mod.EXPORTS), declared3 ^ set(loss_mod.EXPORTS)
+    declared |= declared2 | declared3
     handle = ctypes.CDLL(lib)
     for name in declared:
         assert hasattr(handle, name), name
