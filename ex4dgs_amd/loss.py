@@ -3,6 +3,7 @@ include/ex4d_loss.h, instead of the reference's l1_loss + ssim and their autogra
 (utils/loss_utils.py:22-25, :47-81 as combined by train.py:144-151 of the reference).
 
     loss, l1_errors, ssim_errors = l1_ssim_loss(image, gt_image, lambda_dssim)
+    loss, l1_errors, ssim_errors, hook_tensor = l1_ssim_loss(image, gt_image, lambda_dssim, acc=acc)
 
 `loss` is differentiable w.r.t. `image`; the two [H,W] error maps are the per-pixel channel means the reference hands
 to its densification statistics (train.py:149-150) and carry no gradient.  No CPU fallback.
@@ -44,7 +45,7 @@ def _lib():
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, gt, lambda_dssim):
+    def forward(ctx, image, gt, lambda_dssim, errors):
         lib = _lib()
         if not image.is_cuda:
             raise RuntimeError(f"image is on {image.device}: the fused L1+SSIM loss only runs on a ROCm GPU (no CPU fallback)")
@@ -54,7 +55,7 @@ class _L1SSIM(torch.autograd.Function):
         Cn, H, W = image.shape
         f32 = dict(dtype=torch.float32, device=image.device)
         loss = torch.empty(1, **f32)
-        l1e, sse = torch.empty(H, W, **f32), torch.empty(H, W, **f32)
+        l1e, sse = errors if errors is not None else (torch.empty(H, W, **f32), torch.empty(H, W, **f32))
         dmaps = torch.empty(3, Cn, H, W, **f32)
         scratch = torch.empty(lib.ex4d_l1_ssim_scratch_floats(H, W), **f32)
         with torch.cuda.device(image.device):
@@ -80,12 +81,21 @@ class _L1SSIM(torch.autograd.Function):
                                            g.data_ptr(), grad.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(lib.ex4d_loss_last_error().decode())
-        return grad, None, None
+        return grad, None, None, None
 
 
-def l1_ssim_loss(image, gt_image, lambda_dssim=0.2):
-    """(loss, l1_errors[H,W], ssim_errors[H,W]) of train.py:144-151 for a [C,H,W] render and its ground truth."""
-    return _L1SSIM.apply(image, gt_image, lambda_dssim)
+def l1_ssim_loss(image, gt_image, lambda_dssim=0.2, acc=None):
+    """(loss, l1_errors[H,W], ssim_errors[H,W]) of train.py:144-151 for a [C,H,W] render and its ground truth.
+    With `acc` (the rasterizer's [1,H,W] accumulation output) a fourth value is returned: the [3,H,W] tensor
+    stack([acc[0], l1_errors, ssim_errors]) the reference installs as the gradient of the flow image (train.py:151-152);
+    the two error maps are then written straight into it (they are views of it)."""
+    if acc is None:
+        return _L1SSIM.apply(image, gt_image, lambda_dssim, None)
+    H, W = image.shape[-2:]
+    hook = torch.empty(3, H, W, dtype=torch.float32, device=image.device)
+    hook[0].copy_(acc.detach()[0])
+    loss, l1e, sse = _L1SSIM.apply(image, gt_image, lambda_dssim, (hook[1], hook[2]))
+    return loss, l1e, sse, hook
 
 
 def l1_ssim_loss_unfused(image, gt_image, lambda_dssim=0.2):

@@ -458,8 +458,9 @@ def test_fused_loss_on_a_render_full_size_and_upstream_scale(hip_lib):
     assert torch.equal(l1, l2) and torch.equal(a1, a2) and torch.equal(s1, s2)
     torch.testing.assert_close(g3, 3.0 * img_leaf.grad, rtol=1e-6, atol=0)
     _check_loss(hip_lib, image.detach().cpu().numpy(), gt.cpu().numpy(), 0.2, flat=True)
-    # end to end: the loss backpropagates into the Gaussians through the rasterizer
-    loss, _, _ = l1_ssim_loss(image, gt, 0.2)
+    # end to end: the loss backpropagates into the Gaussians through the rasterizer; the hook tensor of train.py:151
+    loss, l1e, sse, hook = l1_ssim_loss(image, gt, 0.2, acc=out["acc"])
+    assert torch.equal(hook, torch.stack([out["acc"].detach()[0], a1, s1])) and torch.equal(l1e, a1) and torch.equal(loss.detach(), l1.detach())
     loss.backward()
     gsum = sum(float(p.grad.abs().sum()) for p in model.parameters() if p.grad is not None)
     assert np.isfinite(gsum) and gsum > 0
