@@ -1,0 +1,126 @@
+// Fused multi-tensor RAdam step for gfx950.
+//
+// torch.optim.RAdam over the reference's 15 parameter groups (scene/c_gaussian_model.py:430-449) runs ~10 element-wise
+// passes per tensor: 3.2 ms per step for the 110 M parameters of a 1 M-Gaussian model on MI355X.  This is one launch that
+// streams every tensor once: p, m, v read+write and g read = 28 B/element, 3.07 GB -> 0.38 ms at the 8 TB/s roofline.
+// HBM-bound streaming: 16-byte loads/stores, 4096-element chunks, a chunk table in kernel arguments maps workgroups to
+// tensors.  ffp-contract is off for this file: the update follows torch's op order in float32.
+#include "ex4d_internal.h"
+#include "../../include/ex4d_optim.h"
+#include <cmath>
+#include <cstdio>
+
+namespace {
+
+#define RADAM_CHUNK 4096          // elements per workgroup (256 threads x 4 float4)
+
+struct RadamSlot {
+    float *p; const float *g; float *m; float *v;
+    long long numel;
+    float w1;          // 1 - beta1
+    float beta2;
+    float w2;          // 1 - beta2
+    float bc1;         // 1 - beta1^t
+    float lr;
+    float sqrt_bc2;    // sqrt(1 - beta2^t)
+    float rect;        // variance rectification, valid when rectified
+    float eps;
+    int rectified;     // rho_t > 5
+    unsigned first_chunk;   // index of this tensor's first chunk in the launch
+};
+
+struct RadamArgs { RadamSlot slot[EX4D_RADAM_MAX_TENSORS]; int count; };
+
+__device__ __forceinline__ void radam_update(float &p, const float g, float &m, float &v, const RadamSlot &s)
+{
+    m = m + s.w1 * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * s.beta2;                              // exp_avg_sq.mul_(beta2)
+    v = v + (s.w2 * g) * g;                       //           .addcmul_(grad, grad, value=1 - beta2)
+    const float mhat = m / s.bc1;
+    float upd = mhat * s.lr;
+    if (s.rectified) {
+        const float adaptive = s.sqrt_bc2 / (sqrtf(v) + s.eps);
+        upd = (upd * adaptive) * s.rect;
+    }
+    p = p - upd;
+}
+
+__global__ __launch_bounds__(256) void radam_kernel(const RadamArgs a)
+{
+    // which tensor owns this chunk (<= 32 slots, wave-uniform scan)
+    int t = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.count; i++) if (blockIdx.x >= a.slot[i].first_chunk) t = i;
+    const RadamSlot &s = a.slot[t];
+    const long long base = (long long)(blockIdx.x - s.first_chunk) * RADAM_CHUNK;
+    const long long n = s.numel - base < RADAM_CHUNK ? s.numel - base : RADAM_CHUNK;
+    float *p = s.p + base; const float *g = s.g + base; float *m = s.m + base; float *v = s.v + base;
+    const bool vec = n == RADAM_CHUNK && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = k * 256 + threadIdx.x;
+            float4 pp = ((float4 *)p)[i], mm = ((float4 *)m)[i], vv = ((float4 *)v)[i];
+            const float4 gg = ((const float4 *)g)[i];
+            radam_update(pp.x, gg.x, mm.x, vv.x, s); radam_update(pp.y, gg.y, mm.y, vv.y, s);
+            radam_update(pp.z, gg.z, mm.z, vv.z, s); radam_update(pp.w, gg.w, mm.w, vv.w, s);
+            ((float4 *)p)[i] = pp; ((float4 *)m)[i] = mm; ((float4 *)v)[i] = vv;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            radam_update(pp, g[i], mm, vv, s);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+    }
+}
+
+thread_local char g_optim_err[256] = "";
+
+}  // namespace
+
+extern "C" {
+
+const char *ex4d_optim_last_error(void) { return g_optim_err; }
+
+int ex4d_radam_step(const Ex4dRadamTensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream_)
+{
+    g_optim_err[0] = 0;
+    if (count < 0 || count > EX4D_RADAM_MAX_TENSORS || (count > 0 && !tensors)) {
+        snprintf(g_optim_err, sizeof(g_optim_err), "count %d outside [0, %d]", count, EX4D_RADAM_MAX_TENSORS);
+        return EX4D_ERR_ARG;
+    }
+    RadamArgs a;
+    a.count = 0;
+    unsigned chunks = 0;
+    const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
+    for (int i = 0; i < count; i++) {
+        const Ex4dRadamTensor &t = tensors[i];
+        if (t.numel == 0) continue;
+        if (t.numel < 0 || t.step < 1 || !t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) {
+            snprintf(g_optim_err, sizeof(g_optim_err), "tensor %d: null pointer, negative size or step < 1", i);
+            return EX4D_ERR_ARG;
+        }
+        RadamSlot &s = a.slot[a.count++];
+        s.p = t.param; s.g = t.grad; s.m = t.exp_avg; s.v = t.exp_avg_sq; s.numel = t.numel;
+        // the Python-double scalar arithmetic of torch's RAdam, cast to float32 where it meets a tensor
+        const double step = (double)t.step;
+        const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
+        const double rho_t = rho_inf - 2.0 * step * std::pow(beta2, step) / bc2;
+        s.w1 = (float)(1.0 - beta1); s.beta2 = (float)beta2; s.w2 = (float)(1.0 - beta2);
+        s.bc1 = (float)bc1; s.lr = (float)t.lr; s.sqrt_bc2 = (float)std::sqrt(bc2); s.eps = (float)eps;
+        s.rectified = rho_t > 5.0;
+        s.rect = s.rectified ? (float)std::sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) : 0.f;
+        s.first_chunk = chunks;
+        const long long c = (t.numel + RADAM_CHUNK - 1) / RADAM_CHUNK;
+        if (c + chunks > 0x7fffffffLL) { snprintf(g_optim_err, sizeof(g_optim_err), "too many elements for one launch"); return EX4D_ERR_ARG; }
+        chunks += (unsigned)c;
+    }
+    if (chunks == 0) return EX4D_OK;
+    hipLaunchKernelGGL(radam_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream_, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_optim_err, sizeof(g_optim_err), "launch failed: %s", hipGetErrorString(e)); return EX4D_ERR_HIP; }
+    return EX4D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+"""Fused RAdam: a torch.optim.Optimizer with the constructor, param-group and state layout of
+`torch.optim.RAdam` -- what the reference builds at scene/c_gaussian_model.py:449 and steps at train.py:250 -- whose
+step() is ONE HIP launch over every parameter tensor (include/ex4d_optim.h) instead of ~10 element-wise passes per tensor.
+
+State per parameter: {"step": float32 CPU scalar tensor, "exp_avg", "exp_avg_sq"} -- the same keys and shapes as
+torch.optim.RAdam, so the reference's densification code that edits optimizer state in place
+(c_gaussian_model.py: replace_tensor_to_optimizer / _prune_optimizer / cat_tensors_to_optimizer) works unchanged.
+No CPU fallback: parameters must live on a ROCm device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+
+EXPORTS = ("ex4d_optim_last_error", "ex4d_radam_step")
+MAX_TENSORS = 32
+
+
+class Ex4dRadamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
+
+
+def _lib():
+    lib = _C.load()
+    if not getattr(lib, "_optim_ready", False):
+        lib.ex4d_optim_last_error.restype = C.c_char_p
+        lib.ex4d_radam_step.restype = C.c_int
+        lib.ex4d_radam_step.argtypes = [C.POINTER(Ex4dRadamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        lib._optim_ready = True
+    return lib
+
+
+class FusedRAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if weight_decay != 0:
+            raise ValueError("FusedRAdam: weight_decay is not used by the reference (c_gaussian_model.py:449) and is not implemented")
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("FusedRAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib()
+        batches = {}                               # (device, betas, eps) -> descriptors
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue                       # like torch: tensors without a gradient keep their step count
+                if not p.is_cuda:
+                    raise RuntimeError(f"parameter on {p.device}: FusedRAdam only runs on a ROCm GPU (no CPU fallback)")
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous():
+                    raise RuntimeError("FusedRAdam: parameters and gradients must be dense contiguous float32")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous()):
+                    raise RuntimeError("FusedRAdam: optimizer state must be contiguous")
+                key = (p.device, tuple(group["betas"]), float(group["eps"]))
+                batches.setdefault(key, []).append(
+                    (Ex4dRadamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(group["lr"]), int(state["step"].item())), g))
+        for (dev, betas, eps), items in batches.items():
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for i in range(0, len(items), MAX_TENSORS):
+                    chunk = items[i:i + MAX_TENSORS]
+                    arr = (Ex4dRadamTensor * len(chunk))(*[c[0] for c in chunk])
+                    if lib.ex4d_radam_step(arr, len(chunk), betas[0], betas[1], eps, stream):
+                        raise RuntimeError(lib.ex4d_optim_last_error().decode())
+        return loss

@@ -1,0 +1,45 @@
+/*
+ * ex4d_optim.h -- C ABI of the fused multi-tensor RAdam step.
+ *
+ * Replaces `gaussians.optimizer.step()` (train.py:250 of the reference) for the optimizer the reference builds at
+ * scene/c_gaussian_model.py:449, `torch.optim.RAdam(l, lr=0.001)` over 15 parameter groups with per-group learning rates
+ * (:430-447; defaults betas=(0.9, 0.999), eps=1e-8, weight_decay=0).  torch.optim is a third-party dependency of the
+ * reference (environment.yml:10 pins pytorch=2.1.2); the algorithm restated here is its documented one
+ * (Liu et al., "On the Variance of the Adaptive Learning Rate and Beyond", as implemented by torch's _single_tensor_radam):
+ *     m <- m + (1-b1)(g - m);  v <- b2 v + (1-b2) g g;  mhat = m / (1 - b1^t)
+ *     rho_t = rho_inf - 2 t b2^t / (1 - b2^t),  rho_inf = 2/(1-b2) - 1
+ *     rho_t > 5:  p <- p - mhat * lr * sqrt(1 - b2^t)/(sqrt(v) + eps) * rect(rho_t)        else   p <- p - mhat * lr
+ * One launch updates every tensor: 28 bytes of HBM traffic per element (p, m, v read+write, g read), nothing else.
+ * All scalar coefficients are computed on the host in double precision exactly like the Python scalars of torch.
+ */
+#ifndef EX4D_OPTIM_H_INCLUDED
+#define EX4D_OPTIM_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EX4D_RADAM_MAX_TENSORS 32
+
+typedef struct Ex4dRadamTensor {
+    float *param;            /* device, updated in place */
+    const float *grad;       /* device */
+    float *exp_avg;          /* device, updated in place */
+    float *exp_avg_sq;       /* device, updated in place */
+    int64_t numel;
+    double lr;               /* the group's learning rate for this step */
+    int64_t step;            /* t: the tensor's step count AFTER this step's increment (>= 1) */
+} Ex4dRadamTensor;
+
+const char *ex4d_optim_last_error(void);
+
+/* tensors: HOST array of `count` descriptors (count <= EX4D_RADAM_MAX_TENSORS per call).  stream: hipStream_t. */
+int ex4d_radam_step(const Ex4dRadamTensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,3 +23,12 @@ for foreach in (None, False):
         opt.zero_grad(set_to_none=True)
         for p in params: p.grad = torch.empty_like(p)
     torch.cuda.synchronize(); print(f"  zero_grad+realloc: {1e3 * (time.perf_counter() - t0) / 20:.3f} ms")
+from ex4dgs_amd.optim import FusedRAdam
+opt = FusedRAdam(groups, lr=0.001)
+for p in params:
+    p.grad = torch.randn_like(p)
+for _ in range(8): opt.step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): opt.step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+print(f"FusedRAdam: {1e3 * dt:.3f} ms/step = {28 * n / dt / 1e12:.2f} TB/s of 28 B/element")

@@ -6,6 +6,7 @@ What is captured:
   sh_eval.npz        utils/sh_utils.eval_sh outputs (independent check of the SH->RGB restatement)
   cameras.npz        getWorld2View2 / getProjectionMatrix / getProjectionMatrixCV / Cameravideo matrix block
   loss_l1_ssim.npz   utils/loss_utils.l1_loss + ssim (train.py:144-151 combination) outputs + autograd grads
+  radam.npz          torch.optim.RAdam (c_gaussian_model.py:449 call, per-group lr) parameter/state trajectories
   marshalling.json   positional-argument order the reference wrapper hands to _C (DGR/py:64-89, :120-149)
 
 Run:  python tests/golden/make_golden.py      (needs /root/reference; third-party deps are stubbed)
@@ -150,6 +151,37 @@ def golden_loss():
     return len(out)
 
 
+def golden_radam():
+    """The optimizer the reference constructs (c_gaussian_model.py:430-449): RAdam, defaults, per-group lr that changes every
+    step (update_learning_rate), one group without gradient on some steps.  torch is the reference's dependency, not its code."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37, 3), (5, 35, 4), (4099,), (3, 1)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    groups = [{"params": [p], "lr": 1e-3 * (i + 1), "name": str(i)} for i, p in enumerate(params)]
+    opt = torch.optim.RAdam(groups, lr=0.001)
+    out = {"n_steps": 12, "n_params": len(params)}
+    for i, p in enumerate(params):
+        out[f"p{i}/init"] = p.detach().numpy().copy()
+    for it in range(12):
+        for i, (p, grp) in enumerate(zip(params, opt.param_groups)):
+            grp["lr"] = 1e-3 * (i + 1) * (0.9 ** it)
+            skip = (i == 3 and it in (2, 3))                               # a tensor whose grad is None keeps its step count
+            p.grad = None if skip else (torch.randn(p.shape, generator=g) * (10.0 ** (i - 2))) * (1.0 if it != 7 else 0.0)
+            out[f"p{i}/lr{it}"] = np.float64(grp["lr"])
+            out[f"p{i}/has_grad{it}"] = not skip
+            if not skip:
+                out[f"p{i}/grad{it}"] = p.grad.numpy().copy()
+        opt.step()
+        for i, p in enumerate(params):
+            out[f"p{i}/after{it}"] = p.detach().numpy().copy()
+    for i, p in enumerate(params):
+        st = opt.state[p]
+        out[f"p{i}/exp_avg"] = st["exp_avg"].numpy().copy(); out[f"p{i}/exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+        out[f"p{i}/step"] = np.float32(st["step"].item())
+    np.savez_compressed(os.path.join(OUT, "radam.npz"), **out)
+    return len(out)
+
+
 def golden_marshalling():
     """Drive the reference's autograd wrapper with a recording stub `_C` and store which input lands in
     which positional slot (by tagging each tensor with a unique first element)."""
@@ -217,4 +249,5 @@ if __name__ == "__main__":
     print("sh_eval:", golden_sh())
     print("cameras:", golden_cameras())
     print("loss:", golden_loss())
+    print("radam:", golden_radam())
     print("marshalling:", golden_marshalling())

@@ -278,6 +278,53 @@ def test_loss_refuses_cpu_tensors():
         l1_ssim_loss(torch.zeros(3, 8, 8), torch.zeros(3, 8, 8), 0.2)
 
 
+# ------------------------------------------------------------------ 8f-3: RAdam oracle pinned by torch.optim.RAdam trajectories
+def radam_golden_replay(step_fn):
+    """Replays tests/golden/radam.npz; step_fn(i, it, grad or None, lr) performs one update; returns the golden dict."""
+    g = np.load(os.path.join(h.ROOT, "tests", "golden", "radam.npz"))
+    for it in range(int(g["n_steps"])):
+        for i in range(int(g["n_params"])):
+            has = bool(g[f"p{i}/has_grad{it}"])
+            step_fn(i, it, g[f"p{i}/grad{it}"] if has else None, float(g[f"p{i}/lr{it}"]))
+    return g
+
+
+def test_radam_oracle_matches_torch_trajectories():
+    from oracle import optim_oracle
+    g0 = np.load(os.path.join(h.ROOT, "tests", "golden", "radam.npz"))
+    n = int(g0["n_params"])
+    P = [g0[f"p{i}/init"].copy() for i in range(n)]
+    M = [np.zeros_like(p) for p in P]; V = [np.zeros_like(p) for p in P]; steps = [0] * n
+    seen_both = set()
+
+    def step(i, it, grad, lr):
+        if grad is not None:
+            steps[i] += 1
+            seen_both.add(bool(optim_oracle.radam_step(P[i], grad, M[i], V[i], steps[i], lr)))
+        if i == n - 1:
+            for j in range(n):
+                ref = g0[f"p{j}/after{it}"]
+                np.testing.assert_allclose(P[j], ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    radam_golden_replay(step)
+    assert seen_both == {True, False}                   # the trajectory crosses the rho_t > 5 switch
+    for j in range(n):
+        assert steps[j] == int(g0[f"p{j}/step"])
+        np.testing.assert_allclose(M[j], g0[f"p{j}/exp_avg"], rtol=2e-6, atol=2e-6 * np.abs(M[j]).max())
+        np.testing.assert_allclose(V[j], g0[f"p{j}/exp_avg_sq"], rtol=2e-6, atol=2e-6 * np.abs(V[j]).max())
+
+
+def test_fused_radam_refuses_cpu_and_weight_decay():
+    from ex4dgs_amd.optim import FusedRAdam
+    p = torch.nn.Parameter(torch.zeros(4))
+    with pytest.raises(ValueError):
+        FusedRAdam([p], weight_decay=0.1)
+    opt = FusedRAdam([{"params": [p], "lr": 0.1, "name": "xyz"}], lr=0.001)
+    assert opt.param_groups[0]["betas"] == (0.9, 0.999) and opt.param_groups[0]["eps"] == 1e-8 and opt.param_groups[0]["name"] == "xyz"
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
@@ -296,7 +343,12 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     hdr3 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_loss.h")).read(), flags=re.S)
     declared3 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr3))
     assert declared3 == set(loss_mod.EXPORTS), declared3 ^ set(loss_mod.EXPORTS)
-    declared |= declared2 | declared3
+    from ex4dgs_amd import optim as optim_mod
+    hdr4 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_optim.h")).read(), flags=re.S)
+    declared4 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr4))
+    assert declared4 == set(optim_mod.EXPORTS), declared4 ^ set(optim_mod.EXPORTS)
+    assert ctypes.sizeof(optim_mod.Ex4dRadamTensor) == 56
+    declared |= declared2 | declared3 | declared4
     handle = ctypes.CDLL(lib)
     for name in declared:
         assert hasattr(handle, name), name

@@ -464,3 +464,78 @@ def test_fused_loss_on_a_render_full_size_and_upstream_scale(hip_lib):
     loss.backward()
     gsum = sum(float(p.grad.abs().sum()) for p in model.parameters() if p.grad is not None)
     assert np.isfinite(gsum) and gsum > 0
+
+
+# ------------------------------------------------------------------ 8f-3: fused RAdam
+@pytest.mark.gpu
+def test_fused_radam_follows_torch_trajectories(hip_lib):
+    """tests/golden/radam.npz: 12 steps of torch.optim.RAdam over 4 tensors with per-step learning rates, a tensor without
+    gradient on two steps, an all-zero gradient step, crossing the rho_t > 5 switch."""
+    from ex4dgs_amd.optim import FusedRAdam
+    from tests.test_cpu_oracle_and_host import radam_golden_replay
+    g0 = np.load(os.path.join(h.ROOT, "tests", "golden", "radam.npz"))
+    n = int(g0["n_params"])
+    params = [torch.nn.Parameter(torch.tensor(g0[f"p{i}/init"], device="cuda")) for i in range(n)]
+    opt = FusedRAdam([{"params": [p], "lr": 1.0, "name": str(i)} for i, p in enumerate(params)], lr=0.001)
+
+    def step(i, it, grad, lr):
+        opt.param_groups[i]["lr"] = lr
+        params[i].grad = None if grad is None else torch.tensor(grad, device="cuda")
+        if i == n - 1:
+            opt.step()
+            for j in range(n):
+                ref = g0[f"p{j}/after{it}"]
+                np.testing.assert_allclose(params[j].detach().cpu().numpy(), ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()))
+    radam_golden_replay(step)
+    for j, p in enumerate(params):
+        st = opt.state[p]
+        assert float(st["step"]) == float(g0[f"p{j}/step"])
+        np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), g0[f"p{j}/exp_avg"], rtol=2e-6, atol=2e-6 * np.abs(g0[f"p{j}/exp_avg"]).max())
+        np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), g0[f"p{j}/exp_avg_sq"], rtol=2e-6, atol=2e-6 * np.abs(g0[f"p{j}/exp_avg_sq"]).max())
+
+
+@pytest.mark.gpu
+def test_fused_radam_vs_oracle_on_model_sized_groups(hip_lib):
+    """The 15 parameter groups of a 200k-Gaussian model (odd sizes, >1 chunk per tensor, unaligned tails), 8 steps against the
+    numpy oracle; state tensors stay editable in place like the reference's densification does."""
+    from oracle import optim_oracle
+    from ex4dgs_amd.optim import FusedRAdam
+    from ex4dgs_amd.scene import make_scene
+    model, cam, bg = make_scene("cfg3", P=200_003, device="cuda")
+    params = model.parameters()
+    for p in params:
+        p.requires_grad_(True)
+    lrs = [1.6e-4, 1e-3, 2.5e-3, 5e-2, 5e-3, 1e-3, 1e-4, 1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 5e-2, 1e-4, 1e-3, 1e-3]
+    opt = FusedRAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(params, lrs))], lr=0.001)
+    P = [p.detach().cpu().numpy().copy() for p in params]
+    M = [np.zeros_like(a) for a in P]; V = [np.zeros_like(a) for a in P]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for it in range(1, 9):
+        for i, p in enumerate(params):
+            p.grad = torch.randn(p.shape, generator=gen, device="cuda") * (0.1 if i % 2 else 1e-4)
+            if it == 4:
+                p.grad[::3] = 0                      # rows invisible in this frame: momentum still moves them
+            optim_oracle.radam_step(P[i], p.grad.cpu().numpy(), M[i], V[i], it, lrs[i])
+        opt.step()
+    for i, p in enumerate(params):
+        scale = max(1.0, float(np.abs(P[i]).max()))
+        np.testing.assert_allclose(p.detach().cpu().numpy(), P[i], rtol=0, atol=2e-6 * scale, err_msg=str(i))
+        np.testing.assert_allclose(opt.state[p]["exp_avg"].cpu().numpy(), M[i], rtol=1e-5, atol=2e-6 * np.abs(M[i]).max())
+        np.testing.assert_allclose(opt.state[p]["exp_avg_sq"].cpu().numpy(), V[i], rtol=1e-5, atol=2e-6 * np.abs(V[i]).max())
+    # state edited in place (what _prune_optimizer / cat_tensors_to_optimizer do) is what the next step uses
+    p0 = params[0]
+    st = opt.state.pop(p0)
+    keep = torch.arange(0, p0.shape[0], 2, device="cuda")
+    new_p = torch.nn.Parameter(p0.detach()[keep].clone())
+    st["exp_avg"] = st["exp_avg"][keep].clone(); st["exp_avg_sq"] = st["exp_avg_sq"][keep].clone()
+    opt.param_groups[0]["params"][0] = new_p
+    opt.state[new_p] = st
+    new_p.grad = torch.ones_like(new_p)
+    for p in params[1:]:
+        p.grad = None
+    before = new_p.detach().clone()
+    opt.step()
+    assert float(st["step"]) == 9.0 and not torch.equal(before, new_p.detach())
+    ref_p, ref_m, ref_v = P[0][::2].copy(), M[0][::2].copy(), V[0][::2].copy()
+    optim_oracle.radam_step(ref_p, np.ones_like(ref_p), ref_m, ref_v, 9, lrs[0])
+    np.testing.assert_allclose(new_p.detach().cpu().numpy(), ref_p, rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref_p).max())))
