@@ -148,11 +148,33 @@ def model_step_timing(cfg_name, dev, grads, steps=20, warmup=5, points=None):
         for i in range(steps):
             train_iter(i)
         torch.cuda.synchronize()
-        out[("fused" if mode == "fused_getters" else "torch") + "_host_side_train_iter_ms"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
-        del model
+        tag = "fused" if mode == "fused_getters" else "torch"
+        out[tag + "_host_side_train_iter_ms"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+
+        # ... plus the optimizer step of train.py:250-251 (RAdam over the 15 groups, tiny lr so the scene stays put)
+        from ex4dgs_amd.optim import FusedRAdam
+        groups = [{"params": [p], "lr": 1e-7, "name": str(i)} for i, p in enumerate(model.parameters())]
+        opt = FusedRAdam(groups, lr=0.001) if mode == "fused_getters" else torch.optim.RAdam(groups, lr=0.001)
+
+        def full_iter(i):
+            o = render(cam, model, None, bg, timestamp=stamps[i % 3], near=cfg.min_depth, far=cfg.max_depth, sync=False)
+            loss, _l1e, _sse = loss_fn(o["render"], gt, 0.2)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        for i in range(warmup + 3):
+            full_iter(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            full_iter(i)
+        torch.cuda.synchronize()
+        out[tag + "_host_side_full_iter_with_radam_ms"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+        del model, opt
     out["what"] = ("*_getters_ms_per_frame: getters (xyz/rotation/opacity/scaling/features at t) + rasterizer fwd+bwd to the model "
                    "parameters; *_train_iter_ms: the same plus the L1+SSIM loss and error maps of train.py:144-151 "
-                   "(torch = the reference's op composition, fused = ex4d_attributes + ex4d_l1_ssim); 1 GPU, same HIP rasterizer in both")
+                   "(torch = the reference's op composition, fused = ex4d_attributes + ex4d_l1_ssim); *_full_iter_with_radam_ms: plus "
+                   "optimizer.step() + zero_grad (torch.optim.RAdam vs FusedRAdam); 1 GPU, same HIP rasterizer in both")
     return out
 
 
