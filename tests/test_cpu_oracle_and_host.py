@@ -325,6 +325,28 @@ def test_fused_radam_refuses_cpu_and_weight_decay():
         opt.step()
 
 
+# ------------------------------------------------------------------ 8f-4: distCUDA2 oracle, two independent formulations
+def knn_point_sets():
+    rng = np.random.default_rng(21)
+    uniform = rng.random((4000, 3), dtype=np.float32) * 10
+    clustered = np.concatenate([c + 0.05 * rng.standard_normal((500, 3)) for c in rng.standard_normal((8, 3)) * 5]).astype(np.float32)
+    dup = uniform[:1500].copy(); dup[100:110] = dup[100]; dup[500] = dup[499]          # coincident points count as neighbours
+    plane = uniform[:2000].copy(); plane[:, 2] = 1.5                                    # zero extent on one axis
+    line = np.zeros((700, 3), np.float32); line[:, 0] = np.sort(rng.random(700)).astype(np.float32)
+    return dict(uniform=uniform, clustered=clustered, dup=dup, plane=plane, line=line, same=np.ones((70, 3), np.float32))
+
+
+def test_knn_oracle_formulations_agree():
+    from oracle import knn_oracle
+    for name, pts in knn_point_sets().items():
+        a, b = knn_oracle.dist2_bruteforce(pts), knn_oracle.dist2_kdtree(pts, k_search=16 if name != "same" else 69)
+        assert np.array_equal(a, b), name
+    assert np.all(knn_oracle.dist2_bruteforce(knn_point_sets()["same"]) == 0)
+    tiny = knn_point_sets()["uniform"]
+    assert np.isinf(knn_oracle.dist2_bruteforce(tiny[:1])).all() and np.isinf(knn_oracle.dist2_bruteforce(tiny[:2])).all()
+    assert (knn_oracle.dist2_bruteforce(tiny[:3]) > 1e37).all() and np.isfinite(knn_oracle.dist2_bruteforce(tiny[:4])).all()
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
@@ -348,7 +370,11 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     declared4 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr4))
     assert declared4 == set(optim_mod.EXPORTS), declared4 ^ set(optim_mod.EXPORTS)
     assert ctypes.sizeof(optim_mod.Ex4dRadamTensor) == 56
-    declared |= declared2 | declared3 | declared4
+    from ex4dgs_amd.simple_knn import _C as knn_mod
+    hdr5 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_knn.h")).read(), flags=re.S)
+    declared5 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr5))
+    assert declared5 == set(knn_mod.EXPORTS), declared5 ^ set(knn_mod.EXPORTS)
+    declared |= declared2 | declared3 | declared4 | declared5
     handle = ctypes.CDLL(lib)
     for name in declared:
         assert hasattr(handle, name), name

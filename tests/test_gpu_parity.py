@@ -539,3 +539,43 @@ def test_fused_radam_vs_oracle_on_model_sized_groups(hip_lib):
     ref_p, ref_m, ref_v = P[0][::2].copy(), M[0][::2].copy(), V[0][::2].copy()
     optim_oracle.radam_step(ref_p, np.ones_like(ref_p), ref_m, ref_v, 9, lrs[0])
     np.testing.assert_allclose(new_p.detach().cpu().numpy(), ref_p, rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref_p).max())))
+
+
+# ------------------------------------------------------------------ 8f-4: distCUDA2 (simple-knn)
+@pytest.mark.gpu
+def test_dist2_bit_exact_vs_bruteforce(hip_lib):
+    """The result is a selection (three smallest float32 distances), not a sum over many terms: bit-exact."""
+    from oracle import knn_oracle
+    from ex4dgs_amd.simple_knn._C import distCUDA2
+    from tests.test_cpu_oracle_and_host import knn_point_sets
+    sets = knn_point_sets()
+    for name, pts in sets.items():
+        got = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
+        assert np.array_equal(got, knn_oracle.dist2_bruteforce(pts)), name
+    u = sets["uniform"]
+    for P in (1, 2, 3, 4, 5, 63, 64, 65, 127, 1023, 1024, 1025, 2049):
+        got = distCUDA2(torch.tensor(u[:P], device="cuda")).cpu().numpy()
+        assert np.array_equal(got, knn_oracle.dist2_bruteforce(u[:P])), P
+    assert distCUDA2(torch.zeros(0, 3, device="cuda")).shape == (0,)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        distCUDA2(torch.zeros(4, 3))
+
+
+@pytest.mark.gpu
+def test_dist2_at_scale_and_initialisation_use(hip_lib):
+    """300k points (scene-like: surfaces + clusters + outliers) against the kd-tree formulation; then the reference's use
+    (c_gaussian_model.py:395-396): scales = log(sqrt(clamp_min(dist2, 1e-7)))."""
+    from oracle import knn_oracle
+    from ex4dgs_amd.simple_knn._C import distCUDA2
+    rng = np.random.default_rng(8)
+    sheet = np.stack([rng.random(150_000) * 20, rng.random(150_000) * 20, 0.01 * rng.standard_normal(150_000)], 1)
+    blobs = np.concatenate([c + 0.3 * rng.standard_normal((14_000, 3)) for c in rng.standard_normal((10, 3)) * 8])
+    far = rng.standard_normal((10_000, 3)) * 200
+    pts = np.concatenate([sheet, blobs, far]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    x = torch.tensor(pts, device="cuda")
+    got = distCUDA2(x)
+    assert np.array_equal(got.cpu().numpy(), knn_oracle.dist2_kdtree(pts, k_search=16))
+    assert torch.equal(got, distCUDA2(x))                                   # deterministic
+    scales = torch.log(torch.sqrt(torch.clamp_min(got, 0.0000001)))[..., None].repeat(1, 3)
+    assert torch.isfinite(scales).all()
