@@ -347,6 +347,64 @@ def test_knn_oracle_formulations_agree():
     assert (knn_oracle.dist2_bruteforce(tiny[:3]) > 1e37).all() and np.isfinite(knn_oracle.dist2_bruteforce(tiny[:4])).all()
 
 
+# ------------------------------------------------------------------ 8f-4: the two-file PLY checkpoint format
+def test_ply_checkpoint_format_round_trip_and_layout(tmp_path):
+    """save_ply/load_ply against an independent structured-array formulation of what the reference does through plyfile
+    (c_gaussian_model.py:514-547: one named float32 record per Gaussian; :560-666: column-by-column reads by name)."""
+    from ex4dgs_amd import ply_io
+    from ex4dgs_amd.scene import make_scene
+    model, _, _ = make_scene("cfg3", P=1200, device="cpu")
+    path = str(tmp_path / "point_cloud" / "iteration_30000" / "point_cloud.ply")
+    ply_io.save_ply(model, path)
+    dyn_path = path.replace("point_cloud.ply", "dynamic_point_cloud.ply")
+    assert os.path.exists(dyn_path)
+
+    def parse(pth):                                  # minimal PLY reader: header -> numpy structured dtype -> records
+        raw = open(pth, "rb").read()
+        head, body = raw.split(b"end_header\n", 1)
+        lines = head.decode().split("\n")
+        assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+        n = int(lines[2].split()[2]); assert lines[2].startswith("element vertex ")
+        names = [l.split()[2] for l in lines[3:] if l.startswith("property")]
+        assert all(l.split()[1] == "float" for l in lines[3:] if l.startswith("property"))
+        rec = np.frombuffer(body, dtype=[(nm, "<f4") for nm in names])
+        assert rec.shape[0] == n and len(body) == n * 4 * len(names)
+        return names, rec
+    names, rec = parse(path)
+    K = model._xyz_motion.shape[1]
+    assert names == ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)] + \
+        ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "xyz_disp_0", "xyz_disp_1", "xyz_disp_2"]
+    g = lambda n: getattr(model, n).numpy()
+    assert np.array_equal(rec["y"], g("_xyz")[:, 1]) and np.all(rec["nx"] == 0)
+    assert np.array_equal(rec["f_dc_2"], g("_features_dc")[:, 0, 2])
+    assert np.array_equal(rec["f_rest_17"], g("_features_rest")[:, 2, 1])          # channel-major: 17 = channel 1 * 15 + coeff 2
+    assert np.array_equal(rec["rot_3"], g("_rotation")[:, 3]) and np.array_equal(rec["xyz_disp_1"], g("_xyz_disp")[:, 1])
+    dnames, drec = parse(dyn_path)
+    assert dnames[:3] == ["motion_xyz_0_0", "motion_xyz_0_1", "motion_xyz_0_2"] and dnames[-1] == f"motion_rot_{K - 1}_3"
+    assert len(dnames) == K * 3 + 3 + 45 + 3 + 1 + 2 + 2 + K * 4
+    assert np.array_equal(drec["motion_xyz_12_1"], g("_xyz_motion")[:, 12, 1])
+    assert np.array_equal(drec["motion_rot_30_2"], g("_rotation_motion")[:, 30, 2])
+    assert np.array_equal(drec["motion_opacity_v_1"], g("_opacity_duration_var")[:, 1, 0])
+    assert np.array_equal(drec["motion_f_rest_44"], g("_features_rest_motion")[:, 14, 2])
+    out = ply_io.load_ply(path, device="cpu")
+    for n in model.PARAM_NAMES:
+        assert out[n].dtype == torch.float32 and out[n].is_contiguous() and torch.equal(out[n], getattr(model, n)), n
+    # properties are found by name: a file with permuted columns (and an extra one) loads identically
+    perm = np.random.default_rng(0).permutation(len(dnames))
+    pn = [dnames[i] for i in perm] + ["extra"]
+    mat = np.stack([drec[nm] for nm in pn[:-1]] + [np.zeros(len(drec), np.float32)], 1)
+    ply_io._write(dyn_path, pn, mat)
+    out2 = ply_io.load_ply(path, device="cpu")
+    for n in model.PARAM_NAMES:
+        assert torch.equal(out2[n], out[n]), n
+    # static-only model (config 2): zero dynamic rows
+    smodel, _, _ = make_scene("cfg2", P=300, device="cpu")
+    spath = str(tmp_path / "s" / "point_cloud.ply")
+    ply_io.save_ply(smodel, spath)
+    sout = ply_io.load_ply(spath, device="cpu")
+    assert sout["_xyz_motion"].shape == smodel._xyz_motion.shape and torch.equal(sout["_xyz"], smodel._xyz)
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
