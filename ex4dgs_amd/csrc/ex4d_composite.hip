@@ -36,6 +36,26 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// gfx950 issues the VOP2 encoding of v_cndmask_b32 (implicit VCC) in ~24 cycles but the VOP3 encoding in ~5 (measured,
+// tests/dev_micro/pk_rate.hip), and the compiler shrinks every select whose condition sits in VCC to VOP2.  Selects and
+// wave votes inside the per-Gaussian loops are therefore spelled out: condition as a 64-bit lane mask in SGPRs.
+// Conditions are kept as 64-bit lane masks in SGPRs: a ballot of ONE compare is the v_cmp itself, masks combine on the
+// scalar unit, "no lane" is a scalar test (a ballot of a combined bool costs a v_cndmask + v_cmp round trip instead).
+typedef unsigned long long lanemask;
+#define LANES(cmp) __builtin_amdgcn_ballot_w64(cmp)
+__device__ __forceinline__ float select_f(lanemask m, float if_set, float if_clear)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int select_i(lanemask m, int if_set, int if_clear)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+
 __device__ __forceinline__ float wave_min(float v)
 {
 #pragma unroll
@@ -143,13 +163,13 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
 
-    bool done = !p.inside;
+    lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
     uint32_t last_contributor = 0;
     int32_t best = -1;
 
     for (int base = 0; base < n; base += 64) {
-        if (__ballot(!done) == 0) break;
+        if (live == 0) break;
         const int k = base + lane;
         bool keep = false;
         uint32_t id = 0;
@@ -179,8 +199,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
         wave_lds_sync();
         int last_j = -1, best_j = -1;
         for (int j = 0; j < cnt; j++) {
-            // the all-done vote costs two VALU slots: take it every 8th entry only (a finished quadrant idles <= 7 entries)
-            if ((j & 7) == 0 && __ballot(!done) == 0) break;
+            if (live == 0) break;
             const float4 g0 = s_q0[wave][j];
             const float2 g1 = s_q1[wave][j];
             // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
@@ -188,22 +207,24 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
             const float power2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;
             const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(power2));
             const float test_T = T * (1.f - alpha);
-            const bool ok = !done && (power2 <= 0.0f) && !(alpha < 1.0f / 255.0f);
-            const bool stop = ok && (test_T < 0.0001f);
-            done = done || stop;
-            if (ok && !stop) {
-                // CR/forward.cu:389-422
-                const float4 g2 = s_q2[wave][j];
-                const float4 g3 = s_q3[wave][j];
-                const float wgt = alpha * T;
-                C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
-                Dm += g2.x * wgt;
-                acc += wgt;
-                F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt;
-                if (wgt > max_vis) { max_vis = wgt; best_j = j; }
-                T = test_T;
-                last_j = j;
-            }
+            const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
+            const lanemask stop = ok & LANES(test_T < 0.0001f);
+            live &= ~stop;
+            const lanemask add = ok & ~stop;
+            if (add == 0) continue;
+            // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
+            const float4 g2 = s_q2[wave][j];
+            const float4 g3 = s_q3[wave][j];
+            const float wgt = select_f(add, alpha * T, 0.f);
+            C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
+            Dm += g2.x * wgt;
+            acc += wgt;
+            F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt;
+            const lanemask brighter = LANES(wgt > max_vis);
+            best_j = select_i(brighter, j, best_j);
+            max_vis = select_f(brighter, wgt, max_vis);
+            T = select_f(add, test_T, T);
+            last_j = select_i(add, j, last_j);
         }
         if (last_j >= 0) last_contributor = s_orig[wave][last_j] + 1;
         if (best_j >= 0) best = (int32_t)s_id[wave][best_j];
@@ -317,6 +338,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
     float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f;
 
+    const lanemask inside = LANES(p.inside);
     const uint32_t deepest = wave_max_u32(last_contributor);     // nothing behind it touches this quadrant
     if (deepest == 0) return;
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
@@ -359,14 +381,14 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             const float G = __builtin_amdgcn_exp2f(power2);                   // exp(power)
             const float araw = g1.y * G;
             const float alpha = fminf(0.99f, araw);
-            const bool ok = p.inside && (orig < last_contributor) && (power2 <= 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(ok) == 0) continue;
+            const lanemask ok = inside & LANES(orig < last_contributor) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
+            if (ok == 0) continue;
 
             // CR/backward.cu:592-679 for all 64 lanes at once, without a divergent branch: lanes that do not
             // contribute run the same arithmetic with alpha = G = 0, which makes every partial exactly 0 and leaves
             // T (x 1/(1-0)), the colour recurrence (R = 0*c + 1*R) and dL_dacc (x 1) unchanged.
-            const float alpha_m = ok ? alpha : 0.f;
-            const float G_m = ok ? G : 0.f;
+            const float alpha_m = select_f(ok, alpha, 0.f);
+            const float G_m = select_f(ok, G, 0.f);
             const float4 g2 = s_q2[wave][j];
             const float one_m = 1.f - alpha_m;
             const float inv1ma = __builtin_amdgcn_rcpf(one_m);
@@ -374,8 +396,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             const float dcc = alpha_m * T;                          // dchannel_dcolor
             float v[16];
             v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
-            const bool dep_ok = (g2.x > min_depth) & (dcc > 0.0f);
-            const float gdep = dep_ok ? gdepth : 0.f;
+            const float gdep = select_f(LANES(g2.x > min_depth) & LANES(dcc > 0.0f), gdepth, 0.f);
             v[2] = gdep * dcc;
             float dL_dalpha = (final_depth - g2.x) * gdep * T;
             // accum_rec of the reference == colour accumulated behind this Gaussian; R is advanced after use
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             v[7] = dcc * gp0; v[8] = dcc * gp1; v[9] = dcc * gp2;
             v[10] = dcc * gflow0; v[11] = dcc * gflow1; v[12] = dcc * gflow2;
             dL_dalpha *= T;
-            gacc *= (ok ? T : 1.f);
+            gacc *= select_f(ok, T, 1.f);
             dL_dalpha += bgT * inv1ma;
             // with s = dL_dG * G = w G dL_dalpha:  dL_dmean2D.x = s (-(A dx + B dy)) W/2 = s (2 a' dx + b' dy) (ln2 W/2),
             // dL_dconic.x = -s dx^2 / 2, ...; the constant factors (ln2 W/2, ln2 H/2, -1/2) are applied once per
