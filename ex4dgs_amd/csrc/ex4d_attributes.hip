@@ -157,14 +157,21 @@ template <bool GATHER>
 __global__ __launch_bounds__(256) void features_kernel(int Ns, int Nd, float *__restrict__ dc, float *__restrict__ rest,
     float *__restrict__ dc_m, float *__restrict__ rest_m, float *__restrict__ shs)
 {
-    const size_t total = (size_t)(Ns + Nd) * 48;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t row = e / 48;
-        const int c = (int)(e - row * 48);
-        float *p;
-        if (row < (size_t)Ns) p = (c < 3) ? dc + row * 3 + c : rest + row * 45 + (c - 3);
-        else { const size_t j = row - Ns; p = (c < 3) ? dc_m + j * 3 + c : rest_m + j * 45 + (c - 3); }
-        if (GATHER) shs[e] = *p; else *p = shs[e];
+    // one float4 of the [N,48] block per thread and step (32-bit index math; 12 float4 per row); the dc / rest side is four
+    // scalar accesses at consecutive addresses (rows of 3 and 45 floats cannot be 16-byte aligned)
+    const unsigned total4 = (unsigned)(Ns + Nd) * 12u;
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < total4; q += gridDim.x * 256u) {
+        const unsigned row = q / 12u;
+        const int c4 = (int)(q - row * 12u) * 4;
+        float *d, *r;
+        if (row < (unsigned)Ns) { d = dc + (size_t)row * 3; r = rest + (size_t)row * 45; }
+        else { const size_t j = row - (unsigned)Ns; d = dc_m + j * 3; r = rest_m + j * 45; }
+        float *p0, *p1, *p2, *p3;
+        if (c4 == 0) { p0 = d; p1 = d + 1; p2 = d + 2; p3 = r; }
+        else { p0 = r + (c4 - 3); p1 = p0 + 1; p2 = p0 + 2; p3 = p0 + 3; }
+        float4 *s4 = reinterpret_cast<float4 *>(shs) + q;
+        if (GATHER) *s4 = make_float4(*p0, *p1, *p2, *p3);
+        else { const float4 v = *s4; *p0 = v.x; *p1 = v.y; *p2 = v.z; *p3 = v.w; }
     }
 }
 
@@ -262,8 +269,8 @@ int ex4d_attributes_forward(const Ex4dAttrParams *a,
     if (a->Nd > 0 && (a->k < 1 || a->k + 2 >= a->K)) { snprintf(g_attr_err, sizeof(g_attr_err), "keyframe index %d needs k-1..k+2 inside [0,%d)", a->k, a->K); return EX4D_ERR_ARG; }
     hipLaunchKernelGGL(attributes_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, *a, xyz, xyz_disp, rotation, opacity, scaling,
         xyz_motion, rotation_motion, opacity_motion, dur_center, dur_var, scaling_motion, means3D, rotations, opacities, scales);
-    const size_t total = (size_t)N * 48;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const size_t total = (size_t)N * 12;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(features_kernel<true>, dim3(blocks), dim3(256), 0, stream, a->Ns, a->Nd, (float *)features_dc, (float *)features_rest,
         (float *)features_dc_motion, (float *)features_rest_motion, shs);
     const hipError_t e = hipGetLastError();
@@ -296,8 +303,8 @@ int ex4d_attributes_backward(const Ex4dAttrParams *a,
         dur_center, dur_var, scaling_motion, g_means3D, g_rotations, g_opacities, g_scales,
         g_xyz, g_xyz_disp, g_rotation, g_opacity, g_scaling, g_xyz_motion, g_rotation_motion, g_opacity_motion, g_dur_center, g_dur_var,
         g_scaling_motion);
-    const size_t total = (size_t)N * 48;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const size_t total = (size_t)N * 12;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(features_kernel<false>, dim3(blocks), dim3(256), 0, stream, a->Ns, a->Nd, g_features_dc, g_features_rest,
         g_features_dc_motion, g_features_rest_motion, (float *)g_shs);
     const hipError_t e = hipGetLastError();

@@ -77,4 +77,13 @@ class FusedRAdam(torch.optim.Optimizer):
                     arr = (Ex4dRadamTensor * len(chunk))(*[c[0] for c in chunk])
                     if lib.ex4d_radam_step(arr, len(chunk), betas[0], betas[1], eps, stream):
                         raise RuntimeError(lib.ex4d_optim_last_error().decode())
+        # the library wrote through raw pointers: tell autograd the tensors changed (version counters), exactly what the
+        # in-place torch ops of torch.optim.RAdam do -- caches keyed on parameter versions depend on it
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    st = self.state[p]
+                    torch.autograd.graph.increment_version(p)
+                    torch.autograd.graph.increment_version(st["exp_avg"])
+                    torch.autograd.graph.increment_version(st["exp_avg_sq"])
         return loss

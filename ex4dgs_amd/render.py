@@ -28,9 +28,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, timestamp=None, scaling_modifie
     # gradient traps: the 2D-mean gradient lands in screenspace_points.grad, the per-Gaussian
     # "flow"/error channel gradient in flow.grad (gaussian_renderer/__init__.py:28-32, :66-70)
     screenspace_points = torch.zeros_like(means3D, requires_grad=True) + 0
-    screenspace_points.retain_grad()
     flow = torch.zeros_like(means3D, requires_grad=True) + 0
-    flow.retain_grad()
+    if screenspace_points.requires_grad:           # under torch.no_grad() (evaluation) there is nothing to retain (:30-33 try/except)
+        screenspace_points.retain_grad()
+        flow.retain_grad()
 
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     if subpixel_offset is None:

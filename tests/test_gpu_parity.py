@@ -579,3 +579,40 @@ def test_dist2_at_scale_and_initialisation_use(hip_lib):
     assert torch.equal(got, distCUDA2(x))                                   # deterministic
     scales = torch.log(torch.sqrt(torch.clamp_min(got, 0.0000001)))[..., None].repeat(1, 3)
     assert torch.isfinite(scales).all()
+
+
+# ------------------------------------------------------------------ the pieces together: a short training loop
+@pytest.mark.gpu
+def test_fused_training_loop_end_to_end(hip_lib):
+    """getters (fused) -> render -> L1+SSIM (fused) -> backward -> FusedRAdam, same timestamp twice in a row: the optimizer
+    must invalidate the per-timestamp attribute cache (parameter version counters), and the loss must go down."""
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.render import render
+    from ex4dgs_amd.loss import l1_ssim_loss
+    from ex4dgs_amd.optim import FusedRAdam
+    target, cam, bg = make_scene("cfg3", P=30_000, device="cuda", fused=True)
+    with torch.no_grad():
+        gts = {t: render(cam, target, None, bg, timestamp=t, near=4.0, far=300.0)["render"].clone() for t in (40, 200)}
+    model, _, _ = make_scene("cfg3", P=30_000, device="cuda", fused=True)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    with torch.no_grad():
+        model._features_dc += 0.3 * torch.randn(model._features_dc.shape, generator=g, device="cuda")
+        model._features_dc_motion += 0.3 * torch.randn(model._features_dc_motion.shape, generator=g, device="cuda")
+        model._opacity -= 0.5
+    for p in model.parameters():
+        p.requires_grad_(True)
+    lrs = {"_features_dc": 5e-2, "_features_dc_motion": 5e-2, "_opacity": 5e-2, "_opacity_motion": 5e-2}
+    opt = FusedRAdam([{"params": [getattr(model, n)], "lr": lrs.get(n, 1e-4), "name": n} for n in model.PARAM_NAMES], lr=0.001)
+    losses = []
+    for it in range(40):
+        t = (40, 40, 200, 200)[it % 4]
+        out = render(cam, model, None, bg, timestamp=t, near=4.0, far=300.0)
+        loss, l1e, sse, hook = l1_ssim_loss(out["render"], gts[t], 0.2, acc=out["acc"])
+        v0 = model._xyz._version
+        loss.backward()
+        opt.step()
+        assert model._xyz._version > v0
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-4:]) < 0.9 * np.mean(losses[:4]), losses
