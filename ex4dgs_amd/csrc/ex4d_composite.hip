@@ -293,6 +293,18 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane)
     return r;
 }
 
+#define RED_VALUES 13
+
+// sum of this lane's 16 floats (a quarter row of s_red), then across the quad: all four lanes hold the row sum
+__device__ __forceinline__ float quad_row_sum(float4 c0, float4 c1, float4 c2, float4 c3)
+{
+    float r = (((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w))) +
+              (((c2.x + c2.y) + (c2.z + c2.w)) + ((c3.x + c3.y) + (c3.z + c3.w)));
+    r += dpp_mov<0xB1>(r);       // quad_perm [1,0,3,2]
+    r += dpp_mov<0x4E>(r);       // quad_perm [2,3,0,1]
+    return r;
+}
+
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     int W, int H, int gx, int num_tiles,
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
     __shared__ uint32_t s_id[WPB][64];
     __shared__ uint32_t s_orig[WPB][64];
+    __shared__ float s_red[WPB][RED_VALUES * 64];     // per-Gaussian partials, transposed through LDS (see below)
 
     int tile, quad;
     tile_of_block<WPB>(num_tiles, tile, quad);
@@ -318,6 +331,20 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
     const uint2 range = ranges[tile];
     const size_t HW = (size_t)H * W;
+
+    // Wave-wide sums of the 13 per-pixel partials of one Gaussian.  A register butterfly (v_permlane32/16_swap + DPP)
+    // costs ~225 VALU issue cycles per Gaussian on gfx950 (swaps issue in ~9 cycles) -- 40 % of this VALU-bound loop.
+    // Instead the partials take a trip through the otherwise idle LDS pipe: every lane stores its 13 values
+    // (row q = value, 64 floats per row), then lane l sums the 16-pixel quarter g = l&3 of row q = l>>2 from four 16-byte
+    // reads and two quad DPP adds finish the row: ~75 VALU cycles.  16-byte chunk c of row q lives at chunk c ^ q, which
+    // spreads the simultaneous chunk reads of all (q, g) evenly over the banks; stores stay lane-contiguous per row.
+    float *red_w[RED_VALUES];
+#pragma unroll
+    for (int q = 0; q < RED_VALUES; q++) red_w[q] = &s_red[wave][q * 64 + (((lane >> 2) ^ q) << 2) + (lane & 3)];
+    const int red_q = min(lane >> 2, RED_VALUES - 1);
+    const float4 *red_r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) red_r[k] = reinterpret_cast<const float4 *>(&s_red[wave][red_q * 64 + ((((lane & 3) * 4 + k) ^ red_q) << 2)]);
 
     // CR/backward.cu:489-549
     const float T_final = p.inside ? final_Ts[p.pix_id] : 0.f;
@@ -343,8 +370,10 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     if (deepest == 0) return;
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
-    const int which = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    const bool writer = ((lane & 3) == 0) && (which < 13);
+    const int which = lane >> 2;
+    const bool writer = ((lane & 3) == 0) && (which < RED_VALUES);
+    const uint32_t kNoPending = 0xffffffffu;
+    uint32_t pending_id = kNoPending;            // wave-uniform: Gaussian whose partials sit in s_red
 
     for (int base = 0; base < (int)deepest; base += 64) {
         const int k = (int)deepest - 1 - base - lane;            // descending list position
@@ -384,6 +413,12 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             const lanemask ok = inside & LANES(orig < last_contributor) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
             if (ok == 0) continue;
 
+            // the row sums of the PREVIOUS contributing Gaussian: its partials were stored at the end of its iteration, the
+            // reads are issued now and consumed after this Gaussian's arithmetic -- the LDS round trip hides behind ~60 VALU
+            // instructions (LDS serves one wave's requests in order, so the reads see those stores without a wait)
+            const float4 c0 = *red_r[0], c1 = *red_r[1], c2 = *red_r[2], c3 = *red_r[3];
+            wave_lds_sync();
+
             // CR/backward.cu:592-679 for all 64 lanes at once, without a divergent branch: lanes that do not
             // contribute run the same arithmetic with alpha = G = 0, which makes every partial exactly 0 and leaves
             // T (x 1/(1-0)), the colour recurrence (R = 0*c + 1*R) and dL_dacc (x 1) unchanged.
@@ -394,8 +429,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             const float inv1ma = __builtin_amdgcn_rcpf(one_m);
             T = T * inv1ma;
             const float dcc = alpha_m * T;                          // dchannel_dcolor
-            float v[16];
-            v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
+            float v[RED_VALUES];
             const float gdep = select_f(LANES(g2.x > min_depth) & LANES(dcc > 0.0f), gdepth, 0.f);
             v[2] = gdep * dcc;
             float dL_dalpha = (final_depth - g2.x) * gdep * T;
@@ -423,10 +457,20 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             v[4] = sdx * dy;
             v[5] = (sG * dy) * dy;
             v[6] = G_m * (dL_dalpha + gacc);
-            const float r = reduce_scatter16(v, lane);
-            if (writer) unsafeAtomicAdd(&acc16[16 * (size_t)s_id[wave][j] + which], r);
+            const float row = quad_row_sum(c0, c1, c2, c3);        // all lanes: the DPP adds read the quad neighbours
+            if (pending_id != kNoPending && writer) unsafeAtomicAdd(&acc16[16 * (size_t)pending_id + which], row);
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < RED_VALUES; q++) *red_w[q] = v[q];
+            pending_id = s_id[wave][j];
         }
         wave_lds_sync();
+    }
+    if (pending_id != kNoPending) {
+        wave_lds_sync();
+        const float4 c0 = *red_r[0], c1 = *red_r[1], c2 = *red_r[2], c3 = *red_r[3];
+        const float row = quad_row_sum(c0, c1, c2, c3);
+        if (writer) unsafeAtomicAdd(&acc16[16 * (size_t)pending_id + which], row);
     }
 }
 
