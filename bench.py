@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the Gaussian count (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--no-model-step", action="store_true", help="skip the training-iteration timings (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
@@ -333,7 +334,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + ("" if world == 1 else (" + async RCCL grad all-reduce" if buckets is not None else " (no collective)"))},
             "roofline": roof,
         }
-        if world == 1:
+        if world == 1 and not args.no_model_step:
             try:
                 line["model_step"] = model_step_timing(args.config, dev, grads, points=args.points)
             except Exception as e:
