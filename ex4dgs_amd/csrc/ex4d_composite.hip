@@ -16,9 +16,10 @@
 //   * the 64 lanes then walk the compacted list with wave-uniform LDS broadcasts, one flat predicate per
 //     pair (no nested divergent branches: SALU mask traffic costs as much issue bandwidth as VALU here);
 //   * backward: same traversal in reverse, starting at the quadrant's deepest contributor instead of the
-//     list end; the 13 per-Gaussian partials of the 64 pixels are combined by a wave64 reduce-scatter
-//     (v_permlane32_swap / v_permlane16_swap / DPP row ops: 35 cross-lane ops instead of 13 x 64 float
-//     atomics) and leave the wave as ONE 13-lane atomic instruction onto a 64-byte accumulator row.
+//     list end; the 13 per-Gaussian partials of the 64 pixels are summed through the LDS pipe (13 stores, four
+//     16-byte reads per lane, two quad DPP adds -- instead of 13 x 64 float atomics or a register butterfly whose
+//     v_permlane swaps are ~9 issue cycles each) and leave the wave as ONE 13-lane atomic instruction onto a
+//     64-byte accumulator row.
 // Tiles are assigned to workgroups XCD-aware: workgroup b runs on XCD b % 8, so each XCD gets a
 // contiguous band of the screen and neighbouring tiles (which share Gaussians) hit the same L2.
 // Arithmetic follows the reference's expressions; FMA contraction is allowed here (results are compared
@@ -249,48 +250,10 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave64 reduce-scatter of 16 per-lane values.  Afterwards every lane l holds the wave-wide sum of value
-//   which(l) = ((l>>5)&1)*8 + ((l>>4)&1)*4 + ((l>>3)&1)*2 + ((l>>2)&1)
-// (all four lanes of a quad hold the same sum).
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
-__device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane)
-{
-    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-    float w8[8], w4[4], w2[2];
-    // halves: v_permlane32_swap exchanges a[32..63] <-> b[0..31]; then a+b = per-half sums, value i low / i+8 high
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-        w8[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    // 16-lane rows: v_permlane16_swap exchanges a.odd_rows <-> b.even_rows
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w8[i]), __float_as_uint(w8[i + 4]), false, false);
-        w4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    (void)lane;
-    // 8-lane halves of a row (DPP row_ror:8 pairs lane l with l^8): x + ror8(x) is the pair sum in BOTH lanes; the
-    // DPP bank mask then keeps value i in banks 0-1 (lanes 0-7 of the row) and value i+2 in banks 2-3 -- no v_cndmask
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const float lo = w4[i] + dpp_mov<0x128>(w4[i]);
-        const float hi = w4[i + 2] + dpp_mov<0x128>(w4[i + 2]);
-        w2[i] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0xE4 /* quad_perm identity */, 0xf, 0xC, false));
-    }
-    // 4-lane halves of an 8-lane group: DPP row_half_mirror pairs lane l with lane 7-l (bit 2 differs)
-    const float lo = w2[0] + dpp_mov<0x141>(w2[0]);
-    const float hi = w2[1] + dpp_mov<0x141>(w2[1]);
-    float r = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(hi), 0xE4, 0xf, 0xA, false));
-    r += dpp_mov<0xB1>(r);       // quad_perm [1,0,3,2]
-    r += dpp_mov<0x4E>(r);       // quad_perm [2,3,0,1]
-    return r;
 }
 
 #define RED_VALUES 13
