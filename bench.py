@@ -302,11 +302,13 @@ def main():
         dom_bytes = stage_bytes["sort"]
     roof = None
     traffic = None
+    valu_busy = None
     try:   # HBM bytes per launch from the PMC passes committed under profiles/ (collected with tools/pmc.sh, not in this run)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         if args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            valu_busy = pmc["kernels"][dom].get("valu_busy_frac")
     except Exception:
         traffic = None
     if dom is not None and dom_bytes:
@@ -314,6 +316,8 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel_ms": round(agg[dom], 4), "algorithmic_bytes": int(dom_bytes),
+                # the kernel the contract prices against HBM is VALU-issue bound in practice: SQ counters of the committed PMC pass
+                "valu_busy_frac_pmc": valu_busy,
                 "frame": {"A_fwd_bytes": int(A_fwd), "A_bwd_bytes": int(A_bwd), "A_bytes": int(A),
                           "achieved_GBps_walltime": round(A / (ms_per_step * 1e-3) / 1e9, 1),
                           "frac_walltime": round(A / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
