@@ -114,11 +114,19 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         const uint32_t i = base + it * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = (key[it] >> shift) & mask;
-        uint64_t peers = __ballot(valid);
+        // lanes holding the same digit: per bit keep the ballot if my bit is set, its complement otherwise -- written as
+        // ballot ^ (bit - 1) on 32-bit halves (plain xor/and; a select here compiles to the VOP2 v_cndmask that issues in ~24
+        // cycles on gfx950 and made this loop the most expensive part of the pass)
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        uint32_t plo = (uint32_t)vmask, phi = (uint32_t)(vmask >> 32);
         for (int b = 0; b < nbits; b++) {
-            const uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
+            const uint32_t bit = (d >> b) & 1u;
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
+            const uint32_t flip = bit - 1u;                       // 0 when my bit is set, ~0 otherwise
+            plo &= (uint32_t)bal ^ flip;
+            phi &= (uint32_t)(bal >> 32) ^ flip;
         }
+        const uint64_t peers = ((uint64_t)phi << 32) | plo;
         const uint32_t rank = __popcll(peers & lt);
         const int leader = __ffsll((long long)peers) - 1;
         uint32_t before = 0;
@@ -336,8 +344,10 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
     const uint32_t nb = rs_blocks_for(n);
     const bool small = rs_items_for(n) == 4;
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
-    for (int shift = 0; shift < end_bit; shift += 8) {
-        const int nbits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+    // balanced digits (13 bits -> 7 + 6, not 8 + 5): a pass with fewer bins writes longer runs per digit and workgroup
+    const int npass = (end_bit + 7) / 8;
+    for (int pass = 0, shift = 0; pass < npass; pass++) {
+        const int nbits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);
         const uint32_t mask = (1u << nbits) - 1u;
         if (small) hipLaunchKernelGGL(rs_histogram_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
         else hipLaunchKernelGGL(rs_histogram_kernel<RS_ITEMS>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
@@ -347,6 +357,7 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
         *result_in_a = !*result_in_a;
+        shift += nbits;
     }
     return hipGetLastError();
 }
