@@ -282,28 +282,34 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
         count = (uint32_t)w * (rc.y >> 16);
         if (w <= 0) w = 1;
     }
+    // row = local / w without a per-output division: local < 2^16 (a rect has at most gx*gy tiles; images with more than 65535 tiles
+    // take the plain division below) and w < 2^16, so floor(local / w) == umulhi(local, floor((2^32 - 1) / w) + 1) exactly; one division per Gaussian
+    const uint32_t magic = 0xFFFFFFFFu / (uint32_t)w + 1u;
     // lanes past P take the end of the wave's range as offset so the search below never selects them
     uint32_t end = off + count;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(end, o, 64); end = t > end ? t : end; }
     if (k >= P) off = end;
     const uint32_t start = __shfl(off, 0, 64);
+    const uint32_t xy = (uint32_t)x0 | ((uint32_t)y0 << 16);
     for (uint32_t tb = start; tb < end; tb += 64) {       // wave-uniform trip count: every lane takes part in the shuffles
         const uint32_t t = tb + lane;
-        // largest lane i with off_i <= t (zero-count lanes share their successor's offset, so this is the owner)
-        int lo = 0;
+        // largest lane i with off_i <= t (zero-count lanes share their successor's offset, so this is the owner);
+        // branch-free and select-free: lo += step when the probe's offset is <= t
+        uint32_t lo = 0;
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-            const int probe = lo + step;
-            const uint32_t v = __shfl(off, probe, 64);
-            if (v <= t) lo = probe;
+        for (uint32_t step = 32; step > 0; step >>= 1) {
+            const uint32_t v = __shfl(off, (int)(lo + step), 64);
+            lo += step & (0u - (uint32_t)(v <= t));
         }
-        const uint32_t o_off = __shfl(off, lo, 64), o_gid = __shfl(gid, lo, 64);
-        const int o_x0 = __shfl(x0, lo, 64), o_y0 = __shfl(y0, lo, 64), o_w = __shfl(w, lo, 64);
+        const uint32_t o_off = __shfl(off, (int)lo, 64), o_gid = __shfl(gid, (int)lo, 64);
+        const uint32_t o_xy = __shfl(xy, (int)lo, 64), o_w = (uint32_t)__shfl(w, (int)lo, 64), o_magic = __shfl(magic, (int)lo, 64);
         const uint32_t local = t - o_off;
-        const int ty = o_y0 + (int)(local / (uint32_t)o_w), tx = o_x0 + (int)(local % (uint32_t)o_w);
+        uint32_t row = (o_w == 1u) ? local : __umulhi(local, o_magic);           // magic wraps to 0 for w == 1
+        if (gx * gy > 65535) row = local / o_w;                                   // > 4080 x 4080 pixels: plain division
+        const uint32_t ty = (o_xy >> 16) + row, tx = (o_xy & 0xFFFFu) + (local - row * o_w);
         if (t < end) {
-            tile_keys[t] = (uint32_t)(ty * gx + tx);
+            tile_keys[t] = ty * (uint32_t)gx + tx;
             vals[t] = o_gid;
         }
     }
