@@ -37,9 +37,50 @@ class ImgLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "ranges", "total")]
 
 
+class Ex4dSplitSH(C.Structure):          # include/ex4d_rasterizer.h: Ex4dSplitSH / Ex4dSplitSHGrad (same layout)
+    _fields_ = [("dc", C.c_void_p * 2), ("rest", C.c_void_p * 2), ("n_static", C.c_int32)]
+
+
+class SplitSH(tuple):
+    """The SH coefficients as CGaussianModel stores them -- (features_dc [Ns,1,3], features_rest [Ns,15,3],
+    features_dc_motion [Nd,1,3], features_rest_motion [Nd,15,3]) -- accepted wherever the `sh` / `shs` tensor goes:
+    rows [0,Ns) come from the first pair, rows [Ns,Ns+Nd) from the second, exactly get_features()'s concatenation
+    (scene/c_gaussian_model.py:337-353) without materialising it; the backward returns a SplitSH of the four gradients."""
+    def __new__(cls, dc_static, rest_static, dc_dynamic, rest_dynamic):
+        return super().__new__(cls, (dc_static, rest_static, dc_dynamic, rest_dynamic))
+
+    @property
+    def n_static(self):
+        return self[0].shape[0]
+
+    @property
+    def n_dynamic(self):
+        return self[2].shape[0]
+
+    def numel(self):
+        return sum(t.numel() for t in self)
+
+    def size(self, dim):
+        return (self.n_static + self.n_dynamic, 16, 3)[dim]
+
+
+def _split_struct(split, device, what):
+    keep, ptrs = [], []
+    for t, shape1 in zip(split, (1, 15, 1, 15)):
+        if t.dim() != 3 or t.shape[1] != shape1 or t.shape[2] != 3:
+            raise RuntimeError(f"{what}: expected [n,{shape1},3] tensors (dc/rest, static then dynamic)")
+        kt, pt = _dev_f32(t, what, device)
+        keep.append(kt); ptrs.append(pt)
+    if split[0].shape[0] != split[1].shape[0] or split[2].shape[0] != split[3].shape[0]:
+        raise RuntimeError(f"{what}: dc and rest must have the same number of rows")
+    st = Ex4dSplitSH((C.c_void_p * 2)(ptrs[0], ptrs[2]), (C.c_void_p * 2)(ptrs[1], ptrs[3]), int(split[0].shape[0]))
+    return keep, st
+
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forward", "ex4d_backward",
+           "ex4d_forward_split_sh", "ex4d_backward_split_sh",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
            "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset",
            "ex4d_profile_enable", "ex4d_profile_read")
@@ -69,6 +110,12 @@ def load():
     lib.ex4d_forward.argtypes = ([C.POINTER(Ex4dParams)] + [C.c_void_p] * 13 + [ALLOC_FN, C.c_void_p] * 3
                                  + [C.c_void_p] * 6 + [C.c_void_p, C.POINTER(C.c_int32)])
     lib.ex4d_backward.argtypes = [C.POINTER(Ex4dParams), C.c_int32] + [C.c_void_p] * 32
+    lib.ex4d_forward_split_sh.restype = C.c_int
+    lib.ex4d_backward_split_sh.restype = C.c_int
+    lib.ex4d_forward_split_sh.argtypes = ([C.POINTER(Ex4dParams)] + [C.c_void_p] * 3 + [C.POINTER(Ex4dSplitSH)] + [C.c_void_p] * 8
+                                          + [ALLOC_FN, C.c_void_p] * 3 + [C.c_void_p] * 6 + [C.c_void_p, C.POINTER(C.c_int32)])
+    lib.ex4d_backward_split_sh.argtypes = ([C.POINTER(Ex4dParams), C.c_int32] + [C.c_void_p] * 3 + [C.POINTER(Ex4dSplitSH)] + [C.c_void_p] * 21
+                                           + [C.POINTER(Ex4dSplitSH)] + [C.c_void_p] * 5)
     lib.ex4d_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
@@ -135,7 +182,12 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
     out_flow = torch.empty(3, H, W, **f32)
     out_idx = torch.empty(1, H, W, **i32)
 
-    M = sh.size(1) if sh.numel() != 0 else 0     # rasterize_points.cu:92-96
+    split = sh if isinstance(sh, SplitSH) else None
+    if split is not None:
+        if split.n_static + split.n_dynamic != P:
+            raise RuntimeError("SplitSH rows do not add up to the number of Gaussians")
+        sh = torch.empty(0, **f32)
+    M = 16 if split is not None else (sh.size(1) if sh.numel() != 0 else 0)     # rasterize_points.cu:92-96
     keep = []
     ptr = {}
     for name, t in (("background", background), ("means3D", means3D), ("dir3D", dir3D), ("sh", sh), ("colors", colors),
@@ -148,12 +200,24 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
     num_rendered = C.c_int32(0)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
-        code = lib.ex4d_forward(
-            C.byref(prm), ptr["background"], ptr["means3D"], ptr["dir3D"], ptr["sh"], ptr["colors"], ptr["opacity"],
-            ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
-            ptr["subpixel_offset"], cbs[0], None, cbs[1], None, cbs[2], None,
-            out_color.data_ptr(), radii.data_ptr(), out_depth.data_ptr(), out_acc.data_ptr(), out_flow.data_ptr(), out_idx.data_ptr(),
-            C.c_void_p(stream), C.byref(num_rendered))
+        if split is not None:
+            if colors.numel() != 0:
+                raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
+            kp, st = _split_struct(split, dev, "sh")
+            keep.append(kp)
+            code = lib.ex4d_forward_split_sh(
+                C.byref(prm), ptr["background"], ptr["means3D"], ptr["dir3D"], C.byref(st), ptr["opacity"],
+                ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
+                ptr["subpixel_offset"], cbs[0], None, cbs[1], None, cbs[2], None,
+                out_color.data_ptr(), radii.data_ptr(), out_depth.data_ptr(), out_acc.data_ptr(), out_flow.data_ptr(), out_idx.data_ptr(),
+                C.c_void_p(stream), C.byref(num_rendered))
+        else:
+            code = lib.ex4d_forward(
+                C.byref(prm), ptr["background"], ptr["means3D"], ptr["dir3D"], ptr["sh"], ptr["colors"], ptr["opacity"],
+                ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
+                ptr["subpixel_offset"], cbs[0], None, cbs[1], None, cbs[2], None,
+                out_color.data_ptr(), radii.data_ptr(), out_depth.data_ptr(), out_acc.data_ptr(), out_flow.data_ptr(), out_idx.data_ptr(),
+                C.c_void_p(stream), C.byref(num_rendered))
     _check(code)
     return (int(num_rendered.value), out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth, out_acc, out_flow, out_idx)
 
@@ -169,12 +233,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
-    M = sh.size(1) if sh.numel() != 0 else 0
     f32 = dict(dtype=torch.float32, device=dev)
-    shapes = [(P, 3), (P, NUM_CHANNELS), (P, 1), (P, 3), (P, 6), (P, M, 3), (P, 3), (P, 4), (P, 3)]
+    split = sh if isinstance(sh, SplitSH) else None
+    if split is not None:
+        sh = torch.empty(0, **f32)
+    M = 16 if split is not None else (sh.size(1) if sh.numel() != 0 else 0)
+    shapes = [(P, 3), (P, NUM_CHANNELS), (P, 1), (P, 3), (P, 6), (P, M, 3) if split is None else (0,), (P, 3), (P, 4), (P, 3)]
     if P == 0:   # rasterize_points.cu:189
-        return tuple(torch.zeros(*s, **f32) for s in shapes)
+        outs0 = [torch.zeros(*s, **f32) for s in shapes]
+        if split is not None:
+            outs0[5] = SplitSH(*[torch.zeros_like(t) for t in split])
+        return tuple(outs0)
     outs = [torch.empty(*s, **f32) for s in shapes]
+    if split is not None:
+        outs[5] = SplitSH(*[torch.empty_like(t, memory_format=torch.contiguous_format) for t in split])
     keep = []
     ptr = {}
     for name, t in (("background", background), ("means3D", means3D), ("sh", sh), ("colors", colors), ("scales", scales),
@@ -189,6 +261,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, False, debug)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
+        if split is not None:
+            kp, st = _split_struct(split, dev, "sh")
+            kg, gst = _split_struct(outs[5], dev, "dL_dsh")
+            keep += [kp, kg]
+            code = lib.ex4d_backward_split_sh(
+                C.byref(prm), C.c_int32(int(R)), ptr["background"], ptr["means3D"], radii_c.data_ptr(), C.byref(st),
+                ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
+                ptr["subpixel_offset"], ptr["acc_depth"], ptr["acc"],
+                geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
+                ptr["dL_dout_color"], ptr["dL_dout_depth"], ptr["dL_grad_out_flow"], ptr["dL_grad_out_acc"],
+                outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(),
+                C.byref(gst), outs[6].data_ptr(), outs[7].data_ptr(), outs[8].data_ptr(),
+                scratch.data_ptr(), C.c_void_p(stream))
+            _check(code)
+            rasterize_gaussians_backward.last_scratch = scratch
+            return tuple(outs)
         code = lib.ex4d_backward(
             C.byref(prm), C.c_int32(int(R)), ptr["background"], ptr["means3D"], radii_c.data_ptr(), ptr["sh"], ptr["colors"],
             ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],

@@ -56,7 +56,7 @@ def _ptr(t):
 
 class _EvaluateAttributes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scal, *params):
+    def forward(ctx, scal, with_shs, *params):
         lib = _lib()
         p = [x.contiguous() for x in params]
         dev = p[0].device
@@ -67,13 +67,15 @@ class _EvaluateAttributes(torch.autograd.Function):
                 raise RuntimeError("all model parameters must be float32 tensors on the same ROCm device")
         N = scal.Ns + scal.Nd
         f32 = dict(dtype=torch.float32, device=dev)
-        outs = [torch.empty(N, 3, **f32), torch.empty(N, 4, **f32), torch.empty(N, 1, **f32), torch.empty(N, 3, **f32), torch.empty(N, 16, 3, **f32)]
+        outs = [torch.empty(N, 3, **f32), torch.empty(N, 4, **f32), torch.empty(N, 1, **f32), torch.empty(N, 3, **f32),
+                torch.empty(N, 16, 3, **f32) if with_shs else torch.empty(0, **f32)]
         with torch.cuda.device(dev):
             rc = lib.ex4d_attributes_forward(C.byref(scal), *[_ptr(x) for x in p], *[_ptr(o) for o in outs],
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(lib.ex4d_attributes_last_error().decode())
         ctx.scal = scal
+        ctx.with_shs = with_shs
         ctx.save_for_backward(*p)
         return tuple(outs)
 
@@ -87,7 +89,10 @@ class _EvaluateAttributes(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         shapes = ((N, 3), (N, 4), (N, 1), (N, 3), (N, 16, 3))
         gin = [(torch.zeros(*s, **f32) if g is None else g.contiguous()) for g, s in zip((g_means3D, g_rotations, g_opacities, g_scales, g_shs), shapes)]
-        gout = [torch.empty_like(x) for x in p]
+        if not ctx.with_shs:
+            gin[4] = None                          # dL/dsh goes to the feature tensors through the rasterizer (SplitSH), not through here
+        feature_names = ("_features_dc", "_features_rest", "_features_dc_motion", "_features_rest_motion")
+        gout = [None if (not ctx.with_shs and n in feature_names) else torch.empty_like(x) for n, x in zip(PARAM_ORDER, p)]
         byname = dict(zip(PARAM_ORDER, p))
         with torch.cuda.device(dev):
             rc = lib.ex4d_attributes_backward(
@@ -96,13 +101,15 @@ class _EvaluateAttributes(torch.autograd.Function):
                 *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(lib.ex4d_attributes_last_error().decode())
-        return (None,) + tuple(gout)
+        return (None, None) + tuple(gout)
 
 
-def evaluate_attributes(params, t, duration=300, interval=10, time_shift=12, var_pad=3):
-    """params: mapping with the 15 CGaussianModel parameter tensors (PARAM_ORDER).  Returns the five boundary tensors."""
+def evaluate_attributes(params, t, duration=300, interval=10, time_shift=12, var_pad=3, with_shs=True):
+    """params: mapping with the 15 CGaussianModel parameter tensors (PARAM_ORDER).  Returns the five boundary tensors; with
+    with_shs=False the [N,16,3] SH block is not gathered (fifth value empty): hand the rasterizer a SplitSH of the four feature
+    tensors instead."""
     p = [params[n] for n in PARAM_ORDER]
     Ns, Nd = p[0].shape[0], p[7].shape[0]
     K = p[7].shape[1] if Nd > 0 else 0
     scal = time_scalars(t, Ns, Nd, K, duration, interval, time_shift, var_pad)
-    return _EvaluateAttributes.apply(scal, *p)
+    return _EvaluateAttributes.apply(scal, bool(with_shs), *p)

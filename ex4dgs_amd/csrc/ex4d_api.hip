@@ -180,8 +180,8 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out) { carve_img(nullp
 size_t ex4d_backward_scratch_bytes(int32_t P) { return ex4d_align_up((size_t)P * 16 * sizeof(float)); }
 size_t ex4d_backward_scratch_acc_offset(int32_t P) { (void)P; return 0; }
 
-int ex4d_forward(
-    const Ex4dParams *prm,
+static int forward_impl(
+    const Ex4dParams *prm, ShSplit split,
     const float *background, const float *means3D, const float *dir3D, const float *shs, const float *colors_precomp,
     const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
     const float *viewmatrix, const float *projmatrix, const float *campos, const float *subpixel_offset,
@@ -197,8 +197,10 @@ int ex4d_forward(
     if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
     if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !campos)
         return fail(EX4D_ERR_ARG, "means3D, opacities, background, viewmatrix, projmatrix, campos are required");
-    if ((shs == nullptr) == (colors_precomp == nullptr))
+    const bool is_split = split.rest[0] != nullptr || split.rest[1] != nullptr;
+    if (((shs != nullptr || is_split) ? 1 : 0) + (colors_precomp != nullptr ? 1 : 0) != 1 || (shs != nullptr && is_split))
         return fail(EX4D_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+    if (is_split && prm->M != 16) return fail(EX4D_ERR_ARG, "split SH needs M == 16 (dc [n,1,3] + rest [n,15,3])");
     if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
         ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr))
         return fail(EX4D_ERR_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
@@ -218,7 +220,7 @@ int ex4d_forward(
     HIP_TRY(hipMemsetAsync(g.total, 0, 2 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                                     viewmatrix, projmatrix, campos, radii, g, g.total + 1, stream), prm, stream);
+                                     viewmatrix, projmatrix, campos, radii, g, g.total + 1, split, stream), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
@@ -274,8 +276,8 @@ int ex4d_forward(
     return EX4D_OK;
 }
 
-int ex4d_backward(
-    const Ex4dParams *prm, int32_t num_rendered,
+static int backward_impl(
+    const Ex4dParams *prm, ShSplit split, ShSplitGrad gsplit, int32_t num_rendered,
     const float *background, const float *means3D, const int32_t *radii,
     const float *shs, const float *colors_precomp, const float *scales, const float *rotations,
     const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
@@ -292,7 +294,7 @@ int ex4d_backward(
     if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
     if (!geom_buffer || !binning_buffer || !img_buffer || !bwd_scratch) return fail(EX4D_ERR_ARG, "null state buffer");
     if (!dL_dout_color || !dL_dout_depth || !dL_dout_flow || !dL_dout_acc) return fail(EX4D_ERR_ARG, "null upstream gradient");
-    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh))
+    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
         return fail(EX4D_ERR_ARG, "null gradient output");
     GeomState g = carve_geom((void *)geom_buffer, P, nullptr, nullptr);
     BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, nullptr, nullptr);
@@ -311,9 +313,93 @@ int ex4d_backward(
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;            // rasterizer_impl.cu:460
     STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16,
                                      dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir,
-                                     stream), prm, stream);
+                                     split, gsplit, stream), prm, stream);
     MARK(1, "preprocess_bwd");
     return EX4D_OK;
+}
+
+static const ShSplit kNoSplit = { { nullptr, nullptr }, { nullptr, nullptr }, 0 };
+static const ShSplitGrad kNoSplitGrad = { { nullptr, nullptr }, { nullptr, nullptr }, 0 };
+
+int ex4d_forward(
+    const Ex4dParams *prm,
+    const float *background, const float *means3D, const float *dir3D, const float *shs, const float *colors_precomp,
+    const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *campos, const float *subpixel_offset,
+    ex4d_alloc_fn geom_alloc, void *geom_user, ex4d_alloc_fn binning_alloc, void *binning_user,
+    ex4d_alloc_fn img_alloc, void *img_user,
+    float *out_color, int32_t *radii, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx,
+    void *stream_, int32_t *num_rendered)
+{
+    return forward_impl(prm, kNoSplit, background, means3D, dir3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                        viewmatrix, projmatrix, campos, subpixel_offset, geom_alloc, geom_user, binning_alloc, binning_user,
+                        img_alloc, img_user, out_color, radii, out_depth, out_acc, out_flow, out_idx, stream_, num_rendered);
+}
+
+static bool split_ok(const Ex4dParams *prm, const float *const dc[2], const float *const rest[2], int n_static)
+{
+    if (!prm || n_static < 0 || n_static > prm->P) return false;
+    if (n_static > 0 && (!dc[0] || !rest[0])) return false;
+    if (n_static < prm->P && (!dc[1] || !rest[1])) return false;
+    return true;
+}
+
+int ex4d_forward_split_sh(
+    const Ex4dParams *prm, const float *background, const float *means3D, const float *dir3D, const Ex4dSplitSH *shs,
+    const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *campos, const float *subpixel_offset,
+    ex4d_alloc_fn geom_alloc, void *geom_user, ex4d_alloc_fn binning_alloc, void *binning_user,
+    ex4d_alloc_fn img_alloc, void *img_user,
+    float *out_color, int32_t *radii, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx,
+    void *stream_, int32_t *num_rendered)
+{
+    g_err[0] = 0;
+    if (!shs || !split_ok(prm, shs->dc, shs->rest, shs->n_static)) return fail(EX4D_ERR_ARG, "split SH: null tensor or n_static outside [0, P]");
+    const ShSplit sp = { { shs->dc[0], shs->dc[1] }, { shs->rest[0], shs->rest[1] }, shs->n_static };
+    return forward_impl(prm, sp, background, means3D, dir3D, nullptr, nullptr, opacities, scales, rotations, cov3D_precomp,
+                        viewmatrix, projmatrix, campos, subpixel_offset, geom_alloc, geom_user, binning_alloc, binning_user,
+                        img_alloc, img_user, out_color, radii, out_depth, out_acc, out_flow, out_idx, stream_, num_rendered);
+}
+
+int ex4d_backward(
+    const Ex4dParams *prm, int32_t num_rendered,
+    const float *background, const float *means3D, const int32_t *radii,
+    const float *shs, const float *colors_precomp, const float *scales, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    const float *subpixel_offset, const float *out_depth, const float *out_acc,
+    const void *geom_buffer, const void *binning_buffer, const void *img_buffer,
+    const float *dL_dout_color, const float *dL_dout_depth, const float *dL_dout_flow, const float *dL_dout_acc,
+    float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, void *bwd_scratch, void *stream_)
+{
+    return backward_impl(prm, kNoSplit, kNoSplitGrad, num_rendered, background, means3D, radii, shs, colors_precomp, scales, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, campos, subpixel_offset, out_depth, out_acc, geom_buffer, binning_buffer,
+                         img_buffer, dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                         dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir, bwd_scratch, stream_);
+}
+
+int ex4d_backward_split_sh(
+    const Ex4dParams *prm, int32_t num_rendered,
+    const float *background, const float *means3D, const int32_t *radii,
+    const Ex4dSplitSH *shs, const float *scales, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    const float *subpixel_offset, const float *out_depth, const float *out_acc,
+    const void *geom_buffer, const void *binning_buffer, const void *img_buffer,
+    const float *dL_dout_color, const float *dL_dout_depth, const float *dL_dout_flow, const float *dL_dout_acc,
+    float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, const Ex4dSplitSHGrad *dL_dsh,
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, void *bwd_scratch, void *stream_)
+{
+    g_err[0] = 0;
+    if (!shs || !dL_dsh || !split_ok(prm, shs->dc, shs->rest, shs->n_static) || dL_dsh->n_static != shs->n_static ||
+        !split_ok(prm, (const float *const *)dL_dsh->dc, (const float *const *)dL_dsh->rest, dL_dsh->n_static))
+        return fail(EX4D_ERR_ARG, "split SH: null tensor, n_static outside [0, P] or mismatching gradient split");
+    if (prm->M != 16) return fail(EX4D_ERR_ARG, "split SH needs M == 16 (dc [n,1,3] + rest [n,15,3])");
+    const ShSplit sp = { { shs->dc[0], shs->dc[1] }, { shs->rest[0], shs->rest[1] }, shs->n_static };
+    const ShSplitGrad gsp = { { dL_dsh->dc[0], dL_dsh->dc[1] }, { dL_dsh->rest[0], dL_dsh->rest[1] }, dL_dsh->n_static };
+    return backward_impl(prm, sp, gsp, num_rendered, background, means3D, radii, nullptr, nullptr, scales, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, campos, subpixel_offset, out_depth, out_acc, geom_buffer, binning_buffer,
+                         img_buffer, dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                         dL_dmeans3D, dL_dcov3D, nullptr, dL_dscales, dL_drotations, dL_ddir, bwd_scratch, stream_);
 }
 
 void ex4d_profile_enable(int on) { g_prof.on = on != 0; }

@@ -269,10 +269,12 @@ int ex4d_attributes_forward(const Ex4dAttrParams *a,
     if (a->Nd > 0 && (a->k < 1 || a->k + 2 >= a->K)) { snprintf(g_attr_err, sizeof(g_attr_err), "keyframe index %d needs k-1..k+2 inside [0,%d)", a->k, a->K); return EX4D_ERR_ARG; }
     hipLaunchKernelGGL(attributes_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, *a, xyz, xyz_disp, rotation, opacity, scaling,
         xyz_motion, rotation_motion, opacity_motion, dur_center, dur_var, scaling_motion, means3D, rotations, opacities, scales);
-    const size_t total = (size_t)N * 12;
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(features_kernel<true>, dim3(blocks), dim3(256), 0, stream, a->Ns, a->Nd, (float *)features_dc, (float *)features_rest,
-        (float *)features_dc_motion, (float *)features_rest_motion, shs);
+    if (shs) {       // NULL: the caller feeds the rasterizer the four feature tensors directly (Ex4dSplitSH), nothing to gather
+        const size_t total = (size_t)N * 12;
+        const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(features_kernel<true>, dim3(blocks), dim3(256), 0, stream, a->Ns, a->Nd, (float *)features_dc, (float *)features_rest,
+            (float *)features_dc_motion, (float *)features_rest_motion, shs);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_attr_err, sizeof(g_attr_err), "launch failed: %s", hipGetErrorString(e)); return EX4D_ERR_HIP; }
     return EX4D_OK;
@@ -303,10 +305,12 @@ int ex4d_attributes_backward(const Ex4dAttrParams *a,
         dur_center, dur_var, scaling_motion, g_means3D, g_rotations, g_opacities, g_scales,
         g_xyz, g_xyz_disp, g_rotation, g_opacity, g_scaling, g_xyz_motion, g_rotation_motion, g_opacity_motion, g_dur_center, g_dur_var,
         g_scaling_motion);
-    const size_t total = (size_t)N * 12;
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(features_kernel<false>, dim3(blocks), dim3(256), 0, stream, a->Ns, a->Nd, g_features_dc, g_features_rest,
-        g_features_dc_motion, g_features_rest_motion, (float *)g_shs);
+    if (g_shs) {     // NULL: dL/dsh was written into the four gradient tensors by the rasterizer itself (Ex4dSplitSHGrad)
+        const size_t total = (size_t)N * 12;
+        const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(features_kernel<false>, dim3(blocks), dim3(256), 0, stream, a->Ns, a->Nd, g_features_dc, g_features_rest,
+            g_features_dc_motion, g_features_rest_motion, (float *)g_shs);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_attr_err, sizeof(g_attr_err), "launch failed: %s", hipGetErrorString(e)); return EX4D_ERR_HIP; }
     return EX4D_OK;

@@ -56,11 +56,15 @@ struct ImgState {
 
 static inline uint32_t rs_num_blocks(uint32_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK; }
 
+// SH coefficients as the model stores them (include/ex4d_rasterizer.h: Ex4dSplitSH); all pointers null = one [P,M,3] tensor
+struct ShSplit { const float *dc[2]; const float *rest[2]; int n_static; };
+struct ShSplitGrad { float *dc[2]; float *rest[2]; int n_static; };
+
 // ---- launchers (each launches on `stream`, returns hipGetLastError()) -------------------------
 hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
-    int32_t *radii, GeomState g, uint32_t *prefilter_violation, hipStream_t stream);
+    int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split, hipStream_t stream);
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);
@@ -69,7 +73,7 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
     const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
     const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
     float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
-    float *dL_dscales, float *dL_drotations, float *dL_ddir, hipStream_t stream);
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, ShSplit split, ShSplitGrad gsplit, hipStream_t stream);
 
 // stable LSD radix sort of (key,value) uint32 pairs over key bits [0, end_bit); result lands in
 // (keys_out, vals_out) which must be one of the two ping-pong pairs; returns which through *result_in_a.

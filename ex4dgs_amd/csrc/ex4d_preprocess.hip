@@ -195,6 +195,72 @@ __device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, cons
     }
 }
 
+// The same rows taken from the four tensors the model keeps (dc [n,1,3] + rest [n,15,3], static rows first, then dynamic) --
+// saves the [P,16,3] concatenation pass (scene/c_gaussian_model.py:351-353) and, in the backward, the split of dL_dsh.
+// Inside one tensor the rows of a wave are ONE contiguous span (64 x 45 or 64 x 3 floats), so the copy is linear: no index
+// arithmetic, 16-byte accesses when the span is aligned.  The LDS slice keeps that linear layout (rest rows at stride 45,
+// dc rows at stride 3 behind them); a lane reads / writes its row with scalar LDS accesses at immediate offsets
+// (stride 45 is odd: conflict-free).  Only the single wave that straddles the static/dynamic boundary goes element by element.
+#define SH_SPLIT_DC_OFFSET (64 * 45)
+
+__device__ __forceinline__ void wave_copy_linear(float *__restrict__ dst, const float *__restrict__ src, int nfloats, int lane)
+{
+    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
+        const int n4 = nfloats >> 2;
+        for (int q = lane; q < n4; q += 64) reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(src)[q];
+        const int e = (n4 << 2) + lane;
+        if (e < nfloats) dst[e] = src[e];
+    } else {
+        for (int e = lane; e < nfloats; e += 64) dst[e] = src[e];
+    }
+}
+
+// nrows = rows of this wave that exist (<= 64)
+__device__ __forceinline__ void wave_load_sh_split(const ShSplit &sp, int wave_first, int nrows, float *lds, int lane)
+{
+    if (nrows > 0) {
+        const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
+        if (all_dynamic || all_static) {
+            const int part = all_dynamic ? 1 : 0;
+            const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
+            wave_copy_linear(lds, sp.rest[part] + r0 * 45, nrows * 45, lane);
+            wave_copy_linear(lds + SH_SPLIT_DC_OFFSET, sp.dc[part] + r0 * 3, nrows * 3, lane);
+        } else {
+            for (int e = lane; e < nrows * 45; e += 64) {
+                const int R = wave_first + e / 45, part = R >= sp.n_static;
+                lds[e] = sp.rest[part][(size_t)(R - (part ? sp.n_static : 0)) * 45 + e % 45];
+            }
+            for (int e = lane; e < nrows * 3; e += 64) {
+                const int R = wave_first + e / 3, part = R >= sp.n_static;
+                lds[SH_SPLIT_DC_OFFSET + e] = sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3];
+            }
+        }
+    }
+    wave_sync_lds();
+}
+
+__device__ __forceinline__ void wave_store_sh_split(const ShSplitGrad &sp, int wave_first, int nrows, const float *lds, int lane)
+{
+    wave_sync_lds();
+    if (nrows <= 0) return;
+    const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
+    if (all_dynamic || all_static) {
+        const int part = all_dynamic ? 1 : 0;
+        const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
+        wave_copy_linear(sp.rest[part] + r0 * 45, lds, nrows * 45, lane);
+        wave_copy_linear(sp.dc[part] + r0 * 3, lds + SH_SPLIT_DC_OFFSET, nrows * 3, lane);
+    } else {
+        for (int e = lane; e < nrows * 45; e += 64) {
+            const int R = wave_first + e / 45, part = R >= sp.n_static;
+            sp.rest[part][(size_t)(R - (part ? sp.n_static : 0)) * 45 + e % 45] = lds[e];
+        }
+        for (int e = lane; e < nrows * 3; e += 64) {
+            const int R = wave_first + e / 3, part = R >= sp.n_static;
+            sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3] = lds[SH_SPLIT_DC_OFFSET + e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
@@ -205,7 +271,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int prefiltered, uint32_t *__restrict__ prefilter_violation,
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
-    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t *__restrict__ total_instances)
+    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t *__restrict__ total_instances, const ShSplit sp)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -287,19 +353,33 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
     const int ncoef = (D + 1) * (D + 1);
     float coefv[16][3];
-    const bool staged = (shs != nullptr) && (M == 16);
+    const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
+    const bool staged = (shs != nullptr || split) && (M == 16);
     if (staged) {
         float *lds = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
         const uint64_t need = __ballot(visible);
-        wave_load_sh(shs + (size_t)(blockIdx.x * 256 + wave * 64) * 48, lds, need, (ncoef * 3 + 3) / 4, lane);
-        const float4 *row = reinterpret_cast<const float4 *>(lds + lane * SH_ROW);
+        const int wave_first = blockIdx.x * 256 + wave * 64;
         float tmp[48];
-        const int nvec = (ncoef * 3 + 3) / 4;
+        if (split) {
+            wave_load_sh_split(sp, wave_first, (P - wave_first) < 64 ? (P - wave_first) : 64, lds, lane);
 #pragma unroll
-        for (int v = 0; v < 12; v++) {
-            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (visible && v < nvec) t4 = row[v];
-            tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w;
+            for (int f = 0; f < 48; f++) tmp[f] = 0.f;
+            if (visible) {
+#pragma unroll
+                for (int f = 0; f < 3; f++) tmp[f] = lds[SH_SPLIT_DC_OFFSET + lane * 3 + f];
+#pragma unroll
+                for (int f = 3; f < 48; f++) if (f < ncoef * 3) tmp[f] = lds[lane * 45 + (f - 3)];
+            }
+        } else {
+            wave_load_sh(shs + (size_t)wave_first * 48, lds, need, (ncoef * 3 + 3) / 4, lane);
+            const float4 *row = reinterpret_cast<const float4 *>(lds + lane * SH_ROW);
+            const int nvec = (ncoef * 3 + 3) / 4;
+#pragma unroll
+            for (int v = 0; v < 12; v++) {
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (visible && v < nvec) t4 = row[v];
+                tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) { coefv[k][0] = tmp[3 * k]; coefv[k][1] = tmp[3 * k + 1]; coefv[k][2] = tmp[3 * k + 2]; }
@@ -419,18 +499,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const float *__restrict__ acc16,
     float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
-    float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir)
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir, const ShSplit sp, const ShSplitGrad gsp)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_range = idx < P;
     const bool visible = in_range && (radii[idx] > 0);
-    const bool staged = (shs != nullptr) && (M == 16);
+    const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
+    const bool staged = (shs != nullptr || split) && (M == 16);
     float *lds_row_base = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
     const int wave_first = blockIdx.x * 256 + wave * 64;
-    if (staged)
-        wave_load_sh(shs + (size_t)wave_first * 48, lds_row_base, __ballot(visible), ((D + 1) * (D + 1) * 3 + 3) / 4, lane);
+    if (staged) {
+        if (split) wave_load_sh_split(sp, wave_first, (P - wave_first) < 64 ? (P - wave_first) : 64, lds_row_base, lane);
+        else wave_load_sh(shs + (size_t)wave_first * 48, lds_row_base, __ballot(visible), ((D + 1) * (D + 1) * 3 + 3) / 4, lane);
+    }
     float g_mean2D[3] = { 0, 0, 0 }, g_color[3] = { 0, 0, 0 }, g_dir[3] = { 0, 0, 0 }, g_opacity = 0;
     float g_mean3D[3] = { 0, 0, 0 }, g_cov[6] = { 0, 0, 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_rot[4] = { 0, 0, 0, 0 };
     float g_sh[16][3];
@@ -490,12 +573,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         g_mean3D[1] = (pm[4] * m_w - pm[7] * mul1) * gx + (pm[5] * m_w - pm[7] * mul2) * gy + (pm[6] * m_w - pm[7] * mul3) * gz;
         g_mean3D[2] = (pm[8] * m_w - pm[11] * mul1) * gx + (pm[9] * m_w - pm[11] * mul2) * gy + (pm[10] * m_w - pm[11] * mul3) * gz;
 
-        if (shs) {
+        if (shs || split) {
             // SH backward, CR/backward.cu:20-139
             const float3 dir_orig = make_float3(mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]);
             const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
             const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-            const float *sh = staged ? (lds_row_base + lane * SH_ROW) : (shs + (size_t)idx * M * 3);
+            // split layout: rest rows at stride 45 (coefficient k >= 1 at 3 (k - 1)); only k >= 1 is read below
+            const float *sh = split ? (lds_row_base + lane * 45 - 3) : (staged ? (lds_row_base + lane * SH_ROW) : (shs + (size_t)idx * M * 3));
             const uint8_t cl = clamped[idx];
             float dRGB[3];
 #pragma unroll
@@ -618,15 +702,26 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (M == 16) {
         // dL_dsh of the wave = one contiguous 12 KB span: stage the rows in LDS, store fully coalesced
         wave_sync_lds();                       // all lanes finished reading their SH rows
-        float4 *row = reinterpret_cast<float4 *>(lds_row_base + lane * SH_ROW);
+        if (split) {
 #pragma unroll
-        for (int v = 0; v < 12; v++) {
-            float t[4];
+            for (int ch = 0; ch < 3; ch++) lds_row_base[SH_SPLIT_DC_OFFSET + lane * 3 + ch] = g_sh[0][ch];
 #pragma unroll
-            for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
-            row[v] = make_float4(t[0], t[1], t[2], t[3]);
+            for (int k = 1; k < 16; k++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) lds_row_base[lane * 45 + 3 * (k - 1) + ch] = g_sh[k][ch];
+        } else {
+            float4 *row = reinterpret_cast<float4 *>(lds_row_base + lane * SH_ROW);
+#pragma unroll
+            for (int v = 0; v < 12; v++) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
+                row[v] = make_float4(t[0], t[1], t[2], t[3]);
+            }
         }
-        wave_store_sh(dL_dsh + (size_t)wave_first * 48, lds_row_base, (P - wave_first) < 64 ? (P - wave_first) : 64, lane);
+        const int nrows_sh = (P - wave_first) < 64 ? (P - wave_first) : 64;
+        if (split) wave_store_sh_split(gsp, wave_first, nrows_sh, lds_row_base, lane);
+        else wave_store_sh(dL_dsh + (size_t)wave_first * 48, lds_row_base, nrows_sh, lane);
         wave_sync_lds();
     }
     {
@@ -659,7 +754,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
-    int32_t *radii, GeomState g, uint32_t *prefilter_violation, hipStream_t stream)
+    int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split, hipStream_t stream)
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
@@ -668,7 +763,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, g.sort_keys_a, g.depth_order, g.block_totals);
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, g.sort_keys_a, g.depth_order, g.block_totals, split);
     return hipGetLastError();
 }
 
@@ -684,13 +779,13 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
     const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
     const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
     float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
-    float *dL_dscales, float *dL_drotations, float *dL_ddir, hipStream_t stream)
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, ShSplit split, ShSplitGrad gsplit, hipStream_t stream)
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:417-418
     const float fx = prm.W / (2.0f * prm.tanfovx);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
         prm.P, prm.D, prm.M, means3D, radii, shs, g.clamped, scales, rotations, prm.scale_modifier, cov3D_ptr,
         viewmatrix, projmatrix, campos, prm.W, prm.H, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16,
-        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir);
+        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir, split, gsplit);
     return hipGetLastError();
 }

@@ -8,6 +8,11 @@
 
 so that gaussian_renderer.render(), train.py and render.py of the reference run unchanged with
 `ex4dgs_amd/` on sys.path.  The native layer underneath is ex4dgs_amd._C (ctypes -> libex4d_hip.so).
+
+One extension: wherever `shs` goes, a `SplitSH(features_dc, features_rest, features_dc_motion, features_rest_motion)` is accepted
+too -- the four tensors CGaussianModel.get_features() concatenates every frame (scene/c_gaussian_model.py:337-353).  The kernels
+then read the coefficients where the model keeps them and write dL/dsh straight into four gradient tensors: no [P,16,3] copy
+forward, no split backward.
 """
 from typing import NamedTuple
 
@@ -15,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _C
+from .._C import SplitSH
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -55,8 +61,11 @@ def _call_native(fn, args, debug, dump_name, what):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, *split):
         s = raster_settings
+        ctx.split = len(split) == 4
+        if ctx.split:
+            sh = SplitSH(*split)
         # positional order of RasterizeGaussiansCUDA (rasterize_points.cu:36-60)
         args = (s.bg, means3D, dir3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                 s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size, s.subpixel_offset,
@@ -65,8 +74,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, args, s.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
-                              geomBuffer, binningBuffer, imgBuffer, depth, acc, flow)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, torch.Tensor([]) if ctx.split else sh,
+                              geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, *split)
         ctx.mark_non_differentiable(radii, idxs)
         return color, radii, depth, flow, acc, idxs
 
@@ -74,7 +83,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii, grad_out_depth, grad_out_flow, grad_out_acc, _grad_idx):
         s = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
-         geomBuffer, binningBuffer, imgBuffer, depth, acc, _flow) = ctx.saved_tensors
+         geomBuffer, binningBuffer, imgBuffer, depth, acc, _flow) = ctx.saved_tensors[:13]
+        if ctx.split:
+            sh = SplitSH(*ctx.saved_tensors[13:])
         # positional order of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:136-166)
         args = (s.bg, means3D, radii, colors_precomp, scales, rotations, depth, acc, s.min_depth, s.max_depth,
                 s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size,
@@ -84,11 +95,17 @@ class _RasterizeGaussians(torch.autograd.Function):
          grad_scales, grad_rotations, grad_dir3D) = _call_native(
             _C.rasterize_gaussians_backward, args, s.debug, "snapshot_bw.dump", "backward")
         # one gradient per forward input, in input order (reference :165-176)
+        if ctx.split:
+            return (grad_means3D, grad_means2D, grad_dir3D, None, grad_colors_precomp, grad_opacities,
+                    grad_scales, grad_rotations, grad_cov3Ds_precomp, None, *grad_sh)
         return (grad_means3D, grad_means2D, grad_dir3D, grad_sh, grad_colors_precomp, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, None)
 
 
 def rasterize_gaussians(means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    if isinstance(sh, SplitSH):
+        return _RasterizeGaussians.apply(means3D, means2D, dir3D, torch.Tensor([]), colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings, *sh)
     return _RasterizeGaussians.apply(means3D, means2D, dir3D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 

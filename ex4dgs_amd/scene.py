@@ -130,12 +130,13 @@ class DynamicGaussians:
                    "_xyz_motion", "_rotation_motion", "_opacity_motion", "_opacity_duration_center",
                    "_opacity_duration_var", "_scaling_motion", "_features_dc_motion", "_features_rest_motion")
 
-    def __init__(self, params, duration=300, interval=10, time_pad=2, var_pad=3, kernel_size=0.1, sh_degree=3, fused=False):
+    def __init__(self, params, duration=300, interval=10, time_pad=2, var_pad=3, kernel_size=0.1, sh_degree=3, fused=False, split_sh=True):
         for n in self.PARAM_NAMES:
             setattr(self, n, params[n])
         # fused=True: the five getters are served by ONE fused HIP evaluation per (timestamp, parameter version)
         # (ex4dgs_amd.attributes) instead of ~15 torch kernels + 3 torch.cat copies
         self.fused = fused
+        self.split_sh = split_sh        # with fused: get_features() hands the four feature tensors to the rasterizer, no [N,16,3] copy
         self._fused_key = None
         self._fused_out = None
         self.duration = max(duration, 1)
@@ -175,7 +176,8 @@ class DynamicGaussians:
         self._last_t = t
         if key != self._fused_key:
             self._fused_out = evaluate_attributes({n: getattr(self, n) for n in self.PARAM_NAMES}, t, duration=self.duration,
-                                                  interval=self.interval, time_shift=self.time_shift, var_pad=self.var_pad)
+                                                  interval=self.interval, time_shift=self.time_shift, var_pad=self.var_pad,
+                                                  with_shs=not self.split_sh)
             self._fused_key = key
         return self._fused_out
 
@@ -222,6 +224,10 @@ class DynamicGaussians:
         return torch.exp(torch.cat([self._scaling, self._scaling_motion], dim=0))   # :335
 
     def get_features(self):
+        if self.fused and self.split_sh:
+            # zero-copy: the rasterizer reads the four tensors where they are (diff_gaussian_rasterization_df.SplitSH)
+            from ._C import SplitSH
+            return SplitSH(self._features_dc, self._features_rest, self._features_dc_motion, self._features_rest_motion)
         if self.fused:
             return self._fused_time_independent(4)
         s = torch.cat((self._features_dc, self._features_rest), dim=1)
@@ -262,7 +268,7 @@ CONFIGS = {
 }
 
 
-def make_scene(cfg, P=None, device="cpu", duration=300, fused=False):
+def make_scene(cfg, P=None, device="cpu", duration=300, fused=False, split_sh=True):
     """Returns (DynamicGaussians, Camera, bg[3]).  Distributions: SURVEY.md 8(d)."""
     if isinstance(cfg, str):
         cfg = CONFIGS[cfg]
@@ -298,7 +304,7 @@ def make_scene(cfg, P=None, device="cpu", duration=300, fused=False):
         _opacity_duration_center=centers, _opacity_duration_var=N(Nd, 2, 1), _scaling_motion=torch.log(scale[Ns:]),
         _features_dc_motion=f_dc[Ns:], _features_rest_motion=f_rest[Ns:])
     params = {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in params.items()}
-    model = DynamicGaussians(params, duration=duration, fused=fused)
+    model = DynamicGaussians(params, duration=duration, fused=fused, split_sh=split_sh)
     cam = focal_camera(cfg.width, cfg.height, cfg.focal, znear=0.01, zfar=100.0, cxr=cfg.cxr, cyr=cfg.cyr).to(device)
     bg = U(3).to(device)
     return model, cam, bg

@@ -36,7 +36,9 @@ typedef struct Ex4dAttrParams {
 
 const char *ex4d_attributes_last_error(void);
 
-/* Forward.  Parameters in CGaussianModel order; outputs means3D[N,3], rotations[N,4], opacities[N,1], scales[N,3], shs[N,16,3]. */
+/* Forward.  Parameters in CGaussianModel order; outputs means3D[N,3], rotations[N,4], opacities[N,1], scales[N,3], shs[N,16,3].
+ * shs may be NULL (then the four feature tensors are not read): the rasterizer can take them as they are, see Ex4dSplitSH in
+ * ex4d_rasterizer.h; likewise g_shs may be NULL in the backward (the four feature gradients are then not written). */
 int ex4d_attributes_forward(const Ex4dAttrParams *a,
     const float *xyz /*[Ns,3]*/, const float *xyz_disp /*[Ns,3]*/, const float *rotation /*[Ns,4]*/, const float *opacity /*[Ns,1]*/,
     const float *scaling /*[Ns,3]*/, const float *features_dc /*[Ns,1,3]*/, const float *features_rest /*[Ns,15,3]*/,

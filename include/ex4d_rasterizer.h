@@ -122,6 +122,36 @@ int ex4d_backward(
 
 size_t ex4d_backward_scratch_bytes(int32_t P);
 
+/*
+ * The same two calls with the SH coefficients given AS THE MODEL STORES THEM instead of one concatenated [P,16,3] tensor:
+ * rows [0, n_static) are (dc[0] [n,1,3], rest[0] [n,15,3]), rows [n_static, P) are (dc[1], rest[1]) -- the four tensors
+ * CGaussianModel.get_features concatenates every frame (scene/c_gaussian_model.py:337-353: two torch.cat of 192 B/Gaussian,
+ * and their split in the backward).  M must be 16; colors_precomp is not used.  Everything else as ex4d_forward/backward;
+ * the backward writes dL/dsh straight into the four gradient tensors (fully written).
+ */
+typedef struct Ex4dSplitSH { const float *dc[2]; const float *rest[2]; int32_t n_static; } Ex4dSplitSH;
+typedef struct Ex4dSplitSHGrad { float *dc[2]; float *rest[2]; int32_t n_static; } Ex4dSplitSHGrad;
+
+int ex4d_forward_split_sh(
+    const Ex4dParams *prm, const float *background, const float *means3D, const float *dir3D, const Ex4dSplitSH *shs,
+    const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,
+    const float *viewmatrix, const float *projmatrix, const float *campos, const float *subpixel_offset,
+    ex4d_alloc_fn geom_alloc, void *geom_user, ex4d_alloc_fn binning_alloc, void *binning_user,
+    ex4d_alloc_fn img_alloc, void *img_user,
+    float *out_color, int32_t *radii, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx,
+    void *stream, int32_t *num_rendered);
+
+int ex4d_backward_split_sh(
+    const Ex4dParams *prm, int32_t num_rendered,
+    const float *background, const float *means3D, const int32_t *radii,
+    const Ex4dSplitSH *shs, const float *scales, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    const float *subpixel_offset, const float *out_depth, const float *out_acc,
+    const void *geom_buffer, const void *binning_buffer, const void *img_buffer,
+    const float *dL_dout_color, const float *dL_dout_depth, const float *dL_dout_flow, const float *dL_dout_acc,
+    float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, const Ex4dSplitSHGrad *dL_dsh,
+    float *dL_dscales, float *dL_drotations, float *dL_ddir, void *bwd_scratch, void *stream);
+
 /* markVisible: replaces Rasterizer::markVisible (rasterizer_impl.cu:143-159); present[P] bytes (0/1). */
 int ex4d_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                       float min_depth, float max_depth, uint8_t *present, void *stream);

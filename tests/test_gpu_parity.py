@@ -616,3 +616,65 @@ def test_fused_training_loop_end_to_end(hip_lib):
         losses.append(float(loss))
     assert all(np.isfinite(losses))
     assert np.mean(losses[-4:]) < 0.9 * np.mean(losses[:4]), losses
+
+
+# ------------------------------------------------------------------ zero-copy SH: the four feature tensors instead of cat()
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ns,Nd,D", [(3000, 1000, 3), (2999, 1001, 3), (4000, 0, 3), (0, 4000, 3), (1, 3999, 2), (3967, 33, 1), (2000, 2000, 0)])
+def test_split_sh_is_bit_identical_to_concatenated(hip_lib, Ns, Nd, D):
+    """SplitSH(dc, rest, dc_motion, rest_motion) through the autograd surface == the same call with the concatenated [P,16,3]
+    tensor: every output bit-identical, dL/dsh bit-identical after splitting, every other gradient bit-identical."""
+    from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSettings, GaussianRasterizer, SplitSH
+    from ex4dgs_amd.scene import make_scene
+    import math as m
+    P = Ns + Nd
+    model, cam, bg = make_scene("cfg3", P=P, device="cuda")
+    t = 137
+    with torch.no_grad():
+        means3D, opac, scl, rot = model.get_xyz_at_t(t), model.get_opacity_at_t(t), model.get_scaling(), model.get_rotation_at_t(t)
+        feats = model.get_features()                                   # [P,16,3]
+    parts = [feats[:Ns, :1].clone(), feats[:Ns, 1:].clone(), feats[Ns:, :1].clone(), feats[Ns:, 1:].clone()]
+    H, W = 512, 640
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=m.tan(cam.FoVx * 0.5), tanfovy=m.tan(cam.FoVy * 0.5), kernel_size=0.1,
+        subpixel_offset=torch.zeros(H, W, 2, device="cuda"), bg=bg.cuda(), scale_modifier=1.0, viewmatrix=cam.world_view_transform.cuda(),
+        projmatrix=cam.full_proj_transform.cuda(), sh_degree=D, campos=cam.camera_center.cuda(), prefiltered=False,
+        min_depth=4.0, max_depth=300.0, debug=False)
+    ras = GaussianRasterizer(settings)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ups = [torch.randn(3, H, W, generator=g, device="cuda"), torch.randn(1, H, W, generator=g, device="cuda") * 0.1,
+           torch.rand(3, H, W, generator=g, device="cuda"), torch.randn(1, H, W, generator=g, device="cuda") * 0.1]
+
+    def run(shs_arg, leaves):
+        ins = [x.clone().requires_grad_(True) for x in (means3D, opac, scl, rot)]
+        m2d = torch.zeros(P, 3, device="cuda", requires_grad=True); d3 = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        out = ras(means3D=ins[0], means2D=m2d, dir3D=d3, opacities=ins[1], shs=shs_arg, scales=ins[2], rotations=ins[3])
+        torch.autograd.backward([out[0], out[2], out[3], out[4]], ups)
+        return out, [x.grad for x in ins + [m2d, d3]], [l.grad for l in leaves]
+    whole = feats.clone().requires_grad_(True)
+    out_a, g_a, (gsh_a,) = run(whole, [whole])
+    leaves = [p_.clone().requires_grad_(True) for p_ in parts]
+    out_b, g_b, gsh_b = run(SplitSH(*leaves), leaves)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+    # gradients accumulate with float atomics in arbitrary order: reproducible to rounding, like two runs of the same call
+    for a, b in zip(g_a, g_b):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()) + 1e-12)
+    ref_parts = [gsh_a[:Ns, :1], gsh_a[:Ns, 1:], gsh_a[Ns:, :1], gsh_a[Ns:, 1:]]
+    for a, b in zip(ref_parts, gsh_b):
+        assert a.shape == b.shape
+        torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-6 * float(gsh_a.abs().max()) + 1e-12)
+        assert torch.equal(b == 0, a == 0)                               # inactive degrees / invisible rows are exact zeros
+
+
+@pytest.mark.gpu
+def test_split_sh_argument_checks(hip_lib):
+    from ex4dgs_amd import _C
+    from ex4dgs_amd._C import SplitSH
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    good = SplitSH(z(5, 1, 3), z(5, 15, 3), z(3, 1, 3), z(3, 15, 3))
+    assert good.n_static == 5 and good.n_dynamic == 3 and good.size(0) == 8 and good.size(1) == 16
+    with pytest.raises(RuntimeError, match="expected"):
+        _C._split_struct(SplitSH(z(5, 1, 3), z(5, 14, 3), z(3, 1, 3), z(3, 15, 3)), torch.device("cuda", 0), "sh")
+    with pytest.raises(RuntimeError, match="same number of rows"):
+        _C._split_struct(SplitSH(z(5, 1, 3), z(4, 15, 3), z(3, 1, 3), z(3, 15, 3)), torch.device("cuda", 0), "sh")
