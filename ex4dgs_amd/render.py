@@ -18,6 +18,18 @@ from .diff_gaussian_rasterization_df import GaussianRasterizationSettings, Gauss
 DEFAULT_PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 
+_ZERO_OFFSETS = {}
+
+
+def _zero_offsets(H, W, device):
+    """The all-zero [H,W,2] subpixel offset the reference allocates and fills on every call (gaussian_renderer/__init__.py:39-40);
+    it is read-only, so one tensor per (H, W, device) is kept."""
+    key = (H, W, str(device))
+    if key not in _ZERO_OFFSETS:
+        _ZERO_OFFSETS[key] = torch.zeros((H, W, 2), dtype=torch.float32, device=device)
+    return _ZERO_OFFSETS[key]
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, timestamp=None, scaling_modifier=1.0, override_color=None,
            subpixel_offset=None, mode=0, training=False, near=0.2, far=100.0, sync=True):
     pipe = DEFAULT_PIPE if pipe is None else pipe
@@ -25,17 +37,17 @@ def render(viewpoint_camera, pc, pipe, bg_color, timestamp=None, scaling_modifie
     means3D = pc.get_xyz_at_t(timestamp)
     device = means3D.device
 
-    # gradient traps: the 2D-mean gradient lands in screenspace_points.grad, the per-Gaussian
-    # "flow"/error channel gradient in flow.grad (gaussian_renderer/__init__.py:28-32, :66-70)
-    screenspace_points = torch.zeros_like(means3D, requires_grad=True) + 0
-    flow = torch.zeros_like(means3D, requires_grad=True) + 0
-    if screenspace_points.requires_grad:           # under torch.no_grad() (evaluation) there is nothing to retain (:30-33 try/except)
-        screenspace_points.retain_grad()
-        flow.retain_grad()
+    # gradient traps: the 2D-mean gradient lands in screenspace_points.grad, the per-Gaussian "flow"/error channel gradient
+    # in flow.grad (gaussian_renderer/__init__.py:28-32, :66-70).  The reference builds both as `zeros(requires_grad=True) + 0`
+    # plus retain_grad(); leaf tensors receive the same gradients without the `+ 0` copies, and the VALUES of means2D are never
+    # read by the rasterizer (only dir3D's are: it is composited into the flow image), so that one need not even be filled.
+    track = torch.is_grad_enabled()
+    screenspace_points = torch.empty_like(means3D, requires_grad=track)
+    flow = torch.zeros_like(means3D, requires_grad=track)
 
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     if subpixel_offset is None:
-        subpixel_offset = torch.zeros((H, W, 2), dtype=torch.float32, device=device)
+        subpixel_offset = _zero_offsets(H, W, device)
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W,
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
