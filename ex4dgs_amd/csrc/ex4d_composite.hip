@@ -38,7 +38,7 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // gfx950 issues the VOP2 encoding of v_cndmask_b32 (implicit VCC) in ~24 cycles but the VOP3 encoding in ~5 (measured,
-// tests/dev_micro/pk_rate.hip), and the compiler shrinks every select whose condition sits in VCC to VOP2.  Selects and
+// tools/dev/micro/pk_rate.hip), and the compiler shrinks every select whose condition sits in VCC to VOP2.  Selects and
 // wave votes inside the per-Gaussian loops are therefore spelled out: condition as a 64-bit lane mask in SGPRs.
 // Conditions are kept as 64-bit lane masks in SGPRs: a ballot of ONE compare is the v_cmp itself, masks combine on the
 // scalar unit, "no lane" is a scalar test (a ballot of a combined bool costs a v_cndmask + v_cmp round trip instead).

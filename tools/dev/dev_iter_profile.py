@@ -1,6 +1,6 @@
 """Dev script (not a test): the fused full training iteration (getters -> render -> L1+SSIM -> backward -> RAdam), for rocprofv3."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ex4dgs_amd.scene import make_scene, CONFIGS
 from ex4dgs_amd.render import render

@@ -1,6 +1,6 @@
 """Dev script (not a test): distCUDA2 timing at 1M points."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ex4dgs_amd.simple_knn._C import distCUDA2
 for P in (100_000, 1_000_000):

@@ -1,6 +1,6 @@
 """Dev script (not a test): times the reference-style torch L1+SSIM loss against the fused HIP op at N3V resolution."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from math import exp
 from ex4dgs_amd.loss import l1_ssim_loss

@@ -1,6 +1,6 @@
 """Dev script (not a test): time torch.optim.RAdam vs FusedRAdam over the 15 parameter groups of a cfg3-sized model."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ex4dgs_amd.scene import make_scene
 from ex4dgs_amd.optim import FusedRAdam
