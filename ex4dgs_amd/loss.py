@@ -119,3 +119,34 @@ def l1_ssim_loss_unfused(image, gt_image, lambda_dssim=0.2):
     l1e = (image - gt_image).abs().mean(dim=0)
     sse = ssim_map(image, gt_image).mean(dim=0)
     return loss, l1e.detach(), sse.detach()
+
+
+# ---- the reference's metric functions by name (utils/loss_utils.py:22-25, :47-52; utils/image_utils.py:17-19), so that
+# `from utils.loss_utils import l1_loss, ssim` / `from utils.image_utils import psnr` can point here -------------------------
+def l1_loss(network_output, gt, mask=None):
+    if mask is not None:
+        return torch.abs((network_output - gt)[mask]).mean()
+    return torch.abs(network_output - gt).mean()
+
+
+def ssim(img1, img2, window_size=WINDOW_SIZE, size_average=True, reduce=True):
+    """SSIM with the reference's signature, on [C,H,W] or [1,C,H,W] tensors, through the fused HIP op (differentiable w.r.t.
+    img1).  reduce=True -> scalar mean; reduce=False -> the [C,H,W] map (one fused call per channel, not differentiable)."""
+    if window_size != WINDOW_SIZE or not size_average:
+        raise NotImplementedError("only the configuration the reference uses: window_size=11, size_average=True")
+    a = img1[0] if img1.dim() == 4 else img1
+    b = img2[0] if img2.dim() == 4 else img2
+    if img1.dim() == 4 and img1.shape[0] != 1:
+        raise NotImplementedError("batched SSIM is not used by the reference (render.py:77 passes one image)")
+    if reduce:
+        loss, _, _ = l1_ssim_loss(a, b.detach(), 1.0)           # lambda = 1: loss = 1 - mean(ssim_map)
+        return 1.0 - loss
+    with torch.no_grad():
+        maps = [l1_ssim_loss(a[c:c + 1].contiguous(), b[c:c + 1].contiguous(), 1.0)[2] for c in range(a.shape[0])]
+        out = torch.stack(maps)
+    return out.unsqueeze(0) if img1.dim() == 4 else out
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))

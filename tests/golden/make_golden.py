@@ -146,6 +146,13 @@ def golden_loss():
             k = f"{name}/lam{lam}/"
             out[k + "loss"] = np.float32(loss.item()); out[k + "Ll1"] = np.float32(Ll1.item())
             out[k + "grad"] = x.grad.numpy().copy(); out[k + "l1_errors"] = l1e.numpy(); out[k + "ssim_errors"] = sse.numpy()
+        from utils.image_utils import psnr
+        with torch.no_grad():
+            xi, yi = torch.tensor(img), torch.tensor(gt)
+            out[name + "/ssim"] = np.float32(ssim(xi.unsqueeze(0), yi.unsqueeze(0)).item())        # render.py:77 call form
+            out[name + "/ssim_map"] = ssim(xi, yi, reduce=False).numpy()                              # train.py:150 call form
+            out[name + "/psnr"] = psnr(xi.unsqueeze(0), yi.unsqueeze(0)).numpy()                      # render.py:76
+            out[name + "/Ll1"] = np.float32(l1_loss(xi, yi).item())
         out[name + "/image"] = img; out[name + "/gt"] = gt
     np.savez_compressed(os.path.join(OUT, "loss_l1_ssim.npz"), **out)
     return len(out)

@@ -678,3 +678,22 @@ def test_split_sh_argument_checks(hip_lib):
         _C._split_struct(SplitSH(z(5, 1, 3), z(5, 14, 3), z(3, 1, 3), z(3, 15, 3)), torch.device("cuda", 0), "sh")
     with pytest.raises(RuntimeError, match="same number of rows"):
         _C._split_struct(SplitSH(z(5, 1, 3), z(4, 15, 3), z(3, 1, 3), z(3, 15, 3)), torch.device("cuda", 0), "sh")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["noise", "smooth", "tiny"])
+def test_metric_functions_by_reference_name(hip_lib, name):
+    """l1_loss / ssim / psnr with the reference's signatures and call forms (train.py:144-150,182; render.py:76-77)."""
+    from ex4dgs_amd.loss import l1_loss, ssim, psnr
+    g = np.load(os.path.join(h.ROOT, "tests", "golden", "loss_l1_ssim.npz"))
+    x = torch.tensor(g[name + "/image"], device="cuda", requires_grad=True)
+    y = torch.tensor(g[name + "/gt"], device="cuda")
+    flat = name == "smooth"
+    s4 = ssim(x.unsqueeze(0), y.unsqueeze(0))
+    assert abs(float(s4) - float(g[name + "/ssim"])) < (3e-6 if flat else 1e-6)
+    (1.0 - s4).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    m = ssim(x.detach(), y, reduce=False)
+    np.testing.assert_allclose(m.cpu().numpy(), g[name + "/ssim_map"], rtol=0, atol=1e-3 if flat else 2e-5)
+    assert abs(float(l1_loss(x, y)) - float(g[name + "/Ll1"])) < 1e-7
+    np.testing.assert_allclose(psnr(x.detach().unsqueeze(0), y.unsqueeze(0)).cpu().numpy(), g[name + "/psnr"], rtol=1e-6)
