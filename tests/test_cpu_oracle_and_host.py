@@ -405,6 +405,25 @@ def test_ply_checkpoint_format_round_trip_and_layout(tmp_path):
     assert sout["_xyz_motion"].shape == smodel._xyz_motion.shape and torch.equal(sout["_xyz"], smodel._xyz)
 
 
+# ------------------------------------------------------------------ INTEGRATION.md route A: the drop-in import names resolve
+def test_drop_in_packages_import_under_the_reference_names():
+    """With ex4dgs_amd/dropin in front on sys.path, the reference's own import lines (gaussian_renderer/__init__.py:15,
+    scene/c_gaussian_model.py:20) resolve to this repository's packages -- and nothing else of the reference is shadowed."""
+    code = ("from diff_gaussian_rasterization_df import GaussianRasterizationSettings, GaussianRasterizer, SplitSH\n"
+            "from simple_knn._C import distCUDA2\n"
+            "import diff_gaussian_rasterization_df as d, simple_knn._C as k\n"
+            "print(d.__file__); print(k.__file__); print(len(GaussianRasterizationSettings._fields))\n"
+            "import importlib.util as u\n"
+            "print([n for n in ('scene', 'utils', 'render', 'train', 'arguments', 'gaussian_renderer', 'loss', 'optim') if u.find_spec(n)])")
+    env = dict(os.environ, PYTHONPATH=os.path.join(h.ROOT, "ex4dgs_amd", "dropin"))
+    out = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0].startswith(os.path.join(h.ROOT, "ex4dgs_amd", "dropin", "diff_gaussian_rasterization_df"))
+    assert lines[1].startswith(os.path.join(h.ROOT, "ex4dgs_amd", "dropin", "simple_knn")) and lines[2] == "16"
+    assert lines[3] == "[]", lines[3]            # module names of the reference stay free
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
