@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the Gaussian count (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="render only (BASELINE config 5 is quoted as forward-only FPS); not the headline metric")
     ap.add_argument("--no-model-step", action="store_true", help="skip the training-iteration timings (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
@@ -231,7 +232,7 @@ def main():
     dir3D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
 
     buckets = None
-    if world > 1 and not args.no_allreduce:
+    if world > 1 and not args.no_allreduce and not args.forward_only:
         buckets = xdist.GradBuckets([x.shape for x in frames[0]], device=dev)
     info = {}
 
@@ -240,6 +241,11 @@ def main():
         xyz, shs, opa, scl, rot = frames[f]
         for t in frames[f] + [means2D[f], dir3D[f]]:
             t.grad = None
+        if args.forward_only:
+            with torch.no_grad():
+                color, radii, depth, flow, acc, idx = rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)
+            info["radii"] = radii
+            return color
         color, radii, depth, flow, acc, idx = rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)
         torch.autograd.backward([color, depth, flow, acc], [grads[0], grads[1], grads[2], grads[3]])
         if buckets is not None:
@@ -327,8 +333,9 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "fwd+bwd ms/frame @1M Gaussians 1352x1014; achieved HBM GB/s vs peak" if args.config == "cfg3" and args.points is None
-                      else f"fwd+bwd ms/frame ({cfg.name})",
+            "metric": (f"forward-only ms/frame ({cfg.name})" if args.forward_only else
+                       "fwd+bwd ms/frame @1M Gaussians 1352x1014; achieved HBM GB/s vs peak" if args.config == "cfg3" and args.points is None
+                       else f"fwd+bwd ms/frame ({cfg.name})"),
             "value": round(ms_per_step / world, 4), "unit": "ms/frame", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
