@@ -232,7 +232,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     _require_rocm(means3D, "means3D")
     dev = means3D.device
     P = means3D.size(0)
-    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    H, W = acc_depth.size(1), acc_depth.size(2)      # forward output [1,H,W]; any upstream gradient may be absent (empty = zeros)
     f32 = dict(dtype=torch.float32, device=dev)
     split = sh if isinstance(sh, SplitSH) else None
     if split is not None:

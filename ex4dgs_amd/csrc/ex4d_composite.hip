@@ -317,12 +317,13 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     const float final_depth = p.inside ? depth_acc[p.pix_id] : 0.f;
     float gdepth = 0.f, gflow0 = 0.f, gflow1 = 0.f, gflow2 = 0.f, gacc = 0.f, gp0 = 0.f, gp1 = 0.f, gp2 = 0.f;
     if (p.inside) {
-        gdepth = dL_ddepths[p.pix_id];
-        gp0 = dL_dpixels[p.pix_id]; gp1 = dL_dpixels[HW + p.pix_id]; gp2 = dL_dpixels[2 * HW + p.pix_id];
+        // a null upstream gradient = that output did not take part in the loss (autograd would otherwise materialise zeros)
+        if (dL_ddepths) gdepth = dL_ddepths[p.pix_id];
+        if (dL_dpixels) { gp0 = dL_dpixels[p.pix_id]; gp1 = dL_dpixels[HW + p.pix_id]; gp2 = dL_dpixels[2 * HW + p.pix_id]; }
         if (acc > 0.0f) {
             gdepth /= acc;
-            gflow0 = dL_dflows[p.pix_id] / acc; gflow1 = dL_dflows[HW + p.pix_id] / acc; gflow2 = dL_dflows[2 * HW + p.pix_id] / acc;
-            gacc = dL_daccs[p.pix_id];
+            if (dL_dflows) { gflow0 = dL_dflows[p.pix_id] / acc; gflow1 = dL_dflows[HW + p.pix_id] / acc; gflow2 = dL_dflows[2 * HW + p.pix_id] / acc; }
+            if (dL_daccs) gacc = dL_daccs[p.pix_id];
         }
     }
     const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);

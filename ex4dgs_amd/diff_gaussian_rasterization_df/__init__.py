@@ -74,6 +74,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, args, s.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
+        # outputs that take no part in the loss arrive in backward as None instead of freshly filled zero tensors
+        # (the native backward treats a null upstream gradient as zeros)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, torch.Tensor([]) if ctx.split else sh,
                               geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, *split)
         ctx.mark_non_differentiable(radii, idxs)
@@ -84,6 +87,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, depth, acc, _flow) = ctx.saved_tensors[:13]
+        none = torch.Tensor([])
+        grad_out_color = none if grad_out_color is None else grad_out_color
+        grad_out_depth = none if grad_out_depth is None else grad_out_depth
+        grad_out_flow = none if grad_out_flow is None else grad_out_flow
+        grad_out_acc = none if grad_out_acc is None else grad_out_acc
         if ctx.split:
             sh = SplitSH(*ctx.saved_tensors[13:])
         # positional order of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:136-166)

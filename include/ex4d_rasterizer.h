@@ -113,7 +113,7 @@ int ex4d_backward(
     const float *out_depth, const float *out_acc,            /* forward outputs [1,H,W] */
     const void *geom_buffer, const void *binning_buffer, const void *img_buffer,
     const float *dL_dout_color /*[3,H,W]*/, const float *dL_dout_depth /*[1,H,W]*/,
-    const float *dL_dout_flow /*[3,H,W]*/, const float *dL_dout_acc /*[1,H,W]*/,
+    const float *dL_dout_flow /*[3,H,W]*/, const float *dL_dout_acc /*[1,H,W]*/,   /* each may be NULL = zeros */
     float *dL_dmeans2D /*[P,3]*/, float *dL_dcolors /*[P,3]*/, float *dL_dopacity /*[P,1]*/,
     float *dL_dmeans3D /*[P,3]*/, float *dL_dcov3D /*[P,6]*/, float *dL_dsh /*[P,M,3]*/,
     float *dL_dscales /*[P,3]*/, float *dL_drotations /*[P,4]*/, float *dL_ddir /*[P,3]*/,

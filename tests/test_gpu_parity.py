@@ -697,3 +697,28 @@ def test_metric_functions_by_reference_name(hip_lib, name):
     np.testing.assert_allclose(m.cpu().numpy(), g[name + "/ssim_map"], rtol=0, atol=1e-3 if flat else 2e-5)
     assert abs(float(l1_loss(x, y)) - float(g[name + "/Ll1"])) < 1e-7
     np.testing.assert_allclose(psnr(x.detach().unsqueeze(0), y.unsqueeze(0)).cpu().numpy(), g[name + "/psnr"], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_absent_upstream_gradients_equal_zero_gradients(hip_lib):
+    """A loss that uses only some of the outputs: autograd passes None for the others; the native backward treats a null
+    upstream gradient as zeros, so no zero tensors are materialised -- same result as explicit zeros (to summation order)."""
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.render import render
+    model, cam, bg = make_scene("cfg3", P=20_000, device="cuda")
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+
+    def grads(loss_fn):
+        for p_ in model.parameters():
+            p_.grad = None
+        out = render(cam, model, None, bg, timestamp=137, near=4.0, far=300.0)
+        loss_fn(out).backward()
+        return [p_.grad.clone() for p_ in model.parameters()], out["viewspace_points"].grad.clone()
+    w = torch.rand(3, cam.image_height, cam.image_width, device="cuda")
+    a, a2d = grads(lambda o: (o["render"] * w).sum())
+    b, b2d = grads(lambda o: (o["render"] * w).sum() + 0.0 * (o["depth"].sum() + o["opticalflow"].sum() + o["acc"].sum()))
+    for x, y in zip(a + [a2d], b + [b2d]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
+    c, _ = grads(lambda o: o["depth"].mean() + o["acc"].mean())          # colour gradient absent
+    assert all(torch.isfinite(t).all() for t in c) and float(sum(t.abs().sum() for t in c)) > 0
