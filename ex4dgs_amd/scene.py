@@ -156,6 +156,13 @@ class DynamicGaussians:
     def parameters(self):
         return [getattr(self, n) for n in self.PARAM_NAMES]
 
+    def zero_grad(self, set_to_none=True):
+        for p in self.parameters():
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
     @property
     def num_static(self):
         return self._xyz.shape[0]

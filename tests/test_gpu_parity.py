@@ -722,3 +722,9 @@ def test_absent_upstream_gradients_equal_zero_gradients(hip_lib):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
     c, _ = grads(lambda o: o["depth"].mean() + o["acc"].mean())          # colour gradient absent
     assert all(torch.isfinite(t).all() for t in c) and float(sum(t.abs().sum() for t in c)) > 0
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke(hip_lib):
+    import __graft_entry__
+    __graft_entry__.smoke()
