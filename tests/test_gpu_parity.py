@@ -728,3 +728,13 @@ def test_absent_upstream_gradients_equal_zero_gradients(hip_lib):
 def test_graft_entry_smoke(hip_lib):
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.gpu
+def test_more_than_65535_tiles(hip_lib):
+    """4112x4112 = 257x257 = 66049 tiles: 17 tile-key bits (three radix passes) and the plain-division path of the
+    instance expansion (its exact multiply-high row/column split is only used up to 65535 tiles)."""
+    from ex4dgs_amd.scene import SceneConfig
+    cfg = SceneConfig("huge: 4112x4112", 1500, 4112, 4112, 2200.0, seed=31, sigma_px_med=30.0)
+    o, g, *_ = _fwd_bwd(cfg)
+    assert o["ranges"].shape[0] == 257 * 257 and o["num_rendered"] > 20000
