@@ -738,3 +738,11 @@ def test_more_than_65535_tiles(hip_lib):
     cfg = SceneConfig("huge: 4112x4112", 1500, 4112, 4112, 2200.0, seed=31, sigma_px_med=30.0)
     o, g, *_ = _fwd_bwd(cfg)
     assert o["ranges"].shape[0] == 257 * 257 and o["num_rendered"] > 20000
+
+
+@pytest.mark.gpu
+def test_edge_cases_of_the_fused_training_path(hip_lib):
+    """Static-only model through attributes -> SplitSH render -> loss -> FusedRAdam (empty dynamic tensors everywhere), tiny
+    images through the loss, coincident points through distCUDA2, P == 0 through the autograd surface."""
+    import runpy
+    runpy.run_path(os.path.join(h.ROOT, "tools", "dev", "edge_cases.py"), run_name="__main__")
