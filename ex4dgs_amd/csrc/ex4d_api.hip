@@ -237,7 +237,7 @@ static int forward_impl(
     if (!in_a) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
     MARK(0, "depth_sort");
     // 3. instance offsets in depth order + total
-    STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, stream), prm, stream);
+    STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, stream), prm, stream);
     MARK(0, "scan_tiles");
     // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
     HIP_TRY(hipEventSynchronize(g_readback.ev));

@@ -190,8 +190,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 
 // ---------------------------------------------------------------- scan of tiles_touched in depth order
 __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint2 *__restrict__ rects,
-    const uint32_t *__restrict__ order, uint2 *__restrict__ sorted_rects, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums)
+    const uint32_t *__restrict__ order, uint2 *__restrict__ sorted_rects, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums,
+    int T, uint2 *__restrict__ ranges)
 {
+    // every kernel launch costs ~5 us of ramp and tail on this part: the zero-fill of the tile ranges (cudaMemset at
+    // CR/rasterizer_impl.cu:328) rides along here instead of being its own launch
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < T; i += gridDim.x * 256) ranges[i] = make_uint2(0u, 0u);
     // coalesced (striped) global accesses, blocked scan: counts go through LDS; each thread scans 8 consecutive items,
     // then wave + block scan of the thread totals
     __shared__ uint32_t cnt[SCAN_CHUNK];
@@ -231,33 +235,6 @@ __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint
     if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + x;
 }
 
-// single block: exclusive scan of block sums in place; grand total -> *total
-__global__ __launch_bounds__(256) void scan_block_sums_kernel(int nblocks, uint32_t *__restrict__ block_sums, uint32_t *__restrict__ total)
-{
-    __shared__ uint32_t wave_sums[4];
-    __shared__ uint32_t carry_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += 256) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? block_sums[i] : 0;
-        uint32_t x = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) wave_sums[wave] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wave_sums[w];
-        const uint32_t carry = carry_s;
-        if (i < nblocks) block_sums[i] = carry + woff + x - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_s = carry + woff + x;
-        __syncthreads();
-    }
-    (void)total;
-}
-
 // ---------------------------------------------------------------- duplication
 // The 64 Gaussians of a wave are consecutive in depth order, so their instances form ONE contiguous output
 // range.  The wave walks that range 64 outputs at a time: every lane finds the Gaussian owning its output
@@ -274,13 +251,27 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
     int x0 = 0, y0 = 0, w = 1;
     if (k < P) {
         gid = order[k];
-        // exclusive offset = inclusive scan value of the previous element (+ its block's base)
-        off = (k == 0) ? 0u : (sorted_offsets[k - 1] + block_sums[(k - 1) / SCAN_CHUNK]);
+        // exclusive offset = inclusive scan value of the previous element (+ its scan chunk's base, below)
+        off = (k == 0) ? 0u : sorted_offsets[k - 1];
         const uint2 rc = sorted_rects[k];                 // getRect (CR/auxiliary.h:46-56) was evaluated once, by the preprocess kernel
         x0 = (int)(rc.x & 0xFFFFu); y0 = (int)(rc.x >> 16);
         w = (int)(rc.y & 0xFFFFu);
         count = (uint32_t)w * (rc.y >> 16);
         if (w <= 0) w = 1;
+    }
+    // base of a scan chunk = sum of the chunk totals before it.  The (k-1) of a wave lie in at most two chunks; the wave sums
+    // the few hundred totals itself instead of a one-workgroup scan kernel in between (one launch less)
+    {
+        const int kf = blockIdx.x * 256 + (threadIdx.x & ~63) - 1;            // k - 1 of the wave's first lane (may be -1)
+        const int c0 = kf < 0 ? 0 : kf / SCAN_CHUNK;
+        uint32_t part = 0;
+        for (int j = lane; j < c0; j += 64) part += block_sums[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (k > 0 && k < P) {
+            const int c = (k - 1) / SCAN_CHUNK;
+            off += part + (c > c0 ? block_sums[c0] : 0u);
+        }
     }
     // row = local / w without a per-output division: local < 2^16 (a rect has at most gx*gy tiles; images with more than 65535 tiles
     // take the plain division below) and w < 2^16, so floor(local / w) == umulhi(local, floor((2^32 - 1) / w) + 1) exactly; one division per Gaussian
@@ -316,11 +307,6 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
 }
 
 // ---------------------------------------------------------------- tile ranges
-__global__ __launch_bounds__(256) void zero_ranges_kernel(int T, uint2 *__restrict__ ranges)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < T) ranges[i] = make_uint2(0u, 0u);
-}
 __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint32_t *__restrict__ tile_ids, uint2 *__restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -369,11 +355,10 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
 }
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
-    uint32_t *block_sums, hipStream_t stream)
+    uint32_t *block_sums, int T, uint2 *ranges, hipStream_t stream)
 {
     const int nb = (P + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, rects, order, sorted_rects, sorted_offsets, block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(256), 0, stream, nb, block_sums, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, rects, order, sorted_rects, sorted_offsets, block_sums, T, ranges);
     return hipGetLastError();
 }
 
@@ -388,7 +373,7 @@ hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, con
 
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream)
 {
-    hipLaunchKernelGGL(zero_ranges_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, ranges);
+    (void)T;      // the ranges were zeroed by the scan kernel
     if (R > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, tile_ids, ranges);
     return hipGetLastError();

@@ -82,7 +82,7 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
 size_t ex4d_radix_hist_words(uint32_t n);
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
-    uint32_t *block_sums, hipStream_t stream);
+    uint32_t *block_sums, int T, uint2 *ranges, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
