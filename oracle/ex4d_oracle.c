@@ -440,8 +440,10 @@ void ex4d_oracle_render_fwd(
     const float *bg_color, float min_depth, float max_depth,
     float *final_T, uint32_t *n_contrib,
     float *out_color /*[3,H,W]*/, float *out_depth, float *out_acc, float *out_flow /*[3,H,W]*/, int32_t *out_idx,
-    float *fragile /* may be NULL */)
+    float *fragile /* may be NULL */, float *idx_margin /* may be NULL */)
 {
+    /* idx_margin (optional, test instrumentation): per pixel, the smallest relative difference of any "alpha*T > max_vis"
+     * comparison that decides the dominant index: an argmax over float weights swaps on 1-ulp differences when two weights tie */
     (void)min_depth;
     const int gx = (W + BLOCK_X - 1) / BLOCK_X;
     for (int py = 0; py < H; py++)
@@ -458,7 +460,7 @@ void ex4d_oracle_render_fwd(
             float C[3] = { 0, 0, 0 };
             float Dm = 0.0f, acc = 0.0f, max_vis = 0.0f;
             float F[3] = { 0, 0, 0 };
-            float frag = 1.0f;
+            float frag = 1.0f, imarg = 1.0f;
             int done = 0;
             /* toDo is a signed int in the reference; r1 >= r0 always */
             for (uint32_t k = r0; k < r1 && !done; k++) {
@@ -484,6 +486,10 @@ void ex4d_oracle_render_fwd(
                 Dm += dep * alpha * T;
                 acc += alpha * T;
                 for (int ch = 0; ch < 3; ch++) F[ch] += dir3D[id * 3 + ch] * alpha * T;
+                if (idx_margin) {
+                    const float wv = alpha * T, big = fmaxf(wv, max_vis);
+                    if (big > 0.0f) { const float m = fabsf(wv - max_vis) / big; if (m < imarg) imarg = m; }
+                }
                 if (alpha * T > max_vis) { max_vis = alpha * T; out_idx[pix_id] = (int32_t)id; }
                 T = test_T;
                 last_contributor = contributor;
@@ -499,6 +505,7 @@ void ex4d_oracle_render_fwd(
             out_acc[pix_id] = acc;
             for (int ch = 0; ch < 3; ch++) out_flow[(size_t)ch * H * W + pix_id] = F[ch];
             if (fragile) fragile[pix_id] = frag;
+            if (idx_margin) idx_margin[pix_id] = imarg;
         }
 }
 

@@ -138,11 +138,12 @@ def forward(means3D, dir3D, opacities, *, shs=None, colors_precomp=None, scales=
     out["final_T"] = np.zeros((H, W), np.float32)
     out["n_contrib"] = np.zeros((H, W), np.uint32)
     out["fragile"] = np.ones((H, W), np.float32) if want_fragile else None
+    out["idx_margin"] = np.ones((H, W), np.float32) if want_fragile else None
     L.ex4d_oracle_render_fwd(
         C.c_int(W), C.c_int(H), _p(b["ranges"]), _p(b["point_list"]), _p(sub), _p(g["means2D"]), _p(features),
         _p(g["conic_opacity"]), _p(g["depths"]), _p(dir3D), _p(bg), C.c_float(min_depth), C.c_float(max_depth),
         _p(out["final_T"]), _p(out["n_contrib"]), _p(out["color"]), _p(out["depth"]), _p(out["acc"]), _p(out["flow"]),
-        _p(out["idx"]), _p(out["fragile"]))
+        _p(out["idx"]), _p(out["fragile"]), _p(out["idx_margin"]))
     out["_inputs"] = dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                           cov3D_precomp=cov3D_precomp, bg=bg, vm=vm, pm=pm, cp=cp, sub=sub, tanfovx=float(tanfovx),
                           tanfovy=float(tanfovy), kernel_size=float(kernel_size), scale_modifier=float(scale_modifier),

@@ -149,11 +149,13 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4):
             assert err[:, ~solid].max() < 0.05 * max(1.0, np.abs(a).max()), f"{k}: fragile pixel error too large"
     if P:
         # the dominant index is an argmax over float weights alpha*T: two Gaussians whose weights agree to a few ulp swap places
-        # with a 1-ulp exp() difference (seen: 2 of 16.9 M pixels at 4112x4112).  Bit-equal except for a bounded handful.
+        # with a 1-ulp exp() difference.  The oracle reports the smallest relative margin of the deciding comparisons per pixel;
+        # pixels with a margin under 1e-4 are excluded (and bounded in number), everywhere else the index is bit-equal.
         a, b = o["idx"][0], to_np(g["idx"])[0]
-        n_bad = int((a[solid] != b[solid]).sum())
-        rep["idx_mismatches"] = n_bad
-        assert n_bad <= max(0, int(1e-6 * solid.sum())), f"dominant index differs on {n_bad} non-fragile pixels"
+        decided = solid & (o["idx_margin"] > 1e-4) if o.get("idx_margin") is not None else solid
+        rep["idx_undecided_frac"] = float(1.0 - decided.sum() / max(1, solid.sum()))
+        assert rep["idx_undecided_frac"] <= 5e-3, rep
+        assert np.array_equal(a[decided], b[decided]), "dominant index differs on pixels whose argmax is not a near-tie"
         a, b = o["n_contrib"].astype(np.int64), to_np(g["n_contrib"]).astype(np.int64)
         assert np.array_equal(a[solid], b[solid]), "n_contrib differs on non-fragile pixels"
         a, b = o["final_T"], to_np(g["final_T"])
