@@ -104,10 +104,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
+        // unconditional loads from a clamped index (no exec-masked branch per item): the waits before the first ranking steps
+        // can then count outstanding loads instead of draining all 32
         const uint32_t i = base + it * 64 + lane;
-        const bool valid = i < n;
-        key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
-        val[it] = valid ? vals_in[i] : 0u;
+        const uint32_t ic = i < n ? i : n - 1;
+        key[it] = keys_in[ic];
+        val[it] = vals_in[ic];
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
