@@ -48,27 +48,34 @@ class FusedRAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib()
         batches = {}                               # (device, betas, eps) -> descriptors
+        touched = []                               # tensors the library writes: their autograd version counters are bumped below
+        f32 = torch.float32
         for group in self.param_groups:
+            key_tail = (tuple(group["betas"]), float(group["eps"]))
+            lr = float(group["lr"])
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue                       # like torch: tensors without a gradient keep their step count
                 if not p.is_cuda:
                     raise RuntimeError(f"parameter on {p.device}: FusedRAdam only runs on a ROCm GPU (no CPU fallback)")
-                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous():
+                if p.dtype != f32 or g.dtype != f32 or g.is_sparse or not p.is_contiguous():
                     raise RuntimeError("FusedRAdam: parameters and gradients must be dense contiguous float32")
                 state = self.state[p]
                 if len(state) == 0:
-                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["step"] = torch.tensor(0.0, dtype=f32)
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                step_t = state["step"]
+                step_t += 1
+                if not g.is_contiguous():
+                    g = g.contiguous()
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous()):
                     raise RuntimeError("FusedRAdam: optimizer state must be contiguous")
-                key = (p.device, tuple(group["betas"]), float(group["eps"]))
-                batches.setdefault(key, []).append(
-                    (Ex4dRadamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(group["lr"]), int(state["step"].item())), g))
+                batches.setdefault((p.device,) + key_tail, []).append(
+                    (Ex4dRadamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step_t.item())), g))
+                touched += (p, m, v)
         for (dev, betas, eps), items in batches.items():
             with torch.cuda.device(dev):
                 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -79,11 +86,6 @@ class FusedRAdam(torch.optim.Optimizer):
                         raise RuntimeError(lib.ex4d_optim_last_error().decode())
         # the library wrote through raw pointers: tell autograd the tensors changed (version counters), exactly what the
         # in-place torch ops of torch.optim.RAdam do -- caches keyed on parameter versions depend on it
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is not None:
-                    st = self.state[p]
-                    torch.autograd.graph.increment_version(p)
-                    torch.autograd.graph.increment_version(st["exp_avg"])
-                    torch.autograd.graph.increment_version(st["exp_avg_sq"])
+        if touched:
+            torch.autograd.graph.increment_version(touched)
         return loss
