@@ -95,6 +95,27 @@ class GradBuckets:
             self._tensors = None
 
 
+def reduce_densification_stats(sums=(), maxima=(), minima=(), group=None):
+    """In-place all-reduce of the running statistics the reference's densification reads every `densification_interval`
+    iterations (scene/c_gaussian_model.py:1095-1145; train.py:210-211): SUM for the accumulators and their denominators
+    (xyz_gradient_accum, denom, xyz_error_accum, xyz_ssim_error_accum, error_denom and the motion twins), MAX for
+    max_radii2D, MIN for min_radii2D / *_error_min.  Same-op tensors travel as one flat message.
+    No-op for single-process runs."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    for tensors, op in ((list(sums), dist.ReduceOp.SUM), (list(maxima), dist.ReduceOp.MAX), (list(minima), dist.ReduceOp.MIN)):
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.all_reduce(flat, op=op, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+
+
 def allreduce_max_scalar(value, device="cpu"):
     """max over ranks of a Python float (used for the max-over-ranks step time of bench.py)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):

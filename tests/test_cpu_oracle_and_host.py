@@ -506,6 +506,12 @@ for a, w in zip(mine, want):
     assert torch.allclose(a, w, atol=1e-6), (a - w).abs().max()
 m = xd.allreduce_max_scalar(1.0 + rank)
 assert m == 2.0
+# densification statistics at their cadence: SUM / MAX / MIN over ranks, several tensors per message
+acc = torch.full((40, 1), 1.0 + rank); den = torch.full((40, 1), 2.0 * (rank + 1)); rad = torch.arange(40.) * (1 if rank else -1)
+emin = torch.full((40, 1), 5.0 - rank); mx_i = torch.tensor([3 + rank, 9 - rank], dtype=torch.int32)
+xd.reduce_densification_stats(sums=[acc, den], maxima=[rad, mx_i], minima=[emin])
+assert torch.equal(acc, torch.full((40, 1), 3.0)) and torch.equal(den, torch.full((40, 1), 6.0))
+assert torch.equal(rad, torch.arange(40.)) and torch.equal(emin, torch.full((40, 1), 4.0)) and mx_i.tolist() == [4, 9]
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 print("OK", rank)
 """
