@@ -763,3 +763,64 @@ def test_randomised_parity_sweep(hip_lib):
         assert e.value.code == 0
     finally:
         sys.argv = argv
+
+
+# ------------------------------------------------------------------ multi-process data path on the GPU (2 ranks share cuda:0)
+_DP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from ex4dgs_amd import dist as xd
+from ex4dgs_amd.scene import make_scene
+from ex4dgs_amd.render import render
+os.environ["LOCAL_RANK"] = "0"                       # both ranks on the one GPU of the box
+rank, world, local = xd.init_from_env(backend="gloo")
+model, cam, bg = make_scene("cfg3", P=20000, device="cuda", fused=True)
+params = model.parameters()
+for p in params:
+    p.requires_grad_(True)
+views = xd.shard_views(4, rank, world)              # 4 timestamps, round-robin
+stamps = [0, 100, 200, 299]
+w = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5)).cuda()
+for v in views:
+    out = render(cam, model, None, bg, timestamp=stamps[v], near=4.0, far=300.0)
+    (out["render"] * w).sum().backward()
+grads = [p.grad for p in params]
+b = xd.GradBuckets([g.shape for g in grads], device="cuda", bucket_bytes=1 << 20, inplace_bytes=1 << 20)
+b.launch(grads); b.wait()
+if rank == 0:
+    torch.save([g.cpu() for g in grads], sys.argv[2])
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("OK", rank)
+"""
+
+
+@pytest.mark.gpu
+def test_frame_sharded_gradients_equal_single_process_sum(hip_lib, tmp_path):
+    """SURVEY 8(e) end to end on real kernels: two processes (sharing this box's one GPU, gloo) render the views
+    i = rank (mod 2), all-reduce the parameter gradients through GradBuckets; the result equals one process
+    accumulating all four views (to float-atomic summation order)."""
+    import subprocess
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.render import render
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    out_file = str(tmp_path / "grads.pt")
+    port = 29700 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), h.ROOT, out_file], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o
+    got = torch.load(out_file)
+    model, cam, bg = make_scene("cfg3", P=20000, device="cuda", fused=True)
+    params = model.parameters()
+    for p in params:
+        p.requires_grad_(True)
+    w = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5)).cuda()
+    for t in (0, 100, 200, 299):
+        out = render(cam, model, None, bg, timestamp=t, near=4.0, far=300.0)
+        (out["render"] * w).sum().backward()
+    for name, p, g in zip(model.PARAM_NAMES, params, got):
+        torch.testing.assert_close(g.cuda(), p.grad, rtol=2e-4, atol=2e-6 * float(p.grad.abs().max()) + 1e-12, msg=lambda m: f"{name}: {m}")
