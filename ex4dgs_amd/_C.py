@@ -139,6 +139,20 @@ def _dev_f32(t, name, device):
     return t, t.data_ptr()
 
 
+def _rows(t, name, rows, cols=None):
+    """Raw pointers carry no shape: a per-Gaussian tensor with fewer rows than P (or an image-sized one with the wrong element
+    count) would be read out of bounds by the kernels, so shapes are checked here."""
+    if t is None or t.numel() == 0:
+        return
+    if t.size(0) != rows or (cols is not None and t.numel() != rows * cols):
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {rows} rows" + (f" of {cols} values" if cols else ""))
+
+
+def _numel(t, name, n):
+    if t is not None and t.numel() not in (0, n):
+        raise RuntimeError(f"{name} has {t.numel()} elements, expected {n}")
+
+
 def _require_rocm(t, name):
     if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}: the ex4dgs_amd rasterizer only runs on a ROCm GPU (no CPU fallback)")
@@ -188,6 +202,14 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
             raise RuntimeError("SplitSH rows do not add up to the number of Gaussians")
         sh = torch.empty(0, **f32)
     M = 16 if split is not None else (sh.size(1) if sh.numel() != 0 else 0)     # rasterize_points.cu:92-96
+    for name, t, cols in (("dir3D", dir3D, 3), ("colors", colors, NUM_CHANNELS), ("opacity", opacity, 1), ("scales", scales, 3),
+                          ("rotations", rotations, 4), ("cov3D_precomp", cov3D_precomp, 6), ("sh", sh, 3 * M)):
+        _rows(t, name, P, cols)
+    _numel(subpixel_offset, "subpixel_offset", 2 * H * W)
+    _numel(background, "background", NUM_CHANNELS)
+    for name, t in (("viewmatrix", viewmatrix), ("projmatrix", projmatrix)):
+        _numel(t, name, 16)
+    _numel(campos, "campos", 3)
     keep = []
     ptr = {}
     for name, t in (("background", background), ("means3D", means3D), ("dir3D", dir3D), ("sh", sh), ("colors", colors),
@@ -239,6 +261,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         sh = torch.empty(0, **f32)
     M = 16 if split is not None else (sh.size(1) if sh.numel() != 0 else 0)
     shapes = [(P, 3), (P, NUM_CHANNELS), (P, 1), (P, 3), (P, 6), (P, M, 3) if split is None else (0,), (P, 3), (P, 4), (P, 3)]
+    for name, t, cols in (("radii", radii, 1), ("colors", colors, NUM_CHANNELS), ("scales", scales, 3), ("rotations", rotations, 4),
+                          ("cov3D_precomp", cov3D_precomp, 6), ("sh", sh, 3 * M)):
+        _rows(t, name, P, cols)
+    if split is not None and split.n_static + split.n_dynamic != P:
+        raise RuntimeError("SplitSH rows do not add up to the number of Gaussians")
+    _numel(subpixel_offset, "subpixel_offset", 2 * H * W)
+    for name, t, n in (("acc", acc, H * W), ("dL_dout_color", dL_dout_color, NUM_CHANNELS * H * W), ("dL_dout_depth", dL_dout_depth, H * W),
+                       ("dL_grad_out_flow", dL_grad_out_flow, 3 * H * W), ("dL_grad_out_acc", dL_grad_out_acc, H * W),
+                       ("viewmatrix", viewmatrix, 16), ("projmatrix", projmatrix, 16), ("campos", campos, 3)):
+        _numel(t, name, n)
     if P == 0:   # rasterize_points.cu:189
         outs0 = [torch.zeros(*s, **f32) for s in shapes]
         if split is not None:
@@ -302,7 +334,11 @@ def mark_visible(means3D, viewmatrix, projmatrix, min_depth, max_depth=3.4028234
     present = torch.zeros(P, dtype=torch.bool, device=dev)
     if P == 0:
         return present
-    m = means3D.contiguous(); v = viewmatrix.contiguous(); p = projmatrix.contiguous()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    (m, _), (v, _), (p, _) = _dev_f32(means3D, "means3D", dev), _dev_f32(viewmatrix, "viewmatrix", dev), _dev_f32(projmatrix, "projmatrix", dev)
+    if v is None or p is None or v.numel() != 16 or p.numel() != 16:
+        raise RuntimeError("viewmatrix and projmatrix must be 4x4 float32 tensors")
     with torch.cuda.device(dev):
         _check(lib.ex4d_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), C.c_float(min_depth), C.c_float(max_depth),
                                      present.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))

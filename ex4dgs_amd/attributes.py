@@ -56,7 +56,7 @@ def _ptr(t):
 
 class _EvaluateAttributes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scal, with_shs, *params):
+    def forward(ctx, scal, with_shs, on_backward, *params):
         lib = _lib()
         p = [x.contiguous() for x in params]
         dev = p[0].device
@@ -76,12 +76,15 @@ class _EvaluateAttributes(torch.autograd.Function):
             raise RuntimeError(lib.ex4d_attributes_last_error().decode())
         ctx.scal = scal
         ctx.with_shs = with_shs
+        ctx.on_backward = on_backward
         ctx.save_for_backward(*p)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_means3D, g_rotations, g_opacities, g_scales, g_shs):
         lib = _lib()
+        if ctx.on_backward is not None:
+            ctx.on_backward()                      # the owner's cache of these outputs is stale from here on (graph consumed)
         p = ctx.saved_tensors
         scal = ctx.scal
         dev = p[0].device
@@ -101,15 +104,15 @@ class _EvaluateAttributes(torch.autograd.Function):
                 *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc:
             raise RuntimeError(lib.ex4d_attributes_last_error().decode())
-        return (None, None) + tuple(gout)
+        return (None, None, None) + tuple(gout)
 
 
-def evaluate_attributes(params, t, duration=300, interval=10, time_shift=12, var_pad=3, with_shs=True):
+def evaluate_attributes(params, t, duration=300, interval=10, time_shift=12, var_pad=3, with_shs=True, on_backward=None):
     """params: mapping with the 15 CGaussianModel parameter tensors (PARAM_ORDER).  Returns the five boundary tensors; with
     with_shs=False the [N,16,3] SH block is not gathered (fifth value empty): hand the rasterizer a SplitSH of the four feature
-    tensors instead."""
+    tensors instead.  `on_backward` (optional callable) runs when a backward pass consumes the graph of this evaluation."""
     p = [params[n] for n in PARAM_ORDER]
     Ns, Nd = p[0].shape[0], p[7].shape[0]
     K = p[7].shape[1] if Nd > 0 else 0
     scal = time_scalars(t, Ns, Nd, K, duration, interval, time_shift, var_pad)
-    return _EvaluateAttributes.apply(scal, bool(with_shs), *p)
+    return _EvaluateAttributes.apply(scal, bool(with_shs), on_backward, *p)

@@ -4,12 +4,14 @@
 // (submodules/diff_gaussian_rasterization_df/cuda_rasterizer/rasterizer_impl.cu:204-363, :367-486, :143-159)
 // and the GeometryState / BinningState / ImageState::fromChunk carving (:161-200).
 #include "ex4d_internal.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 
 namespace {
 
+std::atomic<bool> g_prof_on{false};
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...)
@@ -36,42 +38,55 @@ int fail(int code, const char *fmt, ...)
 #define MARK(which, name) g_prof.mark(which, name, stream)
 
 // Optional per-stage timing with hipEvents on the caller's stream (used by bench.py for the roofline line;
-// off by default, single host thread).
+// off by default).  HIP events belong to the device that was current when they were created: the events are
+// (re)created whenever the calling thread's current device differs from the one they were made on, and the profiler
+// state is per host thread.
 struct StageProfiler {
     static const int kMax = 16;
-    bool on = false;
     hipEvent_t ev[2][kMax + 1];
     const char *names[2][kMax];
     int n[2] = { 0, 0 };
     bool created = false;
+    int device = -1;
     void begin(int which, hipStream_t s)
     {
-        if (!on) return;
-        if (!created) { for (int w = 0; w < 2; w++) for (int i = 0; i <= kMax; i++) (void)hipEventCreate(&ev[w][i]); created = true; }
+        if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (created && dev != device) {
+            for (int w = 0; w < 2; w++) for (int i = 0; i <= kMax; i++) (void)hipEventDestroy(ev[w][i]);
+            created = false; n[0] = n[1] = 0;
+        }
+        if (!created) { for (int w = 0; w < 2; w++) for (int i = 0; i <= kMax; i++) (void)hipEventCreate(&ev[w][i]); created = true; device = dev; }
         n[which] = 0;
         (void)hipEventRecord(ev[which][0], s);
     }
     void mark(int which, const char *name, hipStream_t s)
     {
-        if (!on || n[which] >= kMax) return;
+        if (!g_prof_on.load(std::memory_order_relaxed) || !created || n[which] >= kMax) return;
         names[which][n[which]] = name;
         n[which]++;
         (void)hipEventRecord(ev[which][n[which]], s);
     }
 };
-StageProfiler g_prof;
+thread_local StageProfiler g_prof;
 
-// pinned host word + event for the instance-count read-back (one per host thread, created on first use)
+// pinned host word + event for the instance-count read-back (one per host thread, created on first use; the event is
+// re-created when the thread's current device changes -- events are device-bound)
 struct Readback {
     uint32_t *host = nullptr;
     size_t words = 0;
     hipEvent_t ev;
     bool have_ev = false;
+    int device = -1;
     bool init(size_t need_words)
     {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (have_ev && dev != device) { (void)hipEventDestroy(ev); have_ev = false; }
         if (!have_ev) {
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-            have_ev = true;
+            have_ev = true; device = dev;
         }
         if (need_words > words) {
             if (host) (void)hipHostFree(host);
@@ -402,7 +417,7 @@ int ex4d_backward_split_sh(
                          dL_dmeans3D, dL_dcov3D, nullptr, dL_dscales, dL_drotations, dL_ddir, bwd_scratch, stream_);
 }
 
-void ex4d_profile_enable(int on) { g_prof.on = on != 0; }
+void ex4d_profile_enable(int on) { g_prof_on.store(on != 0); }
 
 int ex4d_profile_read(int which, float *ms, const char **names, int max_stages)
 {

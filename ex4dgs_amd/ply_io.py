@@ -24,11 +24,11 @@ def static_attributes(sh_rest=15, disp=3):
     return l
 
 
-def dynamic_attributes(K, sh_rest=15, xyz_width=3):
+def dynamic_attributes(K, sh_rest=15, xyz_width=3, opacity_c=2, opacity_v=2):
     l = [f"motion_xyz_{i}_{j}" for i in range(K) for j in range(xyz_width)]
     l += [f"motion_f_dc_{i}" for i in range(3)] + [f"motion_f_rest_{i}" for i in range(3 * sh_rest)]
     l += [f"motion_scale_{i}" for i in range(3)] + ["motion_opacity"]
-    l += [f"motion_opacity_c_{i}" for i in range(2)] + [f"motion_opacity_v_{i}" for i in range(2)]
+    l += [f"motion_opacity_c_{i}" for i in range(opacity_c)] + [f"motion_opacity_v_{i}" for i in range(opacity_v)]     # :503-506
     l += [f"motion_rot_{i}_{j}" for i in range(K) for j in range(4)]
     return l
 
@@ -66,7 +66,10 @@ def _read(path):
             elif tok[0] == "element":
                 if seen_element:                  # only the first element is used (plydata.elements[0]); its data follows the header
                     while tok[0] != "end_header":
-                        tok = f.readline().decode("ascii").split() or [""]
+                        line = f.readline()
+                        if not line:
+                            raise ValueError(f"{path}: truncated PLY header")
+                        tok = line.decode("ascii").split() or [""]
                     break
                 seen_element, count = True, int(tok[2])
             elif tok[0] == "property":
@@ -107,7 +110,8 @@ def save_ply(model, path):
                          g("_opacity_motion"), g("_opacity_duration_center").flatten(start_dim=1),
                          g("_opacity_duration_var").flatten(start_dim=1), g("_rotation_motion").flatten(start_dim=1)], dim=1).cpu().numpy()
     _write(path.replace("point_cloud.ply", "dynamic_point_cloud.ply"),
-           dynamic_attributes(xm.shape[1], g("_features_rest_motion").shape[1], xm.shape[2]), dynamic)
+           dynamic_attributes(xm.shape[1], g("_features_rest_motion").shape[1], xm.shape[2],
+                              g("_opacity_duration_center").shape[1], g("_opacity_duration_var").shape[1]), dynamic)
 
 
 def load_ply(path, device="cuda", max_sh_degree=3):

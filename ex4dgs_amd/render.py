@@ -33,8 +33,15 @@ def _zero_offsets(H, W, device):
 def render(viewpoint_camera, pc, pipe, bg_color, timestamp=None, scaling_modifier=1.0, override_color=None,
            subpixel_offset=None, mode=0, training=False, near=0.2, far=100.0, sync=True):
     pipe = DEFAULT_PIPE if pipe is None else pipe
+    if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
+        # gaussian_renderer/__init__.py:76-78, :87-93: the reference's Python-side covariance / SH evaluation bypasses the kernels
+        # this package exists for; refusing is better than silently rendering through the native path instead
+        raise NotImplementedError("pipe.compute_cov3D_python / pipe.convert_SHs_python are not supported: covariance and SH colour "
+                                  "are evaluated by the HIP preprocess kernel")
+    if mode not in (0, 1, 2):
+        raise ValueError(f"mode must be 0 (all Gaussians), 1 (static only) or 2 (dynamic only), got {mode}")
     timestamp = timestamp if timestamp is not None else viewpoint_camera.timestamp
-    means3D = pc.get_xyz_at_t(timestamp)
+    means3D = pc.get_xyz_at_t(timestamp, mode=mode, training=training)
     device = means3D.device
 
     # gradient traps: the 2D-mean gradient lands in screenspace_points.grad, the per-Gaussian "flow"/error channel gradient
@@ -57,10 +64,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, timestamp=None, scaling_modifie
         min_depth=near, max_depth=far, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=settings)
 
-    opacity = pc.get_opacity_at_t(timestamp)
-    scales = pc.get_scaling()
-    rotations = pc.get_rotation_at_t(timestamp)
-    shs, colors_precomp = (pc.get_features(), None) if override_color is None else (None, override_color)
+    opacity = pc.get_opacity_at_t(timestamp, mode=mode, training=training)
+    scales = pc.get_scaling(mode=mode)
+    rotations = pc.get_rotation_at_t(timestamp, mode=mode)
+    shs, colors_precomp = (pc.get_features(mode=mode), None) if override_color is None else (None, override_color)
 
     rendered_image, radii, rendered_depth, out_flow, acc, idxs = rasterizer(
         means3D=means3D, means2D=screenspace_points, dir3D=flow, shs=shs, colors_precomp=colors_precomp,

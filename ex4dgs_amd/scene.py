@@ -92,29 +92,31 @@ def _cube_interp(y0, y1, y2, y3, d):
     return h00 * y1 + h10 * m_k + h01 * y2 + h11 * m_k1
 
 
-def _quat_slerp(v1, v2, t):
-    """utils/interpolations.py:33-52."""
-    v1 = v1 / torch.norm(v1, dim=-1, keepdim=True)
-    v2 = v2 / torch.norm(v2, dim=-1, keepdim=True)
-    d = (v1 * v2).sum(-1, keepdim=True).clamp(-1 + 1e-4, 1 - 1e-4)
-    omega = torch.acos(d).clamp_min(1e-4)
-    s_omega = torch.sin(omega).clamp_min(1e-4)
-    p_0 = torch.sin((1 - t) * omega) / s_omega
-    p_1 = torch.sin(t * omega) / s_omega
-    p_sum = (p_0 + p_1).clamp_min(1e-4)
-    p_0 = p_0 / p_sum
-    p_1 = p_1 / p_sum
-    ret = v1 * p_0 + v2 * p_1
-    ret = torch.where(ret.abs().sum(-1, keepdim=True) > 1e-4, ret, v1)
-    return ret / ret.norm(dim=-1, keepdim=True)
+def _quat_slerp(qa, qb, frac):
+    """Normalised spherical interpolation of two keyframe quaternions with the reference's guards
+    (utils/interpolations.py:33-52): cos(angle) clamped to +-(1 - 1e-4), angle / sin / weight-sum floored at 1e-4,
+    fall-back to the first keyframe when the blend vanishes.  Weights are the two sine ratios, renormalised to sum 1."""
+    floor = 1e-4
+    qa = qa / qa.norm(dim=-1, keepdim=True)
+    qb = qb / qb.norm(dim=-1, keepdim=True)
+    angle = torch.acos((qa * qb).sum(-1, keepdim=True).clamp(floor - 1, 1 - floor)).clamp_min(floor)
+    inv_sin = torch.sin(angle).clamp_min(floor)
+    wa, wb = torch.sin((1 - frac) * angle) / inv_sin, torch.sin(frac * angle) / inv_sin
+    total = (wa + wb).clamp_min(floor)
+    blend = qa * (wa / total) + qb * (wb / total)
+    blend = torch.where(blend.abs().sum(-1, keepdim=True) > floor, blend, qa)
+    return blend / blend.norm(dim=-1, keepdim=True)
 
 
-def _time_bigaussian(mean, var, t, var_min):
-    """utils/interpolations.py:55-61."""
-    m = (t - mean).min(dim=1)[0]
-    v = torch.where((t > mean).any(dim=1), var[:, 1], var[:, 0])
-    o = torch.exp(-1 * (m.pow(2) / (v.exp() + var_min / 2.36).pow(2)))
-    return torch.where((mean[:, 0] - t) * (mean[:, 1] - t) < 0, torch.ones_like(o), o)
+def _time_bigaussian(centers, log_widths, tau, var_min):
+    """Temporal opacity window (utils/interpolations.py:55-61): 1 between the two centres, a Gaussian fall-off outside with the
+    left / right width exp(log_width) + var_min / 2.36; distance measured to the nearer... (min of the two signed offsets)."""
+    offset = (tau - centers).min(dim=1)[0]
+    past_any = (tau > centers).any(dim=1)
+    width = torch.where(past_any, log_widths[:, 1], log_widths[:, 0]).exp() + var_min / 2.36
+    falloff = torch.exp(-1 * (offset.pow(2) / width.pow(2)))
+    between = (centers[:, 0] - tau) * (centers[:, 1] - tau) < 0
+    return torch.where(between, torch.ones_like(falloff), falloff)
 
 
 class DynamicGaussians:
@@ -182,65 +184,90 @@ class DynamicGaussians:
         key = (t, torch.is_grad_enabled()) + tuple((p.data_ptr(), p._version, p.requires_grad) for p in self.parameters())
         self._last_t = t
         if key != self._fused_key:
+            # the cached outputs carry an autograd graph whose saved tensors are freed by the first backward through it: that
+            # backward drops the cache (on_backward), so a later render at the same timestamp re-evaluates instead of failing with
+            # "backward through the graph a second time" (several cameras per timestamp, gradient accumulation)
             self._fused_out = evaluate_attributes({n: getattr(self, n) for n in self.PARAM_NAMES}, t, duration=self.duration,
                                                   interval=self.interval, time_shift=self.time_shift, var_pad=self.var_pad,
-                                                  with_shs=not self.split_sh)
+                                                  with_shs=not self.split_sh, on_backward=self._drop_fused_cache)
             self._fused_key = key
         return self._fused_out
 
-    def get_xyz_at_t(self, t):
+    def _drop_fused_cache(self):
+        self._fused_key = None
+        self._fused_out = None
+
+    def _rows(self, x, mode):
+        """mode 0 = all rows, 1 = static rows only, 2 = dynamic rows only (the `mode` argument of the reference's getters,
+        scene/c_gaussian_model.py:170-176; static rows come first)."""
+        if mode == 0:
+            return x
+        if mode not in (1, 2):
+            raise ValueError(f"mode must be 0 (all), 1 (static) or 2 (dynamic), got {mode}")
+        return x[: self.num_static] if mode == 1 else x[self.num_static:]
+
+    def get_xyz_at_t(self, t, mode=0, training=True):
         if self.fused:
-            return self.evaluate_at_t(t)[0]
+            return self._rows(self.evaluate_at_t(t)[0], mode)
         static = self._xyz + self._xyz_disp * t / self.duration               # :180
-        if self.num_dynamic == 0:
+        if self.num_dynamic == 0 or mode == 1:
             return static
         k, d = self._tk(t)
         y = self._xyz_motion
         dyn = _cube_interp(y[:, k - 1, :3], y[:, k, :3], y[:, k + 1, :3], y[:, k + 2, :3], d)   # :118
-        return torch.cat([static, dyn], dim=0).contiguous()
+        return dyn if mode == 2 else torch.cat([static, dyn], dim=0).contiguous()
 
-    def get_rotation_at_t(self, t):
+    def get_rotation_at_t(self, t, mode=0):
         if self.fused:
-            return self.evaluate_at_t(t)[1]
-        if self.num_dynamic == 0:
+            return self._rows(self.evaluate_at_t(t)[1], mode)
+        if self.num_dynamic == 0 or mode == 1:
             return self._rotation                                             # :198 (raw, un-normalised)
         k, d = self._tk(t)
         y = self._rotation_motion
-        return torch.cat([self._rotation, _quat_slerp(y[:, k, :], y[:, k + 1, :], d)], dim=0).contiguous()
+        dyn = _quat_slerp(y[:, k, :], y[:, k + 1, :], d)
+        return dyn if mode == 2 else torch.cat([self._rotation, dyn], dim=0).contiguous()
 
-    def get_opacity_at_t(self, t):
+    def get_opacity_at_t(self, t, mode=0, training=False):
         if self.fused:
-            return self.evaluate_at_t(t)[2]
+            return self._rows(self.evaluate_at_t(t)[2], mode)
         static = torch.sigmoid(self._opacity)
-        if self.num_dynamic == 0:
+        if self.num_dynamic == 0 or mode == 1:
             return static
         tau = (t + self.time_shift) / self.interval                           # :364
         o = _time_bigaussian(self._opacity_duration_center, self._opacity_duration_var, tau,
                              var_min=self.var_pad / self.interval) * torch.sigmoid(self._opacity_motion)
-        return torch.cat([static, o], dim=0).contiguous()
+        return o if mode == 2 else torch.cat([static, o], dim=0).contiguous()
 
     def _fused_time_independent(self, index):
         # scales / features do not depend on t: reuse the evaluation of the timestamp the other getters asked for
         return self.evaluate_at_t(getattr(self, "_last_t", 0))[index]
 
-    def get_scaling(self):
+    def get_scaling(self, mode=0):
         if self.fused:
-            return self._fused_time_independent(3)
-        if self.num_dynamic == 0:
+            return self._rows(self._fused_time_independent(3), mode)
+        if self.num_dynamic == 0 or mode == 1:
             return torch.exp(self._scaling)
+        if mode == 2:
+            return torch.exp(self._scaling_motion)
         return torch.exp(torch.cat([self._scaling, self._scaling_motion], dim=0))   # :335
 
-    def get_features(self):
+    def get_features(self, mode=0):
         if self.fused and self.split_sh:
             # zero-copy: the rasterizer reads the four tensors where they are (diff_gaussian_rasterization_df.SplitSH)
             from ._C import SplitSH
-            return SplitSH(self._features_dc, self._features_rest, self._features_dc_motion, self._features_rest_motion)
+            parts = [self._features_dc, self._features_rest, self._features_dc_motion, self._features_rest_motion]
+            if mode == 1:
+                parts[2:] = [parts[2][:0], parts[3][:0]]          # static rows only: an empty dynamic half
+            elif mode == 2:
+                parts[:2] = [parts[0][:0], parts[1][:0]]
+            return SplitSH(*parts)
         if self.fused:
-            return self._fused_time_independent(4)
+            return self._rows(self._fused_time_independent(4), mode)
         s = torch.cat((self._features_dc, self._features_rest), dim=1)
-        if self.num_dynamic == 0:
+        if self.num_dynamic == 0 or mode == 1:
             return s
-        return torch.cat((s, torch.cat((self._features_dc_motion, self._features_rest_motion), dim=1)), dim=0).contiguous()
+        d = torch.cat((self._features_dc_motion, self._features_rest_motion), dim=1)
+        return d if mode == 2 else torch.cat((s, d), dim=0).contiguous()
 
 
 # ----------------------------------------------------------------------------------------------
