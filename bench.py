@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -208,6 +209,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     _C.load()
+    if args.bwd_variant is not None:
+        _C.set_option("composite_bwd_variant", args.bwd_variant)
 
     cfg = CONFIGS[args.config]
     model, cam, bg = make_scene(args.config, P=args.points)

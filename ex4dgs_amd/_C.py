@@ -83,7 +83,7 @@ EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forw
            "ex4d_forward_split_sh", "ex4d_backward_split_sh",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
            "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset",
-           "ex4d_profile_enable", "ex4d_profile_read")
+           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option")
 
 
 def library_path():
@@ -117,6 +117,8 @@ def load():
     lib.ex4d_backward_split_sh.argtypes = ([C.POINTER(Ex4dParams), C.c_int32] + [C.c_void_p] * 3 + [C.POINTER(Ex4dSplitSH)] + [C.c_void_p] * 21
                                            + [C.POINTER(Ex4dSplitSH)] + [C.c_void_p] * 5)
     lib.ex4d_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ex4d_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.ex4d_get_option.argtypes = [C.c_char_p]
     _lib = lib
     return lib
 
@@ -373,6 +375,15 @@ def img_views(imgBuffer, W, H):
     return dict(final_T=i[lay.final_T: lay.final_T + 4 * W * H].view(torch.float32).view(H, W),
                 n_contrib=i[lay.n_contrib: lay.n_contrib + 4 * W * H].view(torch.int32).view(H, W),
                 ranges=i[lay.ranges: lay.ranges + 8 * T].view(torch.int32).view(T, 2))
+
+
+def set_option(name, value):
+    """Tuning knobs of include/ex4d_rasterizer.h (e.g. "composite_bwd_variant")."""
+    _check(load().ex4d_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    return int(load().ex4d_get_option(name.encode()))
 
 
 def profile_enable(on=True):

@@ -8,10 +8,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
 std::atomic<bool> g_prof_on{false};
+// tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
+static inline int acc_layout_of(int variant) { return variant == 2 ? 1 : 0; }
+std::atomic<int> g_bwd_variant{4};
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...)
@@ -39,8 +43,8 @@ int fail(int code, const char *fmt, ...)
 
 // Optional per-stage timing with hipEvents on the caller's stream (used by bench.py for the roofline line;
 // off by default).  HIP events belong to the device that was current when they were created: the events are
-// (re)created whenever the calling thread's current device differs from the one they were made on, and the profiler
-// state is per host thread.
+// (re)created whenever the calling thread's current device differs from the one they were made on.  One profiler per process
+// (forward and backward of one frame run on different host threads under torch autograd), serialised by a mutex.
 struct StageProfiler {
     static const int kMax = 16;
     hipEvent_t ev[2][kMax + 1];
@@ -48,9 +52,11 @@ struct StageProfiler {
     int n[2] = { 0, 0 };
     bool created = false;
     int device = -1;
+    std::mutex mu;
     void begin(int which, hipStream_t s)
     {
         if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        std::lock_guard<std::mutex> lock(mu);
         int dev = -1;
         (void)hipGetDevice(&dev);
         if (created && dev != device) {
@@ -63,13 +69,15 @@ struct StageProfiler {
     }
     void mark(int which, const char *name, hipStream_t s)
     {
-        if (!g_prof_on.load(std::memory_order_relaxed) || !created || n[which] >= kMax) return;
+        if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!created || n[which] >= kMax) return;
         names[which][n[which]] = name;
         n[which]++;
         (void)hipEventRecord(ev[which][n[which]], s);
     }
 };
-thread_local StageProfiler g_prof;
+StageProfiler g_prof;
 
 // pinned host word + event for the instance-count read-back (one per host thread, created on first use; the event is
 // re-created when the thread's current device changes -- events are device-bound)
@@ -136,8 +144,9 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     return g;
 }
 
-BinState carve_binning(void *buf, uint32_t R, Ex4dBinningLayout *lay, size_t *total)
+BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *lay, size_t *total)
 {
+    const int T = ((W + EX4D_TILE - 1) / EX4D_TILE) * ((H + EX4D_TILE - 1) / EX4D_TILE);
     Carver c(buf);
     BinState b;
     Ex4dBinningLayout l;
@@ -147,6 +156,7 @@ BinState carve_binning(void *buf, uint32_t R, Ex4dBinningLayout *lay, size_t *to
     b.vals_tmp = c.take<uint32_t>(n);
     b.keys_tmp = c.take<uint32_t>(n);
     b.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words(R));
+    b.cull_masks = c.take<unsigned long long>(ex4d_cull_mask_words(R, T));
     l.total = c.off;
     if (lay) *lay = l;
     if (total) *total = c.off;
@@ -187,10 +197,10 @@ int ex4d_abi_version(void) { return 1; }
 const char *ex4d_target_arch(void) { return "gfx950"; }
 
 size_t ex4d_geom_bytes(int32_t P) { size_t t; carve_geom(nullptr, P, nullptr, &t); return t; }
-size_t ex4d_binning_bytes(int32_t R, int32_t W, int32_t H) { (void)W; (void)H; size_t t; carve_binning(nullptr, (uint32_t)R, nullptr, &t); return t; }
+size_t ex4d_binning_bytes(int32_t R, int32_t W, int32_t H) { size_t t; carve_binning(nullptr, (uint32_t)R, W, H, nullptr, &t); return t; }
 size_t ex4d_img_bytes(int32_t W, int32_t H) { size_t t; carve_img(nullptr, W, H, nullptr, &t); return t; }
 void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out) { carve_geom(nullptr, P, out, nullptr); }
-void ex4d_binning_layout(int32_t R, int32_t W, int32_t H, Ex4dBinningLayout *out) { (void)W; (void)H; carve_binning(nullptr, (uint32_t)R, out, nullptr); }
+void ex4d_binning_layout(int32_t R, int32_t W, int32_t H, Ex4dBinningLayout *out) { carve_binning(nullptr, (uint32_t)R, W, H, out, nullptr); }
 void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out) { carve_img(nullptr, W, H, out, nullptr); }
 size_t ex4d_backward_scratch_bytes(int32_t P) { return ex4d_align_up((size_t)P * 16 * sizeof(float)); }
 size_t ex4d_backward_scratch_acc_offset(int32_t P) { (void)P; return 0; }
@@ -267,7 +277,7 @@ static int forward_impl(
 
     void *bin_buf = binning_alloc(binning_user, ex4d_binning_bytes((int32_t)R, W, H));
     if (!bin_buf) return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed");
-    BinState b = carve_binning(bin_buf, R, nullptr, nullptr);
+    BinState b = carve_binning(bin_buf, R, W, H, nullptr, nullptr);
 
     // 5. emit (tile, id) instances in depth order, 6. stable sort by tile, 7. ranges
     const int passes = (tile_bits(T) + 7) / 8;
@@ -286,7 +296,7 @@ static int forward_impl(
     MARK(0, "tile_ranges");
     // 8. compositing
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
-                                    out_color, out_depth, out_acc, out_flow, out_idx, stream), prm, stream);
+                                    out_color, out_depth, out_acc, out_flow, out_idx, b.cull_masks, stream), prm, stream);
     MARK(0, "composite_fwd");
     return EX4D_OK;
 }
@@ -312,10 +322,11 @@ static int backward_impl(
     if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
         return fail(EX4D_ERR_ARG, "null gradient output");
     GeomState g = carve_geom((void *)geom_buffer, P, nullptr, nullptr);
-    BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, nullptr, nullptr);
+    BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, W, H, nullptr, nullptr);
     ImgState im = carve_img((void *)img_buffer, W, H, nullptr, nullptr);
     float *acc16 = (float *)bwd_scratch;
 
+    const int variant = g_bwd_variant.load(std::memory_order_relaxed);
     g_prof.begin(1, stream);
     HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
     MARK(1, "zero_accumulators");
@@ -323,10 +334,10 @@ static int backward_impl(
     if (num_rendered > 0)
         STAGE(ex4d_launch_composite_bwd(*prm, im.ranges, b.point_list, subpixel_offset, background, g.records,
                                         out_depth, out_acc, im.final_T, im.n_contrib,
-                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, stream), prm, stream);
+                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, b.cull_masks, variant, stream), prm, stream);
     MARK(1, "composite_bwd");
     const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;            // rasterizer_impl.cu:460
-    STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16,
+    STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16, acc_layout_of(variant),
                                      dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir,
                                      split, gsplit, stream), prm, stream);
     MARK(1, "preprocess_bwd");
@@ -417,10 +428,26 @@ int ex4d_backward_split_sh(
                          dL_dmeans3D, dL_dcov3D, nullptr, dL_dscales, dL_drotations, dL_ddir, bwd_scratch, stream_);
 }
 
+int ex4d_set_option(const char *name, int value)
+{
+    if (name && !strcmp(name, "composite_bwd_variant") && (value == 0 || value == 2 || value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
+    return fail(EX4D_ERR_ARG, "unknown option or value out of range");
+}
+
+int ex4d_debug_bwd_stats(unsigned long long *out8, int reset) { return ex4d_bwd_stats(out8, reset) == hipSuccess ? EX4D_OK : EX4D_ERR_HIP; }
+
+int ex4d_get_option(const char *name)
+{
+    if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
+    if (name && !strcmp(name, "acc_layout")) return acc_layout_of(g_bwd_variant.load());
+    return -1;
+}
+
 void ex4d_profile_enable(int on) { g_prof_on.store(on != 0); }
 
 int ex4d_profile_read(int which, float *ms, const char **names, int max_stages)
 {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     if (which < 0 || which > 1 || !g_prof.created) return 0;
     const int n = g_prof.n[which] < max_stages ? g_prof.n[which] : max_stages;
     if (n == 0) return 0;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx)
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks)
 {
     __shared__ float4 s_q0[WPB][64];      // x, y, A, B
     __shared__ float2 s_q1[WPB][64];      // C, w
@@ -185,6 +185,8 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
         }
         const uint64_t mask = __ballot(keep);
         const int cnt = __popcll(mask);
+        // the survivors of this chunk, for the backward pass (ex4d_internal.h: BinState::cull_masks)
+        if (lane == 0) cull_masks[4 * ((size_t)((range.x + (uint32_t)base) >> 6) + (size_t)tile) + quad] = mask;
         if (keep) {
             const int slot = __popcll(mask & lt);
             const float4 *r = records + 4 * (size_t)id;
@@ -438,29 +440,374 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Compositing backward, scan version (default) -- lanes = (Gaussian, pixel slot).
+//
+// The per-pixel version above spends a third of its VALU instructions forming the 13 per-Gaussian partials and summing them over
+// the 64 pixels of the wave (13 LDS stores + 4 x 16-byte reads + 17 adds + the atomic, per Gaussian).  Here the lanes are
+// re-assigned so that those sums accumulate over TIME in registers instead of across lanes: lane (n, g) = (entry n of a batch of
+// 16 list entries, pixel slot g); step s of a batch handles pixels 4s+g (g = 0..3) of the 8x8 quadrant for all 16 Gaussians at
+// once, so after 16 steps every lane holds the partial sums of ITS Gaussian over ITS 16 pixels; the four pixel-slot lanes of a
+// Gaussian are added once per batch.  The per-pixel recurrences of CR/backward.cu:571-680 run ACROSS the 16 Gaussian lanes of a
+// DPP row as prefix scans with a per-pixel carry (in LDS) from batch to batch (list order descending = back to front):
+//     T_i    = T_carry prod_{j<=i} 1/(1 - alpha_j)                                   (T = T / (1 - alpha))
+//     E_i    = E_carry + sum_{j<i} alpha_j T_j (c_j . dL_dpixel)                     (accum_rec in closed form:
+//              (c_i - accum_rec_i) . dL_dpixel T_i = (c_i . dL_dpixel) T_i - E_i / (1 - alpha_i))
+//     gacc_i = gacc_carry prod_{j<=i, contributing} T_j                              (dL_dacc *= T)
+// List compaction comes for free: the forward kernel leaves the survivors of its quadrant cull as one 64-bit mask per
+// (64-entry chunk, quadrant) and this kernel gathers the records of the survivors only.
+//
+// Measured on MI355X, 1.0 M Gaussians / 7.5 M instances (profiles/r02_*): per-pixel kernel 0.458 ms, 2.32e8 VALU instructions;
+// this kernel 0.35 ms, 1.79e8 (86 % VALU-busy; 55 % of the lanes of a step hold a contributing pair, 96 % of the staged
+// Gaussians contribute somewhere in their quadrant).
+//
+// MODE 0 keeps the first formulation of the sums, as contractions over the pixels on the matrix cores:
+//     [gdepth gp0 gp1 gp2 gflow0 gflow1 gflow2] . (alpha T)       [1 x y xx xy yy] . (w G dL_dalpha)       [1] . G (dL_dalpha + dL_dacc)
+// (x, y relative to the quadrant origin; Gaussian-centred moments follow from dx = dx0 - x): lane (n, g) IS the B-operand layout of
+// v_mfma_f32_16x16x4_f32 (B[k = lane>>4][n = lane&15]), the A rows are per-pixel constants held in 32 registers, three MFMAs per
+// step, results land in the lane of their Gaussian.  Correct (same parity bounds) but SLOWER than 15 VALU FMAs per step: 0.40 ms.
+// The f32-input MFMA runs at the f32 VECTOR rate and does not overlap the VALU stream here (48 v_fma + 3 MFMA issue in 224 cycles
+// against 149 for the 48 v_fma alone, tools/dev/micro/mfma_dpp_probe.hip), and only 14 of its 3 x 16 result rows are used.
+// Accumulator row layouts (per-Gaussian backward kernel, ex4d_preprocess.hip): MODE 2 writes layout 0 like the per-pixel kernel;
+// MODE 0 writes layout 1:  0 sum sG dx   1 sum sG dy   2 dL_dmean2D.z   3..5 sum sG (dx^2, dx dy, dy^2)   6 dL_dopacity   7..9 dL_dcolor
+//     10..12 dL_ddir     (sG = dL_dG G; the mean2D.xy / conic gradients are linear in these with the conic as coefficients)
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define DPP_ROW_SHR(n) (0x110 + (n))
+
+// lanes whose DPP source lies outside their 16-lane row keep `old`
+template <int CTRL> __device__ __forceinline__ float dpp_or(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Inclusive prefix product / sum over the 16 lanes of a DPP row (Hillis-Steele, shifts 1 2 4 8).  Product: one instruction
+// per step -- v_mul_f32_dpp leaves lanes without a source untouched (the compiler would emit v_mov_dpp + v_mul); a DPP read of a
+// VGPR written by the previous VALU instruction needs two wait states, which nobody inserts inside an asm statement but us.
+__device__ __forceinline__ float row_scan_mul(float x)
+{
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    return x;
+}
+#define RING 128                 // list entries staged per wave (<= 15 left over + 64 new)
+#define DUMP_FLOATS 320          // per-wave scratch: junk target of the non-carry lanes (64 lanes + 15 steps x 16 floats), epilogue staging
+
+// developer statistics of the scan kernel (variant 8 only): [0] batches, [1] valid Gaussians, [2] steps run, [3] steps skipped,
+// [4] contributing (pixel, Gaussian) pairs, [5] Gaussians with at least one contributing pair in their batch
+__device__ unsigned long long g_bwd_stats[8];
+
+struct BwdLds {
+    float4 ring[3][RING];        // [0] x y a' b'   [1] c' w depth id   [2] r g b list-position     (also: transposition scratch at setup)
+    float4 pa[64];               // per pixel: gp0 gp1 gp2 gdepth
+    float4 pb[64];               //            final_depth  bgT  last_contributor  T carry
+    float4 pc[64];               //            fx  fy  E carry  gacc carry
+    float4 pd[64];               //            gflow0 gflow1 gflow2 -                 (register-accumulation modes only)
+    float dump[DUMP_FLOATS];
+};
+
+__device__ __forceinline__ float row_scan_add_asm(float x)
+{
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    return x;
+}
+
+// MODE: how the 13 sums over the pixels are formed
+//   0  three f32 MFMAs per step (dcc, sG, s6 against per-pixel constant rows held in registers)
+//   2  every lane accumulates the 13 Gaussian-centred partial sums of its 16 pixels in registers (15 VALU per step), the four
+//      pixel-slot lanes of a Gaussian are added in the epilogue                                            (default)
+//   4  = 2 plus the developer statistics of g_bwd_stats
+template <int MODE>
+__device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
+                                          const float (&A1)[16], const float (&A2)[16], float *__restrict__ acc16)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int slot = (head + n) & (RING - 1);
+    const float4 g0 = L.ring[0][slot], g1 = L.ring[1][slot], g2 = L.ring[2][slot];
+    const bool valid = n < nvalid;
+    const float ap = g0.z, bp = g0.w, cp = g1.x, w = g1.y, dep = g1.z;
+    // invalid lanes never pass `orig < last_contributor` (select spelled out: otherwise the compiler turns the compare below into
+    // `valid && ...` and pays a v_cndmask + v_cmp per step to re-materialise the lane mask)
+    const uint32_t orig = (uint32_t)select_i(LANES(valid), (int)__float_as_uint(g2.w), -1);
+    const float flagf = dep > min_depth ? 1.f : 0.f;       // CR/backward.cu:603
+    f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f}, D3 = {0.f, 0.f, 0.f, 0.f};
+    float v[13];
+#pragma unroll
+    for (int q = 0; q < 13; q++) v[q] = 0.f;
+    // carries of pixel 4s+g are written by lane n == 15 of row g; the other lanes write into the dump area (no exec masking)
+    float *wT = (n == 15) ? (&L.pb[g].w) : (&L.dump[lane]);
+    float *wE = (n == 15) ? (&L.pc[g].z) : (&L.dump[lane]);
+    float *wG = (n == 15) ? (&L.pc[g].w) : (&L.dump[lane]);
+    // the per-pixel constants / carries of step s + 1 are requested before step s runs (its LDS latency hides behind the step;
+    // the carries of pixels 4(s+1)+g are last written one batch earlier, so the early read sees the right values)
+    float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = L.pc[g], pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 2 || MODE == 4) pd_n = L.pd[g];
+    unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const float4 pa = pa_n, pb = pb_n, pc = pc_n, pd = pd_n;
+        if (s < 15) {
+            pa_n = L.pa[4 * s + 4 + g]; pb_n = L.pb[4 * s + 4 + g]; pc_n = L.pc[4 * s + 4 + g];
+            if (MODE == 2 || MODE == 4) pd_n = L.pd[4 * s + 4 + g];
+        }
+        const float dx = g0.x - pc.x, dy = g0.y - pc.y;        // the forward kernel's arithmetic: identical alpha, identical decisions
+        const float adx = ap * dx, cdy = cp * dy;
+        const float power2 = dx * (adx + bp * dy) + cdy * dy;
+        const float G = __builtin_amdgcn_exp2f(power2);
+        const float alpha = fminf(0.99f, w * G);
+        const lanemask ok = LANES(orig < __float_as_uint(pb.z)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
+        if (MODE == 4) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
+        if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
+        const float alpha_m = select_f(ok, alpha, 0.f);
+        const float G_m = select_f(ok, G, 0.f);
+        const float inv = __builtin_amdgcn_rcpf(1.f - alpha_m);
+        // T_i = T_carry * prod_{j <= i} inv_j   (the carry is row-uniform: every lane of the row read it from LDS)
+        const float T = pb.w * row_scan_mul(inv);
+        const float dcc = alpha_m * T;                                  // dchannel_dcolor
+        const float cgp = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z;      // c . dL_dpixel
+        const float e = dcc * cgp;
+        const float E = pc.z + row_scan_add_asm(e);
+        // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha)
+        const float gdf = pa.w * flagf;
+        const float u = ((pb.x - dep) * gdf) * T;
+        float dLa = u * T + (cgp * T - (E - e) * inv);
+        dLa += pb.y * inv;
+        float s6 = G_m * dLa;
+        const float sG = w * s6;                                        // dL_dG G = (w dL_dalpha) G
+        if (use_gacc) {             // wave-uniform
+            // dL_dacc *= T for every contributor (CR/backward.cu:650), then dL_dopacity += G (dL_dalpha + dL_dacc)
+            const float ga = pc.w * row_scan_mul(select_f(ok, T, 1.f));
+            s6 += G_m * ga;
+            wG[16 * s] = ga;
+        }
+        if (MODE == 0) {
+            D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s], dcc, D1, 0, 0, 0);
+            D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], sG, D2, 0, 0, 0);
+            D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], s6, D3, 0, 0, 0);
+        } else {
+            v[2] += dcc * gdf;
+            v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
+            v[10] += dcc * pd.x; v[11] += dcc * pd.y; v[12] += dcc * pd.z;
+            v[0] += sG * dx; v[1] += sG * dy;
+            const float sdx = sG * dx;
+            v[3] += sdx * dx; v[4] += sdx * dy; v[5] += (sG * dy) * dy;
+            v[6] += s6;
+        }
+        wT[16 * s] = T;
+        wE[16 * s] = E;
+    }
+    // The sums leave the wave like in the per-pixel kernel -- one atomic instruction covers whole 64-byte accumulator rows
+    // (13 neighbouring floats per Gaussian, 4 Gaussians per instruction) -- after a 1 KB transposition through LDS; 13 separate
+    // 16-lane atomics per batch would send 13x the requests to L2 (measured: 4.4x the kernel time).
+    if (MODE == 4 && lane == 0) {
+        const unsigned long long any16 = (st_any | (st_any >> 16) | (st_any >> 32) | (st_any >> 48)) & 0xffffull;
+        atomicAdd(&g_bwd_stats[0], 1ull); atomicAdd(&g_bwd_stats[1], (unsigned long long)nvalid); atomicAdd(&g_bwd_stats[2], st_run);
+        atomicAdd(&g_bwd_stats[3], st_skip); atomicAdd(&g_bwd_stats[4], st_pairs); atomicAdd(&g_bwd_stats[5], (unsigned long long)__popcll(any16));
+    }
+    wave_lds_sync();
+    float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
+    if (MODE == 2 || MODE == 4) {
+        // every lane holds partial sums over ITS 16 pixels: add the four pixel-slot lanes of a Gaussian (lanes n, n+16, n+32, n+48)
+#pragma unroll
+        for (int q = 0; q < 13; q++) {
+            v[q] += __shfl_xor(v[q], 16, 64);
+            v[q] += __shfl_xor(v[q], 32, 64);
+        }
+        if (g == 0) {
+            // accumulator layout 0 (what the per-pixel kernel writes): dL_dmean2D.xy as sums of sG (2 a' dx + b' dy), sG (2 c' dy + b' dx)
+            // with the pre-scaled conic -- linear in the moments, so the conic is applied once per Gaussian here
+            out[0] = (2.f * ap) * v[0] + bp * v[1];
+            out[1] = (2.f * cp) * v[1] + bp * v[0];
+#pragma unroll
+            for (int q = 2; q < 13; q++) out[q] = v[q];
+        }
+    } else {
+        // lane (n, g) holds rows 4g..4g+3 of column n: sums of ITS Gaussian; moments about the quadrant origin -> Gaussian-centred
+        const float dxb = g0.x - ox, dyb = g0.y - oy;
+        if (g == 0) {               // A1 rows: gdepth gp0 gp1 gp2      A2 rows: 1 x xx 0
+            out[2] = D1[0] * flagf;
+            out[7] = D1[1]; out[8] = D1[2]; out[9] = D1[3];
+            out[0] = dxb * D2[0] - D2[1];
+            out[3] = (dxb * dxb) * D2[0] - (2.f * dxb) * D2[1] + D2[2];
+        } else if (g == 1) {        // A1 rows: gflow0 gflow1 gflow2 0   A2 rows: 1 y yy 0
+            out[10] = D1[0]; out[11] = D1[1]; out[12] = D1[2];
+            out[1] = dyb * D2[0] - D2[1];
+            out[5] = (dyb * dyb) * D2[0] - (2.f * dyb) * D2[1] + D2[2];
+        } else if (g == 2) {        // A2 rows: 1 x y xy
+            out[4] = (dxb * dyb) * D2[0] - dyb * D2[1] - dxb * D2[2] + D2[3];
+        } else {                    // A2 rows: 1 0 0 0
+            out[6] = D3[0];
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int gn = 4 * r + g;                  // Gaussian of this lane in round r; accumulator slot = n
+        const float val = L.dump[17 * gn + n];
+        const uint32_t gid = __float_as_uint(L.ring[1][(head + gn) & (RING - 1)].w);
+        if (gn < nvalid && n < 13) unsafeAtomicAdd(acc16 + 16 * (size_t)gid + n, val);
+    }
+    wave_lds_sync();
+}
+
+template <int WPB, int MODE>
+__global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
+    int W, int H, int gx, int num_tiles,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+    const float *__restrict__ subpixel_offset, const float *__restrict__ bg,
+    const float4 *__restrict__ records,
+    const float *__restrict__ depth_acc, const float *__restrict__ weight_acc, float min_depth,
+    const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
+    const float *__restrict__ dL_dpixels, const float *__restrict__ dL_ddepths,
+    const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
+    float *__restrict__ acc16, const unsigned long long *__restrict__ cull_masks)
+{
+    __shared__ BwdLds lds[WPB];
+    int tile, quad;
+    tile_of_block<WPB>(num_tiles, tile, quad);
+    if (tile >= num_tiles) return;
+    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
+    BwdLds &L = lds[wave];
+    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);      // setup: lane = pixel (x = lane & 7, y = lane >> 3)
+    const uint2 range = ranges[tile];
+    const size_t HW = (size_t)H * W;
+    const uint32_t last_contributor = p.inside ? n_contrib[p.pix_id] : 0u;
+    const uint32_t deepest = wave_max_u32(last_contributor);     // nothing behind it touches this quadrant
+    if (deepest == 0) return;
+
+    // ---- per-pixel constants, CR/backward.cu:489-549
+    const float T_final = p.inside ? final_Ts[p.pix_id] : 0.f;
+    const float acc = p.inside ? weight_acc[p.pix_id] : 0.f;
+    const float final_depth = p.inside ? depth_acc[p.pix_id] : 0.f;
+    float gdepth = 0.f, gflow0 = 0.f, gflow1 = 0.f, gflow2 = 0.f, gacc = 0.f, gp0 = 0.f, gp1 = 0.f, gp2 = 0.f;
+    if (p.inside) {
+        if (dL_ddepths) gdepth = dL_ddepths[p.pix_id];
+        if (dL_dpixels) { gp0 = dL_dpixels[p.pix_id]; gp1 = dL_dpixels[HW + p.pix_id]; gp2 = dL_dpixels[2 * HW + p.pix_id]; }
+        if (acc > 0.0f) {
+            gdepth /= acc;
+            if (dL_dflows) { gflow0 = dL_dflows[p.pix_id] / acc; gflow1 = dL_dflows[HW + p.pix_id] / acc; gflow2 = dL_dflows[2 * HW + p.pix_id] / acc; }
+            if (dL_daccs) gacc = dL_daccs[p.pix_id];
+        }
+    }
+    const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
+    const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
+    const float xr = p.fx - ox, yr = p.fy - oy;
+    L.pa[lane] = make_float4(gp0, gp1, gp2, gdepth);
+    L.pb[lane] = make_float4(final_depth, bgT, __uint_as_float(last_contributor), T_final);
+    L.pc[lane] = make_float4(p.fx, p.fy, 0.f, gacc);
+    if (MODE == 2 || MODE == 4) L.pd[lane] = make_float4(gflow0, gflow1, gflow2, 0.f);
+    const bool use_gacc = LANES(gacc != 0.0f) != 0;              // wave-uniform: dL_dacc takes part in this quadrant at all
+
+    // ---- A operands: row i = lane & 15 of the per-pixel constant matrices, k = pixel 4s + g  ->  one register per step.
+    // Transposed through the (not yet used) ring area: lane = pixel writes its column, lane = (i, g) reads its row entries.
+    float A1[16], A2[16];
+    if (MODE == 0) {
+        float *pt2 = reinterpret_cast<float *>(&L.ring[0][0]);      // [64][16]
+        float *pt1 = reinterpret_cast<float *>(&L.ring[2][0]);      // [64][8]
+        float4 *w2 = reinterpret_cast<float4 *>(pt2 + 16 * lane);
+        w2[0] = make_float4(1.f, xr, xr * xr, 0.f);
+        w2[1] = make_float4(1.f, yr, yr * yr, 0.f);
+        w2[2] = make_float4(1.f, xr, yr, xr * yr);
+        w2[3] = make_float4(1.f, 0.f, 0.f, 0.f);
+        float4 *w1 = reinterpret_cast<float4 *>(pt1 + 8 * lane);
+        w1[0] = make_float4(gdepth, gp0, gp1, gp2);
+        w1[1] = make_float4(gflow0, gflow1, gflow2, 0.f);
+        wave_lds_sync();
+        const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            A2[s] = pt2[16 * (4 * s + g) + i];
+            A1[s] = pt1[8 * (4 * s + g) + (i & 7)];
+            A1[s] = i < 8 ? A1[s] : 0.f;
+        }
+        wave_lds_sync();
+    } else {
+        // no transposition scratch: the ring holds finite values from the start (stale entries are read by invalid lanes)
+        for (int i = lane; i < RING; i += 64) {
+            L.ring[0][i] = make_float4(0.f, 0.f, 0.f, 0.f); L.ring[1][i] = make_float4(0.f, 0.f, 0.f, 0.f); L.ring[2][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) { A1[s] = 0.f; A2[s] = 0.f; }
+        wave_lds_sync();
+    }
+
+    int head = 0, tail = 0;                                       // wave-uniform ring indices (monotonic; slot = index & (RING-1))
+    {
+        // The forward kernel walked this list in the same 64-entry chunks and left the survivors of its quadrant cull as one 64-bit
+        // mask per chunk: no gather / test of the ~70 % of entries that miss the quadrant.  Chunks from the deepest contributor
+        // back to the front; inside a chunk lane l takes list position 64 c + 63 - l, so survivors compact in descending order.
+        const int nchunks = ((int)deepest + 63) >> 6;
+        const size_t mbase = (size_t)__builtin_amdgcn_readfirstlane((int)(4u * (uint32_t)tile + (uint32_t)quad));
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
+        for (int c = nchunks - 1; c >= 0; c--) {
+            uint64_t mask = cull_masks[mbase + 4 * (size_t)((rx + 64u * (uint32_t)c) >> 6)];
+            const int rem = (int)deepest - 64 * c;                // list positions of this chunk that are in front of the deepest contributor
+            if (rem < 64) mask &= (1ull << rem) - 1ull;
+            const int b = 63 - lane;
+            if ((mask >> b) & 1ull) {
+                const int k = 64 * c + b;
+                const uint32_t id = point_list[range.x + k];
+                const float4 *r = records + 4 * (size_t)id;
+                const float4 q0 = r[0], q2 = r[2];
+                const int slot = (tail + __popcll(b == 63 ? 0ull : (mask >> (b + 1)))) & (RING - 1);
+                L.ring[0][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
+                L.ring[1][slot] = make_float4(r[1].x * kHalfLog2e, r[3].w, q2.x, __uint_as_float(id));
+                L.ring[2][slot] = make_float4(q2.y, q2.z, q2.w, __uint_as_float((uint32_t)k));
+            }
+            tail += __popcll(mask);
+            wave_lds_sync();
+            while (tail - head >= 16 || (c == 0 && tail > head)) {
+                const int nb = (tail - head) < 16 ? (tail - head) : 16;
+                bwd_batch<MODE>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                head += nb;
+                wave_lds_sync();
+            }
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { unsigned long long z[8] = { 0 }; e = hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)); }
+    return e;
+}
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, hipStream_t stream)
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
     hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
         prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx);
+        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, cull_masks);
     return hipGetLastError();
 }
 
+// variant: 0 = per-pixel lanes + LDS reduction; 2 = scan version with the sums on the matrix cores (accumulator layout 1);
+//          4 = scan version with register accumulation and the forward kernel's cull masks (default); 8 = 4 + developer statistics
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, hipStream_t stream)
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const unsigned long long *cull_masks, int variant, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
-        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records,
-        out_depth, out_acc, prm.min_depth, final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16);
+    const int Tpad = 8 * ((T + 7) / 8);
+#define BWD_ARGS prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, out_depth, out_acc, prm.min_depth, \
+                 final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16
+    if (variant == 0) hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(Tpad), dim3(256), 0, stream, BWD_ARGS);
+    else if (variant == 2) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, 0>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
+    else if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, 4>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
+    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, 2>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
+#undef BWD_ARGS
     return hipGetLastError();
 }

@@ -40,7 +40,12 @@ struct BinState {
     uint32_t *tile_ids;       // final sorted tile ids
     uint32_t *vals_tmp, *keys_tmp;   // ping-pong
     uint32_t *sort_hist;
+    // per (64-entry chunk of a tile list, quadrant): the lanes that survived the forward kernel's quadrant cull; the compositing
+    // backward compacts its lists from these masks instead of gathering and testing every entry again.
+    // slot of chunk c of tile t: 4 * (((range.x + 64 c) >> 6) + t) + quadrant   (unique: ranges are disjoint and ascending in t)
+    unsigned long long *cull_masks;
 };
+static inline size_t ex4d_cull_mask_words(uint32_t R, int T) { return 4 * ((size_t)(R >> 6) + (size_t)T + 2); }
 struct ImgState {
     float *final_T;
     uint32_t *n_contrib;
@@ -71,7 +76,7 @@ hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *vi
 
 hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3D, const int32_t *radii,
     const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
-    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
+    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16, int acc_layout,
     float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
     float *dL_dscales, float *dL_drotations, float *dL_ddir, ShSplit split, ShSplitGrad gsplit, hipStream_t stream);
 
@@ -89,9 +94,12 @@ hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, 
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, hipStream_t stream);
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, hipStream_t stream);
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const unsigned long long *cull_masks, int variant, hipStream_t stream);
+
+// developer statistics of the scan compositing backward (variant 8)
+hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset);

@@ -188,9 +188,20 @@ typedef struct Ex4dImgLayout {
 void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out);
 void ex4d_binning_layout(int32_t num_rendered, int32_t W, int32_t H, Ex4dBinningLayout *out);
 void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
-/* offset of the packed per-Gaussian accumulator rows (float[P][16]) inside bwd_scratch:
- * 0..2 dL_dmean2D.xyz, 3..5 dL_dconic.(x,y,w), 6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir */
+/* offset of the packed per-Gaussian accumulator rows (float[P][16]) inside bwd_scratch -- for parity tests only.
+ * Row contents depend on ex4d_get_option("acc_layout"):
+ *   0: 0..2 dL_dmean2D.xyz (xy without the factors ln2 W/2, ln2 H/2), 3..5 dL_dconic.(x,y,w) (without -1/2), 6 dL_dopacity,
+ *      7..9 dL_dcolor, 10..12 dL_ddir
+ *   1: 0,1 = sum sG dx, sum sG dy; 2 dL_dmean2D.z; 3..5 = sum sG dx^2, sum sG dx dy, sum sG dy^2 (sG = dL_dG G, d = mean2D - pixel);
+ *      6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir */
 size_t ex4d_backward_scratch_acc_offset(int32_t P);
+
+/* Tuning knobs (process-wide; results are the same within float rounding whatever the setting):
+ *   "composite_bwd_variant"  0 = per-pixel lanes + LDS reduction, 2 = (Gaussian, pixel-slot) lanes with the sums on the matrix
+ *                            cores, 4 = the same lanes with register accumulation (default), 8 = 4 + developer statistics
+ * ex4d_get_option additionally answers "acc_layout" (see above).  Returns EX4D_OK / the value, or an error / -1. */
+int ex4d_set_option(const char *name, int value);
+int ex4d_get_option(const char *name);
 
 /* Optional per-stage timing (hipEvents on the caller's stream, single host thread; used by bench.py).
  * ex4d_profile_read(which = 0 forward / 1 backward) waits for the last recorded call of that kind and

@@ -93,13 +93,29 @@ def gpu_backward_raw(ins, fwd, grads, device="cuda"):
     return res
 
 
-def acc16_in_reference_units(acc16, W, H):
-    """The compositing backward accumulates dL_dmean2D.xy and dL_dconic without their constant factors
-    (ln2*W/2, ln2*H/2, -1/2); the per-Gaussian backward kernel applies them in float32 exactly like this."""
+def acc_layout():
+    """Layout of the compositing backward's accumulator rows (include/ex4d_rasterizer.h: ex4d_get_option("acc_layout"))."""
+    from ex4dgs_amd import _C
+    return _C.get_option("acc_layout")
+
+
+def acc16_in_reference_units(acc16, W, H, conic=None, layout=None):
+    """Accumulator rows of the compositing backward -> the reference's dL_dmean2D.xyz / dL_dconic.(x,y,w) / ... (float32,
+    the same operations in the same order as the per-Gaussian backward kernel, so the result is bit-identical to what it uses).
+    layout 0: xy and conic sums lack their constant factors (ln2*W/2, ln2*H/2, -1/2).
+    layout 1: rows hold the moments sum sG d, sum sG d d^T; the mean2D gradient is -(A Sx + B Sy) W/2, -(C Sy + B Sx) H/2."""
+    layout = acc_layout() if layout is None else layout
     a = np.array(to_np(acc16), dtype=np.float32, copy=True)
-    ln2 = np.float32(0.6931471805599453)
-    a[:, 0] = a[:, 0] * (ln2 * (np.float32(0.5) * np.float32(W)))
-    a[:, 1] = a[:, 1] * (ln2 * (np.float32(0.5) * np.float32(H)))
+    if layout == 0:
+        ln2 = np.float32(0.6931471805599453)
+        a[:, 0] = a[:, 0] * (ln2 * (np.float32(0.5) * np.float32(W)))
+        a[:, 1] = a[:, 1] * (ln2 * (np.float32(0.5) * np.float32(H)))
+    else:
+        c = np.asarray(to_np(conic), dtype=np.float32)
+        A, B, C = c[:, 0], c[:, 1], c[:, 2]
+        sx, sy = a[:, 0].copy(), a[:, 1].copy()
+        a[:, 0] = -(A * sx + B * sy) * (np.float32(0.5) * np.float32(W))
+        a[:, 1] = -(C * sy + B * sx) * (np.float32(0.5) * np.float32(H))
     a[:, 3:6] = np.float32(-0.5) * a[:, 3:6]
     return a
 
@@ -108,7 +124,7 @@ def to_np(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
-def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4):
+def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4, tag=""):
     """o: oracle dict, g: gpu dict.  Integers bit-exact; floats <= atol (relative to max(1,|ref|)) on every
     pixel that is not 'fragile' (an alpha/T/power decision within frag_eps of its threshold in the oracle:
     a 1-ulp exp() difference legitimately flips those, CR/forward.cu:372-387)."""
@@ -161,30 +177,55 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4):
         a, b = o["final_T"], to_np(g["final_T"])
         assert np.abs(a - b)[solid].max() <= atol
     rep["worst"] = float(worst)
+    rep["fragile_pixels"] = int((~solid).sum())
+    rep["pixels"] = int(H * W)
+    if P:
+        rep["idx_undecided_pixels"] = int(solid.sum() - decided.sum())
+    REPORT.append(dict(kind="forward", tag=tag, P=int(P), R=int(o["num_rendered"]), W=int(W), H=int(H), **rep))
     return rep
 
 
-def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0):
-    """Accumulated quantities: |gpu - oracle_double_sum| <= atol + k_eps * 2^-24 * sum|terms| per entry (the
-    reference itself sums with float atomics in arbitrary order).  Per-Gaussian derived gradients:
-    same bound propagated loosely via relative tolerance on the row scale."""
+REPORT = []          # one dict per compared case; conftest.py writes it to gpurun_out/parity_report.json at session end
+GRAD_NAMES = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_ddir", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+
+
+def gradient_errors(ob, gb, P):
+    """Per returned gradient tensor: max-abs error, the tensor's max magnitude, their ratio (the number the 1e-5 bar applies to:
+    max-abs relative to max(1, |reference|_max) of that tensor) and the worst error relative to the row scale."""
     rep = {}
-    P = fwd_o["P"]
-    if P == 0:
-        return rep
-    eps = 2.0 ** -24
-    acc = acc16_in_reference_units(gb["acc16"], fwd_o["W"], fwd_o["H"])[:, :13].astype(np.float64)
-    tol = atol + k_eps * eps * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
-    err = np.abs(acc - ob["sum13"])
-    rep["acc16_worst_ratio"] = float((err / tol).max())
-    assert (err <= tol).all(), f"accumulators out of tolerance: worst ratio {rep['acc16_worst_ratio']}, at {np.unravel_index((err / tol).argmax(), err.shape)}"
-    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_ddir", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+    for k in GRAD_NAMES:
         a, b = ob[k].astype(np.float64), to_np(gb[k]).astype(np.float64)
         assert a.shape == b.shape, (k, a.shape, b.shape)
         if a.size == 0:
             continue
         a2, b2 = a.reshape(P, -1), b.reshape(P, -1)
-        scale = np.maximum(np.abs(a2).max(1, keepdims=True), 1.0)
-        rel = np.abs(a2 - b2) / scale
-        rep[k] = float(rel.max())
+        err = np.abs(a2 - b2)
+        ref_max = float(np.abs(a2).max())
+        row = np.maximum(np.abs(a2).max(1, keepdims=True), 1.0)
+        rep[k] = dict(max_abs=float(err.max()), ref_max=ref_max, rel_to_tensor_max=float(err.max() / max(1.0, ref_max)),
+                      rel_to_row_scale=float((err / row).max()))
+    return rep
+
+
+def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, grad_tol=1e-5, conic=None, tag=""):
+    """Accumulated quantities: |gpu - oracle_double_sum| <= atol + k_eps * 2^-24 * sum|terms| per entry (the reference itself
+    sums with float atomics in arbitrary order).  The nine returned gradients: max-abs error <= grad_tol * max(1, max|reference|)
+    per tensor (north_star's 1e-5, applied relative to the tensor's magnitude: raw values reach 1e3..1e5 where one float32 ulp
+    already exceeds 1e-5)."""
+    rep = {}
+    P = fwd_o["P"]
+    if P == 0:
+        return rep
+    eps = 2.0 ** -24
+    conic = fwd_o["conic_opacity"] if conic is None else conic
+    acc = acc16_in_reference_units(gb["acc16"], fwd_o["W"], fwd_o["H"], conic=conic)[:, :13].astype(np.float64)
+    tol = atol + k_eps * eps * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
+    err = np.abs(acc - ob["sum13"])
+    rep["acc16_worst_ratio"] = float((err / tol).max())
+    rep["acc16_max_abs"] = [float(x) for x in err.max(0)]
+    assert (err <= tol).all(), f"accumulators out of tolerance: worst ratio {rep['acc16_worst_ratio']}, at {np.unravel_index((err / tol).argmax(), err.shape)}"
+    rep["grads"] = gradient_errors(ob, gb, P)
+    REPORT.append(dict(kind="backward", tag=tag, P=int(P), R=int(fwd_o["num_rendered"]), W=int(fwd_o["W"]), H=int(fwd_o["H"]), **rep))
+    for k, r in rep["grads"].items():
+        assert r["rel_to_tensor_max"] <= grad_tol, f"{k}: max-abs error {r['max_abs']:.3e} = {r['rel_to_tensor_max']:.2e} of the tensor's max magnitude {r['ref_max']:.3e} (> {grad_tol})"
     return rep

@@ -23,7 +23,7 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
         mutate(ins, st)
     o = h.oracle_forward(ins, st, subpixel_offset=subpixel)
     g = h.gpu_forward_raw(ins, st, subpixel_offset=subpixel)
-    rep = h.compare_forward(o, g, max_fragile_frac=max_fragile_frac)
+    rep = h.compare_forward(o, g, max_fragile_frac=max_fragile_frac, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t}")
     H, W = st["image_height"], st["image_width"]
     grads = list(h.upstream_grads(torch.from_numpy(o["acc"]), H, W, seed=seed, grad_acc_zero=grad_acc_zero))
     solid = torch.from_numpy(o["fragile"] > 1e-4)
@@ -37,9 +37,14 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
                     n_contrib=np.ascontiguousarray(h.to_np(g["n_contrib"]).astype(np.uint32)))
     ob = oracle.backward(ob_state, *grads)
     gb = h.gpu_backward_raw(ins, g, grads)
-    rep.update(h.compare_backward(ob, gb, o))
+    rep.update(h.compare_backward(ob, gb, o, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} (oracle backward on the GPU forward's state)"))
+    # end to end: oracle(forward -> backward) against GPU(forward -> backward), nothing shared but the inputs.  The oracle's own
+    # forward state differs from the GPU's by forward rounding (<= 1e-5, checked above), which dL_dalpha amplifies through
+    # (final_depth - depth) dL_ddepth / acc: bound 3e-5 instead of 1e-5
+    ob_e2e = oracle.backward(o, *grads)
+    h.compare_backward(ob_e2e, gb, o, atol=3e-5, k_eps=256.0, grad_tol=3e-5, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} END-TO-END")
     # per-Gaussian backward stage in isolation: feed the GPU's own accumulators to the oracle's stage
-    acc = h.acc16_in_reference_units(gb["acc16"], o["W"], o["H"])
+    acc = h.acc16_in_reference_units(gb["acc16"], o["W"], o["H"], conic=o["conic_opacity"])
     res = {k: np.zeros_like(v) for k, v in ob.items() if isinstance(v, np.ndarray) and k.startswith("dL_")}
     res["dL_dmeans2D"] = np.ascontiguousarray(acc[:, 0:3])
     res["dL_dconic"] = np.ascontiguousarray(np.stack([acc[:, 3], acc[:, 4], np.zeros_like(acc[:, 3]), acc[:, 5]], -1))
