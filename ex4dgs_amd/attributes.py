@@ -54,26 +54,70 @@ def _ptr(t):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
 
+FEATURE_NAMES = ("_features_dc", "_features_rest", "_features_dc_motion", "_features_rest_motion")
+_BWD_INPUTS = ("_opacity", "_scaling", "_rotation_motion", "_opacity_motion", "_opacity_duration_center", "_opacity_duration_var", "_scaling_motion")
+
+
+def forward_raw(scal, params, with_shs=True):
+    """One launch of ex4d_attributes_forward on the current stream.  params: the 15 tensors in PARAM_ORDER (contiguous float32, one
+    ROCm device).  Returns [means3D, rotations, opacities, scales, shs-or-empty]; no autograd."""
+    lib = _lib()
+    dev = params[0].device
+    if not params[0].is_cuda:
+        raise RuntimeError(f"parameters are on {dev}: the fused attribute evaluation only runs on a ROCm GPU (no CPU fallback)")
+    for x in params:
+        if x.dtype != torch.float32 or x.device != dev or not x.is_contiguous():
+            raise RuntimeError("all model parameters must be contiguous float32 tensors on the same ROCm device")
+    N = scal.Ns + scal.Nd
+    f32 = dict(dtype=torch.float32, device=dev)
+    outs = [torch.empty(N, 3, **f32), torch.empty(N, 4, **f32), torch.empty(N, 1, **f32), torch.empty(N, 3, **f32),
+            torch.empty(N, 16, 3, **f32) if with_shs else torch.empty(0, **f32)]
+    with torch.cuda.device(dev):
+        rc = lib.ex4d_attributes_forward(C.byref(scal), *[_ptr(x) for x in params], *[_ptr(o) for o in outs],
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        raise RuntimeError(lib.ex4d_attributes_last_error().decode())
+    return outs
+
+
+def backward_raw(scal, params, grads_in, with_shs=True, out=None):
+    """One launch of ex4d_attributes_backward on the current stream.  grads_in: dL/d(means3D, rotations, opacities, scales, shs)
+    (None = zeros; the shs entry is ignored when with_shs is False).  out: optional list of 15 preallocated gradient tensors
+    (PARAM_ORDER; None entries are allocated) -- every one is written exactly once, dense.  Returns the 15 gradients (None for the
+    feature tensors when with_shs is False: their gradient comes out of the rasterizer's SplitSH path)."""
+    lib = _lib()
+    dev = params[0].device
+    N = scal.Ns + scal.Nd
+    f32 = dict(dtype=torch.float32, device=dev)
+    shapes = ((N, 3), (N, 4), (N, 1), (N, 3), (N, 16, 3))
+    gin = [(torch.zeros(*s, **f32) if g is None else g.contiguous()) for g, s in zip(grads_in, shapes)]
+    if not with_shs:
+        gin[4] = None                              # dL/dsh goes to the feature tensors through the rasterizer (SplitSH), not through here
+    gout = []
+    for i, (n, x) in enumerate(zip(PARAM_ORDER, params)):
+        if not with_shs and n in FEATURE_NAMES:
+            gout.append(None)
+        elif out is not None and out[i] is not None:
+            if out[i].shape != x.shape or out[i].dtype != torch.float32 or out[i].device != dev or not out[i].is_contiguous():
+                raise RuntimeError(f"gradient buffer for {n} must be a contiguous float32 tensor of shape {tuple(x.shape)} on {dev}")
+            gout.append(out[i])
+        else:
+            gout.append(torch.empty_like(x))
+    byname = dict(zip(PARAM_ORDER, params))
+    with torch.cuda.device(dev):
+        rc = lib.ex4d_attributes_backward(
+            C.byref(scal), *[_ptr(byname[n]) for n in _BWD_INPUTS],
+            *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        raise RuntimeError(lib.ex4d_attributes_last_error().decode())
+    return gout
+
+
 class _EvaluateAttributes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scal, with_shs, on_backward, *params):
-        lib = _lib()
         p = [x.contiguous() for x in params]
-        dev = p[0].device
-        if not p[0].is_cuda:
-            raise RuntimeError(f"parameters are on {dev}: the fused attribute evaluation only runs on a ROCm GPU (no CPU fallback)")
-        for x in p:
-            if x.dtype != torch.float32 or x.device != dev:
-                raise RuntimeError("all model parameters must be float32 tensors on the same ROCm device")
-        N = scal.Ns + scal.Nd
-        f32 = dict(dtype=torch.float32, device=dev)
-        outs = [torch.empty(N, 3, **f32), torch.empty(N, 4, **f32), torch.empty(N, 1, **f32), torch.empty(N, 3, **f32),
-                torch.empty(N, 16, 3, **f32) if with_shs else torch.empty(0, **f32)]
-        with torch.cuda.device(dev):
-            rc = lib.ex4d_attributes_forward(C.byref(scal), *[_ptr(x) for x in p], *[_ptr(o) for o in outs],
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        if rc:
-            raise RuntimeError(lib.ex4d_attributes_last_error().decode())
+        outs = forward_raw(scal, p, with_shs)
         ctx.scal = scal
         ctx.with_shs = with_shs
         ctx.on_backward = on_backward
@@ -82,28 +126,9 @@ class _EvaluateAttributes(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_means3D, g_rotations, g_opacities, g_scales, g_shs):
-        lib = _lib()
         if ctx.on_backward is not None:
             ctx.on_backward()                      # the owner's cache of these outputs is stale from here on (graph consumed)
-        p = ctx.saved_tensors
-        scal = ctx.scal
-        dev = p[0].device
-        N = scal.Ns + scal.Nd
-        f32 = dict(dtype=torch.float32, device=dev)
-        shapes = ((N, 3), (N, 4), (N, 1), (N, 3), (N, 16, 3))
-        gin = [(torch.zeros(*s, **f32) if g is None else g.contiguous()) for g, s in zip((g_means3D, g_rotations, g_opacities, g_scales, g_shs), shapes)]
-        if not ctx.with_shs:
-            gin[4] = None                          # dL/dsh goes to the feature tensors through the rasterizer (SplitSH), not through here
-        feature_names = ("_features_dc", "_features_rest", "_features_dc_motion", "_features_rest_motion")
-        gout = [None if (not ctx.with_shs and n in feature_names) else torch.empty_like(x) for n, x in zip(PARAM_ORDER, p)]
-        byname = dict(zip(PARAM_ORDER, p))
-        with torch.cuda.device(dev):
-            rc = lib.ex4d_attributes_backward(
-                C.byref(scal), *[_ptr(byname[n]) for n in ("_opacity", "_scaling", "_rotation_motion", "_opacity_motion",
-                                                           "_opacity_duration_center", "_opacity_duration_var", "_scaling_motion")],
-                *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        if rc:
-            raise RuntimeError(lib.ex4d_attributes_last_error().decode())
+        gout = backward_raw(ctx.scal, list(ctx.saved_tensors), (g_means3D, g_rotations, g_opacities, g_scales, g_shs), ctx.with_shs)
         return (None, None, None) + tuple(gout)
 
 

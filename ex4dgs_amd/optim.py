@@ -32,6 +32,21 @@ def _lib():
     return lib
 
 
+def radam_step_raw(items, betas, eps, device):
+    """One fused launch (per <= 32 tensors) over raw element ranges.  items: iterable of
+    (param_ptr, grad_ptr, exp_avg_ptr, exp_avg_sq_ptr, numel, lr, step) -- plain device pointers, so a range may be a whole tensor or
+    a rank's shard of one (RAdam is element-wise: updating ranges separately gives bit-identical results)."""
+    lib = _lib()
+    descs = [Ex4dRadamTensor(int(p), int(g), int(m), int(v), int(n), float(lr), int(step)) for (p, g, m, v, n, lr, step) in items if n > 0]
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for i in range(0, len(descs), MAX_TENSORS):
+            chunk = descs[i:i + MAX_TENSORS]
+            arr = (Ex4dRadamTensor * len(chunk))(*chunk)
+            if lib.ex4d_radam_step(arr, len(chunk), betas[0], betas[1], eps, stream):
+                raise RuntimeError(lib.ex4d_optim_last_error().decode())
+
+
 class FusedRAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if weight_decay != 0:

@@ -42,7 +42,7 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     # forward state differs from the GPU's by forward rounding (<= 1e-5, checked above), which dL_dalpha amplifies through
     # (final_depth - depth) dL_ddepth / acc: bound 3e-5 instead of 1e-5
     ob_e2e = oracle.backward(o, *grads)
-    h.compare_backward(ob_e2e, gb, o, atol=3e-5, k_eps=256.0, grad_tol=3e-5, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} END-TO-END")
+    h.compare_backward(ob_e2e, gb, o, atol=3e-5, k_eps=256.0, rel_tol=3e-5, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} END-TO-END")
     # per-Gaussian backward stage in isolation: feed the GPU's own accumulators to the oracle's stage
     acc = h.acc16_in_reference_units(gb["acc16"], o["W"], o["H"], conic=o["conic_opacity"])
     res = {k: np.zeros_like(v) for k, v in ob.items() if isinstance(v, np.ndarray) and k.startswith("dL_")}

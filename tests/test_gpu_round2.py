@@ -33,13 +33,14 @@ def test_fused_cache_survives_two_backwards_at_one_timestamp(hip_lib):
         out = render(cam, model, None, bg, timestamp=137, near=4.0, far=300.0)
         (out["render"] * gc).sum().backward()           # raised "backward through the graph a second time" before the fix
         grads.append(model._xyz_motion.grad.clone())
-    assert torch.allclose(grads[1], 2 * grads[0], rtol=1e-4, atol=1e-7)      # accumulated twice the same gradient
+    tol = 1e-4 * float(grads[0].abs().max())                 # float atomics: the two passes agree to rounding, not bit-wise
+    assert float((grads[1] - 2 * grads[0]).abs().max()) <= tol      # accumulated twice the same gradient
     # two renders BEFORE one backward share the cached evaluation and both reach the parameters
     model.zero_grad()
     a = render(cam, model, None, bg, timestamp=137, near=4.0, far=300.0)
     b = render(cam, model, None, bg, timestamp=137, near=4.0, far=300.0)
     ((a["render"] + b["render"]) * gc).sum().backward()
-    assert torch.allclose(model._xyz_motion.grad, grads[1], rtol=1e-4, atol=1e-7)
+    assert float((model._xyz_motion.grad - grads[1]).abs().max()) <= tol
 
 
 @pytest.mark.parametrize("fused", [False, True])
