@@ -1,20 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- fwd+bwd ms/frame of the MI355X-native rasterizer on BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg4|...]
 
-One "step" = GaussianRasterizer.forward + .backward (boundary-to-boundary: the reference's
-_RasterizeGaussians autograd surface; model getters and the loss are outside) on one
-synthetic frame per rank: 1.0M static+dynamic Gaussians (K=35 keyframes), 1352x1014, SH degree 3, inputs
-resident in HBM.  N > 1: one process per GPU (torchrun contract), frames sharded round-robin over ranks,
-rasterizer-input gradients sum-all-reduced over RCCL/xGMI asynchronously (overlapping the next frame).
-Rank 0 prints ONE JSON line.  Extra legs outside the timed region: per-stage hipEvent timing (roofline) and,
-on rank 0 at N=1, the CPU baseline (the C oracle on a bounded sample + the pure-PyTorch tiny-scene rasterize).
+N = 1, default config (cfg3: 1.0M static+dynamic Gaussians, K=35 keyframes, 1352x1014, SH degree 3, inputs resident in HBM):
+    one "step" = GaussianRasterizer.forward + .backward on one synthetic frame, boundary to boundary (the reference's
+    _RasterizeGaussians autograd surface; model getters and the loss are outside).  This is BASELINE.json's metric.
+N > 1, or --config cfg4 (2.0M Gaussians x 300 timestamps) at any N:
+    one "step" = the training-iteration core of ONE view per rank (ex4dgs_amd/trainer.py): fused attribute evaluation at the view's
+    timestamp -> rasterizer forward+backward -> fused attribute backward -> asynchronous sum of the 15 MODEL-PARAMETER gradients over
+    the ranks (RCCL over xGMI, overlapping the next frame).  Views / timestamps shard round-robin over the ranks (i = r mod N),
+    parameters are replicated; per-rank work is fixed as N grows (weak scaling), `value` = ms per frame of the whole job.
+`--gpus N` without a torchrun environment starts the N ranks itself (one process per GPU).  Rank 0 prints ONE JSON line.
+Extra legs outside the timed region: per-stage hipEvent timing (roofline) and, on rank 0 at N=1, the CPU baselines (the C oracle on
+BASELINE config 2 at full size and on a bounded sample of config 3, the pure-PyTorch rasterize of config 1).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +34,7 @@ from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSetti
 from ex4dgs_amd.scene import CONFIGS, make_scene                                   # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def frame_inputs(model, t, device):
@@ -55,7 +62,7 @@ def algorithmic_bytes(P, V, R, HW, T, D=3, passes=6):
 
 
 def cpu_baseline(cfg_name, sample_P, t):
-    """Oracle (scalar C port, 1 core) fwd+bwd on a bounded sample of the same generator."""
+    """Oracle (scalar C port, 1 core) fwd+bwd on the generator of `cfg_name` at `sample_P` Gaussians."""
     from oracle import oracle
     model, cam, bg = make_scene(cfg_name, P=sample_P)
     cfg = CONFIGS[cfg_name]
@@ -76,8 +83,9 @@ def cpu_baseline(cfg_name, sample_P, t):
     t3 = time.time()
     ms = 1e3 * ((t1 - t0) + (t3 - t2))
     R = f["num_rendered"]
+    frac = sample_P / CONFIGS[cfg_name].P
     return {"value": round(ms, 1), "unit": "ms/frame", "cores": 1, "kind": "port",
-            "sample": f"{cfg_name} generator at P={sample_P} ({sample_P / CONFIGS[cfg_name].P:.2f}x Gaussians), {W}x{H}, 1 frame fwd+bwd, "
+            "sample": f"{cfg_name} generator at P={sample_P} ({'full size' if frac == 1 else f'{frac:.2f}x Gaussians'}), {W}x{H}, 1 frame fwd+bwd, "
                       f"R={R} instances, oracle/ex4d_oracle.c scalar C, fwd {1e3 * (t1 - t0):.0f} ms + bwd {1e3 * (t3 - t2):.0f} ms",
             "pair_evals_per_s": round(2 * R * 256 / (ms / 1e3), 0)}
 
@@ -178,6 +186,66 @@ def model_step_timing(cfg_name, dev, grads, steps=20, warmup=5, points=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`--gpus N` outside a torchrun environment: start the N ranks ourselves (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like
+    torchrun), forward rank 0's JSON line, fail if any rank fails."""
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if not args.share_device and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (use --share-device --backend gloo to debug on fewer)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    if torch.cuda.is_available():
+        hip_build.build()                       # once, before the ranks race for it
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != n:
+        print(f"bench.py: expected one JSON line with n_gpus={n}, got: {out0[-500:]}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def percentiles(ms):
+    s = sorted(ms)
+    pick = lambda q: s[min(len(s) - 1, int(round(q * (len(s) - 1))))]
+    return {"mean": round(sum(s) / len(s), 4), "p50": round(pick(0.5), 4), "p95": round(pick(0.95), 4), "min": round(s[0], 4), "max": round(s[-1], 4),
+            "n": len(s), "how": "hipEvent pairs around every timed step on the op's stream"}
+
+
+def timed_loop(step, steps, warmup, sync_all, finish=None):
+    """W warm-up steps, then K timed steps between barrier + synchronize pairs; per-step hipEvents on the current stream."""
+    for i in range(warmup):
+        step(i)
+    if finish:
+        finish()
+    sync_all()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        step(i)
+        ev[i + 1].record()
+    if finish:
+        finish()
+    sync_all()
+    t1 = time.perf_counter()
+    per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    return 1e3 * (t1 - t0) / max(steps, 1), per_step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,22 +254,26 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--points", type=int, default=None, help="override the Gaussian count (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-allreduce", action="store_true")
+    ap.add_argument("--no-allreduce", action="store_true", help="N > 1 without the gradient exchange (pure replicas)")
     ap.add_argument("--forward-only", action="store_true", help="render only (BASELINE config 5 is quoted as forward-only FPS); not the headline metric")
     ap.add_argument("--no-model-step", action="store_true", help="skip the training-iteration timings (profiling runs)")
+    ap.add_argument("--train-core", action="store_true", help="N = 1: time the training-iteration core (what N > 1 and cfg4 time) instead of the rasterizer alone")
+    ap.add_argument("--optimizer", default="none", choices=["none", "replicated", "sharded"], help="training-core steps: include the RAdam step")
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the rasterizer has no CPU fallback")
     if args.share_device:
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = xdist.init_from_env(backend=args.backend)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different rank count")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if rank == 0:
@@ -213,48 +285,11 @@ def main():
         _C.set_option("composite_bwd_variant", args.bwd_variant)
 
     cfg = CONFIGS[args.config]
-    model, cam, bg = make_scene(args.config, P=args.points)
-    cam = cam.to(dev); bg = bg.to(dev)
-    H, W = cam.image_height, cam.image_width
-    # three resident frames per rank (timestamps of SURVEY.md 8d), sharded round-robin over ranks
-    stamps = [0, 137, 299, 41, 203, 88, 266, 171]
-    my_stamps = [stamps[(i * world + rank) % len(stamps)] for i in range(3)]
-    frames = [frame_inputs(model, t, dev) for t in my_stamps]
-    del model
-    P = frames[0][0].shape[0]
-    settings = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=0.1,
-        subpixel_offset=torch.zeros(H, W, 2, device=dev), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
-        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False,
-        min_depth=cfg.min_depth, max_depth=cfg.max_depth, debug=False)
-    empty = torch.Tensor([])
+    train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only
+    H, W = cfg.height, cfg.width
     g = torch.Generator().manual_seed(1000 + rank)
     grads = [torch.randn(3, H, W, generator=g).to(dev), (0.1 * torch.randn(1, H, W, generator=g)).to(dev),
              torch.rand(3, H, W, generator=g).to(dev), torch.zeros(1, H, W, device=dev)]
-    means2D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
-    dir3D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
-
-    buckets = None
-    if world > 1 and not args.no_allreduce and not args.forward_only:
-        buckets = xdist.GradBuckets([x.shape for x in frames[0]], device=dev)
-    info = {}
-
-    def step(i):
-        f = i % len(frames)
-        xyz, shs, opa, scl, rot = frames[f]
-        for t in frames[f] + [means2D[f], dir3D[f]]:
-            t.grad = None
-        if args.forward_only:
-            with torch.no_grad():
-                color, radii, depth, flow, acc, idx = rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)
-            info["radii"] = radii
-            return color
-        color, radii, depth, flow, acc, idx = rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)
-        torch.autograd.backward([color, depth, flow, acc], [grads[0], grads[1], grads[2], grads[3]])
-        if buckets is not None:
-            buckets.launch([t.grad for t in frames[f]])      # waits for the previous frame's exchange first
-        info["radii"] = radii
-        return color
 
     def sync_all():
         torch.cuda.synchronize()
@@ -262,38 +297,114 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if buckets is not None:
-        buckets.wait()
-    sync_all()
-    t1 = time.perf_counter()
-    ms_per_step = xdist.allreduce_max_scalar(1e3 * (t1 - t0) / max(args.steps, 1), device=dev)
+    multi = None
+    if not train_mode:
+        # ---------------- rasterizer alone on resident frames (BASELINE metric) ----------------
+        model, cam, bg = make_scene(args.config, P=args.points)
+        cam = cam.to(dev); bg = bg.to(dev)
+        stamps = [0, 137, 299, 41, 203, 88, 266, 171]
+        my_stamps = [stamps[(i * world + rank) % len(stamps)] for i in range(3)]
+        frames = [frame_inputs(model, t, dev) for t in my_stamps]
+        del model
+        P = frames[0][0].shape[0]
+        settings = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=0.1,
+            subpixel_offset=torch.zeros(H, W, 2, device=dev), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False,
+            min_depth=cfg.min_depth, max_depth=cfg.max_depth, debug=False)
+        empty = torch.Tensor([])
+        means2D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
+        dir3D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
 
-    # ---- per-stage hipEvent timing (outside the timed region), scene statistics ------------------
+        def step(i):
+            f = i % len(frames)
+            xyz, shs, opa, scl, rot = frames[f]
+            for t in frames[f] + [means2D[f], dir3D[f]]:
+                t.grad = None
+            if args.forward_only:
+                with torch.no_grad():
+                    return rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)[0]
+            color, radii, depth, flow, acc, idx = rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)
+            torch.autograd.backward([color, depth, flow, acc], [grads[0], grads[1], grads[2], grads[3]])
+            return color
+
+        ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all)
+        parallelism = f"frame-sharded x{world}" + ("" if world == 1 else " (no collective)")
+        step_what = "GaussianRasterizer forward" + ("" if args.forward_only else " + backward") + " on a resident frame"
+    else:
+        # ---------------- training-iteration core, one view per rank per step ----------------
+        from ex4dgs_amd.trainer import FrameTrainer
+        model, cam, bg = make_scene(args.config, P=args.points, device=dev, fused=True)
+        cam = cam.to(dev); bg = bg.to(dev)
+        P = model.num_static + model.num_dynamic
+        n_stamps = 300 if args.config == "cfg4" else 8
+        all_stamps = list(range(300)) if args.config == "cfg4" else [0, 137, 299, 41, 203, 88, 266, 171]
+        my_stamps = [all_stamps[i] for i in xdist.shard_views(n_stamps, rank, world)]      # i = rank (mod world)
+        upstream = lambda out: ([out["render"], out["depth"], out["opticalflow"], out["acc"]], grads)
+        exchange = "none" if (world == 1 or args.no_allreduce) else ("sharded" if args.optimizer == "sharded" else "allreduce")
+        if world == 1 and args.optimizer == "sharded":
+            exchange = "sharded"
+        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"),
+                          lrs={n: 1e-7 for n in model.PARAM_NAMES})       # tiny learning rates: the synthetic scene stays put
+
+        def step(i):
+            return tr.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)["render"]
+
+        ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all, finish=tr.flush)
+        parallelism = f"views/timestamps sharded i = r (mod {world}), parameters replicated" + (
+            "" if tr.exchange is None else (" + reduce-scatter / sharded RAdam / all-gather" if exchange == "sharded" else " + async RCCL all-reduce of the 15 model-parameter gradients"))
+        step_what = ("training-iteration core of one view per rank: fused attribute evaluation -> rasterizer forward+backward -> attribute "
+                     "backward" + ("" if tr.exchange is None else " -> gradient exchange") + ("" if args.optimizer == "none" else f" -> {args.optimizer} RAdam step"))
+        if world > 1:
+            # the same loop without the exchange (exposed communication = difference) and the exchange alone (its full length)
+            tr0 = FrameTrainer(model, exchange="none")
+            step0 = lambda i: tr0.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)
+            ms_noex, _ = timed_loop(step0, args.steps, max(2, args.warmup // 2), sync_all, finish=tr0.flush)
+            ex_alone = None
+            if tr.exchange is not None and exchange == "allreduce":
+                tr0.step(cam, bg, my_stamps[0], upstream, near=cfg.min_depth, far=cfg.max_depth); tr0.flush()
+                gl = list(tr0.grads().values())
+
+                def ex_only(i):
+                    tr.exchange.launch(gl); tr.exchange.wait()
+                ex_alone, _ = timed_loop(ex_only, max(4, args.steps // 4), 2, sync_all)
+            ms_noex = xdist.allreduce_max_scalar(ms_noex, device=dev)
+            multi = {"ranks_seen": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                     "collective_tensors": len(model.PARAM_NAMES) if tr.exchange is not None else 0,
+                     "exchange_bytes_per_rank": tr.exchange.bytes_on_wire() if tr.exchange is not None else 0,
+                     "ms_per_step_without_exchange": round(ms_noex, 4),
+                     "allreduce_ms_per_step": None if ex_alone is None else round(xdist.allreduce_max_scalar(ex_alone, device=dev), 4),
+                     "share_device": bool(args.share_device)}
+        model.fused = False           # plain getters for the statistics pass below (one [P,16,3] SH tensor instead of the SplitSH)
+        frames = [frame_inputs(model, t, dev) for t in my_stamps[:2]]
+        settings = tr._settings(cam, bg, cfg.min_depth, cfg.max_depth)
+        empty = torch.Tensor([])
+        means2D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
+        dir3D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
+
+    ms_per_step = xdist.allreduce_max_scalar(ms_wall, device=dev)
+    if multi is not None:
+        multi["exposed_exchange_ms_per_step"] = round(max(0.0, ms_per_step - multi["ms_per_step_without_exchange"]), 4)
+        if multi["allreduce_ms_per_step"] is not None:
+            multi["overlapped_exchange_ms_per_step"] = round(max(0.0, multi["allreduce_ms_per_step"] - multi["exposed_exchange_ms_per_step"]), 4)
+
+    # ---- per-stage hipEvent timing of the rasterizer (outside the timed region), scene statistics ----------------
     _C.profile_enable(True)
     agg = {}
     nprof = 12
-    R = 0
     for i in range(nprof):
         f = i % len(frames)
         xyz, shs, opa, scl, rot = frames[f]
         for t in frames[f] + [means2D[f], dir3D[f]]:
             t.grad = None
         outs = rasterize_gaussians(xyz, means2D[f], dir3D[f], shs, empty, opa, scl, rot, empty, settings)
-        torch.autograd.backward([outs[0], outs[2], outs[3], outs[4]], grads)
+        if not args.forward_only:
+            torch.autograd.backward([outs[0], outs[2], outs[3], outs[4]], grads)
         torch.cuda.synchronize()
         for which in (0, 1):
             for name, ms in _C.profile_read(which):
                 agg[name] = agg.get(name, 0.0) + ms / nprof
     _C.profile_enable(False)
-    radii = info["radii"]
-    V = int((radii > 0).sum().item())
-    # instance count of the last profiled frame via the C ABI return value
     last = _C.rasterize_gaussians(settings.bg, frames[0][0].detach(), empty, empty, frames[0][2].detach(), frames[0][3].detach(),
                                   frames[0][4].detach(), 1.0, empty, settings.viewmatrix, settings.projmatrix, settings.tanfovx,
                                   settings.tanfovy, 0.1, settings.subpixel_offset, H, W, frames[0][1].detach(), 3, settings.campos,
@@ -302,18 +413,14 @@ def main():
     V = int((last[2] > 0).sum().item())
     T = ((W + 15) // 16) * ((H + 15) // 16)
     stage_bytes, A_fwd, A_bwd = algorithmic_bytes(P, V, R, H * W, T)
-    A = A_fwd + A_bwd
+    A = A_fwd + (0 if args.forward_only else A_bwd)
     kernel_ms = sum(agg.values())
     dom = max(agg, key=agg.get) if agg else None
-    dom_key = {"depth_sort": "sort", "tile_sort": "sort"}.get(dom, dom)
-    dom_bytes = stage_bytes.get(dom_key)
-    if dom == "tile_sort" or dom == "depth_sort":
-        dom_bytes = stage_bytes["sort"]
+    dom_bytes = stage_bytes["sort"] if dom in ("tile_sort", "depth_sort") else stage_bytes.get(dom)
     roof = None
-    traffic = None
-    valu_busy = None
-    try:   # HBM bytes per launch from the PMC passes committed under profiles/ (collected with tools/pmc.sh, not in this run)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+    traffic = valu_busy = None
+    try:   # HBM bytes per launch from the rocprofv3 --pmc passes of this command, collected separately and committed (tools/pmc.sh)
+        with open(os.path.join(ROOT, PMC_FILE)) as fh:
             pmc = json.load(fh)
         if args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
@@ -322,40 +429,47 @@ def main():
         traffic = None
     if dom is not None and dom_bytes:
         achieved = dom_bytes / (agg[dom] * 1e-3) / 1e9
+        rast_ms = ms_per_step if not train_mode else kernel_ms
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": PMC_FILE + " (separate rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
                 "kernel_ms": round(agg[dom], 4), "algorithmic_bytes": int(dom_bytes),
                 # the kernel the contract prices against HBM is VALU-issue bound in practice: SQ counters of the committed PMC pass
                 "valu_busy_frac_pmc": valu_busy,
                 "frame": {"A_fwd_bytes": int(A_fwd), "A_bwd_bytes": int(A_bwd), "A_bytes": int(A),
-                          "achieved_GBps_walltime": round(A / (ms_per_step * 1e-3) / 1e9, 1),
-                          "frac_walltime": round(A / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                          "achieved_GBps_walltime": round(A / (rast_ms * 1e-3) / 1e9, 1),
+                          "frac_walltime": round(A / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                           "achieved_GBps_kernels": round(A / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None},
                 "stage_ms": {k: round(v, 4) for k, v in agg.items()},
-                "pair_evals_per_s_upper": round(2 * 256.0 * R / (ms_per_step * 1e-3), 0)}
+                "pair_evals_per_s_upper": round((1 if args.forward_only else 2) * 256.0 * R / (rast_ms * 1e-3), 0)}
 
     if rank == 0:
+        headline = args.config == "cfg3" and args.points is None and not train_mode and not args.forward_only
         line = {
-            "metric": (f"forward-only ms/frame ({cfg.name})" if args.forward_only else
-                       "fwd+bwd ms/frame @1M Gaussians 1352x1014; achieved HBM GB/s vs peak" if args.config == "cfg3" and args.points is None
-                       else f"fwd+bwd ms/frame ({cfg.name})"),
+            "metric": ("fwd+bwd ms/frame @1M Gaussians 1352x1014; achieved HBM GB/s vs peak" if headline or (args.config == "cfg3" and args.points is None and train_mode)
+                       else f"forward-only ms/frame ({cfg.name})" if args.forward_only else f"fwd+bwd ms/frame ({cfg.name})"),
             "value": round(ms_per_step / world, 4), "unit": "ms/frame", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "frames_per_s": round(1e3 * world / ms_per_step, 2),
+            "step_ms": percentiles(per_step),
             "config": {"workload": cfg.name if args.points is None else f"{cfg.name} [P overridden to {P}]", "P": P, "V": V, "R": R,
-                       "HW": H * W, "tiles": T, "sh_degree": 3, "frames_per_step": world,
-                       "parallelism": f"frame-sharded x{world}" + ("" if world == 1 else (" + async RCCL grad all-reduce" if buckets is not None else " (no collective)"))},
+                       "HW": H * W, "tiles": T, "sh_degree": 3, "frames_per_step": world, "step": step_what, "parallelism": parallelism},
             "roofline": roof,
         }
-        if world == 1 and not args.no_model_step:
+        if multi is not None:
+            line["multi_gpu"] = multi
+        if world == 1 and not args.no_model_step and not train_mode:
             try:
                 line["model_step"] = model_step_timing(args.config, dev, grads, points=args.points)
             except Exception as e:
                 line["model_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
+                # the scalar C oracle on a bounded sample of this run's own workload ...
                 line["cpu_baseline"] = cpu_baseline(args.config, min(args.cpu_sample, P), my_stamps[0])
+                # ... SURVEY.md 8(d)(ii): on BASELINE config 2 at its full size (finishes in seconds), and config 1 on the pure-PyTorch
+                # rasterizer (all host cores)
+                line["cpu_oracle_cfg2_full"] = cpu_baseline("cfg2", CONFIGS["cfg2"].P, 0)
                 line["cpu_torch_baseline"] = cpu_torch_baseline()
             except Exception as e:   # the checker must never take the measurement down
                 line["cpu_baseline"] = {"error": repr(e)}

@@ -1,0 +1,166 @@
+"""One training-iteration core per rank, built from the fused pieces of this package:
+
+    fused attribute evaluation (attributes.forward_raw)            scene/c_gaussian_model.py:170-215,330-375 getters
+ -> rasterizer forward + backward (GaussianRasterizer, SplitSH)    gaussian_renderer/__init__.py:19-124, train.py:139-153
+ -> fused attribute backward into persistent gradient buffers      (autograd of the getters in the reference)
+ -> sum of the 15 model-parameter gradients over the ranks         (the reference is single-process)
+ -> optimizer step: replicated fused RAdam or the sharded one      scene/c_gaussian_model.py:430-449, train.py:250
+
+One view (camera, timestamp) per rank per step: views shard round-robin (dist.shard_views), parameters are replicated.  The
+attribute backward and the gradient exchange of frame i run on a side stream / the communicator's stream while frame i+1 is
+rasterized on the main stream, so on xGMI the exchange hides behind the next frame as far as its length allows.
+No CPU fallback: everything here needs the HIP library and a ROCm device.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import attributes as attr
+from . import dist as xdist
+from ._C import SplitSH
+from .diff_gaussian_rasterization_df import GaussianRasterizationSettings, rasterize_gaussians
+
+# reference learning rates of the 15 groups (arguments/__init__.py of the reference; position groups use the initial value of their schedule)
+DEFAULT_LRS = {"_xyz": 1.6e-4, "_xyz_disp": 1.6e-4, "_rotation": 1e-3, "_opacity": 5e-2, "_scaling": 5e-3, "_features_dc": 2.5e-3,
+               "_features_rest": 2.5e-3 / 20, "_xyz_motion": 1.6e-4, "_rotation_motion": 1e-3, "_opacity_motion": 5e-2,
+               "_opacity_duration_center": 1e-3, "_opacity_duration_var": 1e-3, "_scaling_motion": 5e-3, "_features_dc_motion": 2.5e-3,
+               "_features_rest_motion": 2.5e-3 / 20}
+
+
+class FrameTrainer:
+    """model: scene.DynamicGaussians on a ROCm device.  exchange: "none" | "allreduce" | "sharded" (reduce-scatter + sharded RAdam +
+    all-gather; implies optimizer).  optimizer: False | True (replicated fused RAdam when exchange != "sharded")."""
+
+    def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None):
+        assert exchange in ("none", "allreduce", "sharded")
+        self.model = model
+        self.names = list(attr.PARAM_ORDER)
+        self.params = [getattr(model, n) for n in self.names]
+        self.device = self.params[0].device
+        if self.device.type != "cuda":
+            raise RuntimeError("FrameTrainer needs the model on a ROCm device (no CPU fallback)")
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.mode = exchange if self.world > 1 or exchange == "sharded" else "none"
+        self.overlap = overlap
+        self.side = torch.cuda.Stream(device=self.device) if overlap else None
+        self.feature_idx = [self.names.index(n) for n in attr.FEATURE_NAMES]
+        # persistent gradient buffers of the 11 non-feature parameters (written once per step by the attribute backward);
+        # the four feature gradients come out of the rasterizer's SplitSH path as fresh tensors every step
+        self.pgrad = [None if i in self.feature_idx else torch.zeros_like(p) for i, p in enumerate(self.params)]
+        lrs = dict(DEFAULT_LRS, **(lrs or {}))
+        self.lrs = [lrs[n] for n in self.names]
+        self.opt = None
+        self.exchange = None
+        shapes = [p.shape for p in self.params]
+        if self.mode == "sharded":
+            self.opt = xdist.ShardedRAdam(self.params, self.lrs, group=group)
+            self.exchange = self.opt.exchange
+        else:
+            if self.mode == "allreduce":
+                self.exchange = xdist.ParamGradExchange(shapes, self.device, mode="allreduce", group=group)
+            if optimizer:
+                self.m = [torch.zeros_like(p) for p in self.params]
+                self.v = [torch.zeros_like(p) for p in self.params]
+                self.steps = 0
+        self.optimizer = bool(optimizer) or self.mode == "sharded"
+        self._grads = None
+        self._zero_sub = {}
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _settings(self, cam, bg, near, far):
+        H, W = int(cam.image_height), int(cam.image_width)
+        key = (H, W)
+        if key not in self._zero_sub:
+            self._zero_sub[key] = torch.zeros(H, W, 2, device=self.device)
+        m = self.model
+        return GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), kernel_size=m.kernel_size,
+            subpixel_offset=self._zero_sub[key], bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=m.active_sh_degree, campos=cam.camera_center, prefiltered=False,
+            min_depth=near, max_depth=far, debug=False)
+
+    def finish_exchange(self):
+        """Block the current stream on the pending gradient exchange (its results are needed by the optimizer / the caller)."""
+        if self.exchange is not None:
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    self.exchange.wait()
+                torch.cuda.current_stream(self.device).wait_stream(self.side)
+            else:
+                self.exchange.wait()
+
+    def step(self, cam, bg, t, upstream, near=4.0, far=300.0):
+        """upstream: callable(render dict) -> (list of outputs, list of their gradients), e.g. a loss evaluated with the fused
+        L1+SSIM op, or fixed synthetic gradients.  Returns the render dict (tensors of this frame, detached)."""
+        m = self.model
+        main = torch.cuda.current_stream(self.device)
+        scal = attr.time_scalars(t, m.num_static, m.num_dynamic, m._xyz_motion.shape[1] if m.num_dynamic else 0,
+                                 m.duration, m.interval, m.time_shift, m.var_pad)
+        # the previous frame's exchange must be complete before this frame's optimizer-updated parameters are read (optimizer on) --
+        # without an optimizer it only has to finish before its buffers are overwritten by this frame's attribute backward
+        if self.optimizer and self._grads is not None:
+            self._apply_optimizer()
+        with torch.no_grad():
+            xyz, rot, opa, scl, _ = attr.forward_raw(scal, self.params, with_shs=False)
+        leaves = [x.requires_grad_(True) for x in (xyz, rot, opa, scl)]
+        feats = [self.params[i].detach().requires_grad_(True) for i in self.feature_idx]
+        means2D = torch.empty_like(xyz, requires_grad=True)
+        dir3D = torch.zeros_like(xyz, requires_grad=True)
+        e = torch.Tensor([])
+        st = self._settings(cam, bg, near, far)
+        color, radii, depth, flow, acc, idx = rasterize_gaussians(leaves[0], means2D, dir3D, SplitSH(*feats), e, leaves[2], leaves[3], leaves[1], e, st)
+        out = {"render": color, "depth": depth, "opticalflow": flow, "acc": acc, "radii": radii, "dominent_idxs": idx,
+               "viewspace_points": means2D, "viewspace_l1points": dir3D, "visibility_filter": radii > 0}
+        outs, gouts = upstream(out)
+        torch.autograd.backward(outs, gouts)
+        gin = [x.grad for x in leaves]                    # dL/d(means3D, rotations, opacities, scales)
+        fgrads = [f.grad for f in feats]
+        # ---- attribute backward + exchange: side stream, overlapping the next frame's rasterization
+        if self.side is not None:
+            self.side.wait_stream(main)
+            for g in gin + fgrads:
+                g.record_stream(self.side)
+            ctx = torch.cuda.stream(self.side)
+        else:
+            ctx = torch.cuda.stream(main)
+        with ctx:
+            if self.exchange is not None:
+                self.exchange.wait()                       # previous frame's collectives own the persistent buffers until here
+            gout = attr.backward_raw(scal, self.params, (gin[0], gin[1], gin[2], gin[3], None), with_shs=False, out=self.pgrad)
+            grads = [fgrads[self.feature_idx.index(i)] if i in self.feature_idx else gout[i] for i in range(len(self.params))]
+            self._grads = grads
+            if self.exchange is not None:
+                self.exchange.launch(grads)
+        self.last = {"radii": radii}
+        return out
+
+    def _apply_optimizer(self):
+        self.finish_exchange()
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        if self.mode == "sharded":
+            self.opt._grads = self._grads
+            self.opt.step()
+        else:
+            from .optim import radam_step_raw
+            self.steps += 1
+            items = [(p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), lr, self.steps)
+                     for p, g, mm, vv, lr in zip(self.params, self._grads, self.m, self.v, self.lrs)]
+            radam_step_raw(items, (0.9, 0.999), 1e-8, self.device)
+            torch.autograd.graph.increment_version(self.params)
+        self._grads = None
+
+    def flush(self):
+        """Finish whatever is pending (exchange, optimizer step of the last frame) on the current stream."""
+        if self.optimizer and self._grads is not None:
+            self._apply_optimizer()
+        else:
+            self.finish_exchange()
+            if self.side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def grads(self):
+        """The 15 (summed) parameter gradients of the last frame, valid after flush() when no optimizer consumed them."""
+        return dict(zip(self.names, self._grads)) if self._grads is not None else None

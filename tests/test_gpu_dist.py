@@ -1,0 +1,153 @@
+"""GPU tests of the multi-rank training path (run with `-m gpu` on an MI355X; a 1-GPU box is enough: the two ranks share the
+device and talk over gloo -- the collectives are the same calls that run over RCCL on a multi-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixed_upstream(H, W, seed=5):
+    w = torch.rand(3, H, W, generator=torch.Generator().manual_seed(seed)).cuda()
+    return lambda out: ([out["render"]], [w])
+
+
+def test_frame_trainer_matches_the_autograd_path(hip_lib):
+    """FrameTrainer (manual attribute forward / rasterizer autograd / attribute backward into persistent buffers, side stream)
+    produces the gradients of render() + autograd on the fused model."""
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.render import render
+    from ex4dgs_amd.trainer import FrameTrainer
+    model, cam, bg = make_scene("cfg3", P=20000, device="cuda", fused=True)
+    H, W = cam.image_height, cam.image_width
+    up = _fixed_upstream(H, W)
+    tr = FrameTrainer(model, exchange="none")
+    for t in (0, 137, 299):
+        out = tr.step(cam, bg, t, up)
+        tr.flush()
+        got = {k: v.clone() for k, v in tr.grads().items()}
+        for p in model.parameters():
+            p.requires_grad_(True); p.grad = None
+        ref_out = render(cam, model, None, bg, timestamp=t, near=4.0, far=300.0)
+        assert torch.equal(ref_out["render"], out["render"])
+        (ref_out["render"] * up(ref_out)[1][0]).sum().backward()
+        for name in model.PARAM_NAMES:
+            g, r = got[name], getattr(model, name).grad
+            tol = 2e-5 * float(r.abs().max()) + 1e-12          # float atomics: equal to rounding
+            assert float((g - r).abs().max()) <= tol, (name, t, float((g - r).abs().max()), tol)
+        for p in model.parameters():
+            p.requires_grad_(False); p.grad = None
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from ex4dgs_amd import _C, dist as xd
+from ex4dgs_amd.scene import make_scene
+from ex4dgs_amd.trainer import FrameTrainer
+from ex4dgs_amd.optim import radam_step_raw
+from ex4dgs_amd.attributes import PARAM_ORDER
+
+os.environ["LOCAL_RANK"] = "0"                       # both ranks on the box's one GPU
+rank, world, local = xd.init_from_env(backend="gloo")
+torch.cuda.set_device(0); _C.load()
+model, cam, bg = make_scene("cfg3", P=20000, device="cuda", fused=True)
+H, W = cam.image_height, cam.image_width
+w = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).cuda()
+up = lambda out: ([out["render"]], [w])
+stamps = [0, 100, 200, 299, 41, 88]
+
+# (1) all-reduce of the 15 model-parameter gradients: every rank ends up with the sum over the ranks' frames
+tr = FrameTrainer(model, exchange="allreduce")
+tr.step(cam, bg, stamps[rank], up); tr.flush()
+summed = [g.clone() for g in tr.grads().values()]
+solo = FrameTrainer(model, exchange="none")
+acc = None
+for r in range(world):
+    solo.step(cam, bg, stamps[r], up); solo.flush()
+    g = [x.clone() for x in solo.grads().values()]
+    acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+for name, a, b in zip(PARAM_ORDER, summed, acc):
+    tol = 2e-5 * float(b.abs().max()) + 1e-12
+    assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
+assert tr.exchange.bytes_on_wire() == 4 * sum(p.numel() for p in model.parameters())   # dense: every parameter gradient travels
+
+# (2) sharded optimizer == replicated optimizer, bit for bit, over K steps driven by real rasterizer gradients
+lrs = [1e-3 * (1 + i) for i in range(15)]
+A = [p.clone() for p in model.parameters()]          # replicated dense update of the summed gradient
+mA = [torch.zeros_like(p) for p in A]; vA = [torch.zeros_like(p) for p in A]
+B = [p.clone() for p in model.parameters()]          # sharded: reduce-scatter -> update of the own range -> all-gather
+sh = xd.ShardedRAdam(B, lrs, small_bytes=1 << 14)      # at 20 k Gaussians most tensors are under the default 1 MB packing threshold
+for k in range(1, 5):
+    solo.step(cam, bg, stamps[(2 * k + rank) % len(stamps)], up); solo.flush()
+    local_g = [g.clone() for g in solo.grads().values()]
+    dense_g = [g.clone() for g in local_g]
+    for g in dense_g:
+        torch.distributed.all_reduce(g)
+    radam_step_raw([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, k) for p, g, m, v, lr in zip(A, dense_g, mA, vA, lrs)],
+                   (0.9, 0.999), 1e-8, torch.device("cuda", 0))
+    sh.step(local_g)
+    torch.cuda.synchronize()
+    for name, a, b in zip(PARAM_ORDER, A, B):
+        assert torch.equal(a, b), (name, k, float((a - b).abs().max()))
+assert sh.state_bytes() < 0.6 * 8 * sum(p.numel() for p in A)
+
+# (3) the trainer's own sharded mode runs end to end and keeps the ranks' parameters identical
+m2, _, _ = make_scene("cfg3", P=20000, device="cuda", fused=True)
+tr2 = FrameTrainer(m2, exchange="sharded", lrs={n: 1e-6 for n in PARAM_ORDER})    # unrectified first RAdam steps move by lr * gradient
+for k in range(3):
+    tr2.step(cam, bg, stamps[(2 * k + rank) % len(stamps)], up)
+tr2.flush(); torch.cuda.synchronize()
+for name, p in zip(PARAM_ORDER, m2.parameters()):
+    q = p.clone()
+    torch.distributed.broadcast(q, src=0)
+    assert torch.equal(p, q), (name, float((p - q).abs().max()), int((p != q).sum()), p.numel(), tr2.exchange.small[list(PARAM_ORDER).index(name)])
+    assert torch.isfinite(p).all()
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_two_ranks_exchange_and_sharded_optimizer(hip_lib, tmp_path):
+    script = tmp_path / "dist_worker.py"
+    script.write_text(_WORKER)
+    port = 30700 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), h.ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o[-3000:]
+
+
+@pytest.mark.parametrize("config", ["cfg3", "cfg4"])
+def test_bench_spawns_its_ranks_itself(hip_lib, config):
+    """`bench.py --gpus 2` without torchrun: the script starts both ranks (sharing the box's GPU over gloo), rank 0 prints ONE JSON
+    line whose n_gpus is what was asked for, the collective carries the 15 model-parameter gradients."""
+    cmd = [sys.executable, os.path.join(h.ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--config", config,
+           "--points", "20000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["ranks_seen"] == 2
+    assert d["multi_gpu"]["collective_tensors"] == 15
+    assert d["multi_gpu"]["exchange_bytes_per_rank"] > 0 and d["value"] > 0
+    assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2
+
+
+def test_bench_refuses_a_rank_count_it_cannot_start(hip_lib):
+    cmd = [sys.executable, os.path.join(h.ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--points", "2000", "--steps", "1", "--warmup", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
