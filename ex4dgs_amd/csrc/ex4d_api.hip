@@ -241,11 +241,29 @@ static int forward_impl(
     if (!img_buf) return fail(EX4D_ERR_ALLOC, "image buffer allocation failed");
     ImgState im = carve_img(img_buf, W, H, nullptr, nullptr);
 
+    // depth-sort keys: the bit patterns of the visible depths lie in (bits(min_depth), bits(max_depth)] when 0 <= min_depth < max_depth;
+    // taken relative to bits(min_depth) they need 26 bits for (4, 300], 27 for (0.01, 300] instead of 32 -> 3 radix passes, not 4
+    uint32_t key_base = 0, key_invisible = 0xFFFFFFFFu;
+    int key_bits = 32;
+    if (prm->min_depth >= 0.0f && prm->max_depth > prm->min_depth && prm->max_depth < 3.0e38f) {
+        uint32_t lo, hi;
+        memcpy(&lo, &prm->min_depth, 4); memcpy(&hi, &prm->max_depth, 4);
+        key_base = lo;
+        key_invisible = hi - lo + 1u;
+        key_bits = 1;
+        while (key_bits < 32 && (key_invisible >> key_bits) != 0u) key_bits++;
+    }
+    // the sort ping-pongs between the (a) and (b) pairs and has to end in (a) = depth_order: start in (b) for an odd pass count
+    const bool start_in_b = (ex4d_radix_passes((uint32_t)P, key_bits) & 1) != 0;
+    uint32_t *keys0 = start_in_b ? g.sort_keys_b : g.sort_keys_a, *vals0 = start_in_b ? g.sort_vals_b : g.depth_order;
+    uint32_t *keys1 = start_in_b ? g.sort_keys_a : g.sort_keys_b, *vals1 = start_in_b ? g.depth_order : g.sort_vals_b;
+
     g_prof.begin(0, stream);
     HIP_TRY(hipMemsetAsync(g.total, 0, 2 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                                     viewmatrix, projmatrix, campos, radii, g, g.total + 1, split, stream), prm, stream);
+                                     viewmatrix, projmatrix, campos, radii, g, g.total + 1, split,
+                                     keys0, vals0, key_base, key_invisible, stream), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
@@ -256,10 +274,9 @@ static int forward_impl(
     HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(g_readback.ev, stream));
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
-    bool in_a = true;
-    STAGE(ex4d_radix_sort_pairs(g.sort_keys_a, g.depth_order, g.sort_keys_b, g.sort_vals_b, (uint32_t)P, 32, g.sort_hist, &in_a, stream), prm, stream);
-    // 4 passes: the result is back in the (a) pair = depth_order.  (end_bit 32 / 8 = even number of passes)
-    if (!in_a) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
+    bool in_first = true;
+    STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream), prm, stream);
+    if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
     MARK(0, "depth_sort");
     // 3. instance offsets in depth order + total
     STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, stream), prm, stream);
@@ -280,7 +297,7 @@ static int forward_impl(
     BinState b = carve_binning(bin_buf, R, W, H, nullptr, nullptr);
 
     // 5. emit (tile, id) instances in depth order, 6. stable sort by tile, 7. ranges
-    const int passes = (tile_bits(T) + 7) / 8;
+    const int passes = ex4d_radix_passes(R, tile_bits(T));
     uint32_t *k0 = (passes % 2 == 0) ? b.tile_ids : b.keys_tmp;   // start so that the result lands in (tile_ids, point_list)
     uint32_t *v0 = (passes % 2 == 0) ? b.point_list : b.vals_tmp;
     uint32_t *k1 = (passes % 2 == 0) ? b.keys_tmp : b.tile_ids;

@@ -28,12 +28,12 @@ __device__ __forceinline__ int to_int_sat(float f)
 
 // ---------------------------------------------------------------- radix sort (8-bit digits, stable)
 // pass structure: histogram -> row scan -> scatter.  hist layout: [bin][block] followed by [bin] totals.
-template <int ITEMS>
+template <int ITEMS, int BINS>
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift,
     uint32_t mask, uint32_t nblocks, uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t h[RS_BINS];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[BINS];
+    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) h[b] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
 #pragma unroll 4
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) hist[(size_t)b * nblocks + blockIdx.x] = h[b];
 }
 
 // one block per bin: exclusive scan of that bin's per-block counts; bin total to hist[RS_BINS*nblocks + bin]
-__global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uint32_t *__restrict__ hist, uint32_t bins)
 {
     __shared__ uint32_t wave_sums[4];
     __shared__ uint32_t carry_s;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
         if (threadIdx.x == 255) carry_s = carry + woff + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) hist[(size_t)RS_BINS * nblocks + blockIdx.x] = carry_s;
+    if (threadIdx.x == 0) hist[(size_t)bins * nblocks + blockIdx.x] = carry_s;
 }
 
 // Scatter pass.  A block owns RS_CHUNK consecutive items; wave w owns the w-th quarter of them and walks it in
@@ -80,20 +80,20 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
 //  phase 2  one barrier: per digit, exclusive scan over the 4 waves + block-local digit starts + global bases;
 //  phase 3  items go to their block-local sorted slot in LDS, one barrier, then the block streams the staged
 //           chunk out: neighbouring threads write neighbouring addresses of the same digit run (coalesced).
-template <int ITEMS>
+template <int ITEMS, int BINS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t wave_cnt[4][RS_BINS];     // per-wave digit counts -> exclusive block-local offsets
-    __shared__ uint32_t local_start[RS_BINS];     // first block-local slot of each digit
-    __shared__ uint32_t global_base[RS_BINS];     // global position of this block's first item of each digit
+    __shared__ uint32_t wave_cnt[4][BINS];        // per-wave digit counts -> exclusive block-local offsets
+    __shared__ uint32_t local_start[BINS];        // first block-local slot of each digit
+    __shared__ uint32_t global_base[BINS];        // global position of this block's first item of each digit
     __shared__ uint32_t scan_tmp[8];
     __shared__ uint2 stage[RS_THREADS * ITEMS];             // (key, value) in block-local sorted order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
     const int nbins = 1 << nbits;
-    for (int i = lane; i < RS_BINS; i += 64) wave_cnt[wave][i] = 0;
+    for (int i = lane; i < BINS; i += 64) wave_cnt[wave][i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -144,28 +144,40 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     }
     __syncthreads();
     {
-        // thread d: exclusive scan over waves for digit d, then exclusive scan over digits of the block totals
-        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        if (tid < nbins) { c0 = wave_cnt[0][tid]; c1 = wave_cnt[1][tid]; c2 = wave_cnt[2][tid]; c3 = wave_cnt[3][tid]; }
-        const uint32_t tot = c0 + c1 + c2 + c3;
-        uint32_t x = tot;
+        // thread t owns the BPT consecutive digits t*BPT .. : exclusive scan over waves per digit, then exclusive scan over digits of
+        // the block totals (and of the global digit totals, which gives every digit's global start)
+        constexpr int BPT = BINS / RS_THREADS;
+        uint32_t c[BPT][4], tot[BPT], gtot[BPT];
+        uint32_t tsum = 0, gsum = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) scan_tmp[wave] = x;
-        // exclusive scan of the global digit totals gives the digit's global start
-        const uint32_t gtot = (tid < nbins) ? hist[(size_t)RS_BINS * nblocks + tid] : 0;
-        uint32_t gx = gtot;
+        for (int k = 0; k < BPT; k++) {
+            const int d = tid * BPT + k;
+            const bool live = d < nbins;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(gx, o, 64); if (lane >= o) gx += y; }
-        if (lane == 63) scan_tmp[4 + wave] = gx;
+            for (int w = 0; w < 4; w++) c[k][w] = live ? wave_cnt[w][d] : 0u;
+            tot[k] = c[k][0] + c[k][1] + c[k][2] + c[k][3];
+            gtot[k] = live ? hist[(size_t)BINS * nblocks + d] : 0u;
+            tsum += tot[k]; gsum += gtot[k];
+        }
+        uint32_t x = tsum, gx = gsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64), gy = __shfl_up(gx, o, 64);
+            if (lane >= o) { x += y; gx += gy; }
+        }
+        if (lane == 63) { scan_tmp[wave] = x; scan_tmp[4 + wave] = gx; }
         __syncthreads();
-        uint32_t woff = 0, gwoff = 0;
-        for (int w = 0; w < wave; w++) { woff += scan_tmp[w]; gwoff += scan_tmp[4 + w]; }
-        if (tid < nbins) {
-            const uint32_t ls = woff + x - tot;
-            local_start[tid] = ls;
-            global_base[tid] = gwoff + gx - gtot + hist[(size_t)tid * nblocks + blockIdx.x];
-            wave_cnt[0][tid] = ls; wave_cnt[1][tid] = ls + c0; wave_cnt[2][tid] = ls + c0 + c1; wave_cnt[3][tid] = ls + c0 + c1 + c2;
+        uint32_t ls = x - tsum, gb = gx - gsum;
+        for (int w = 0; w < wave; w++) { ls += scan_tmp[w]; gb += scan_tmp[4 + w]; }
+#pragma unroll
+        for (int k = 0; k < BPT; k++) {
+            const int d = tid * BPT + k;
+            if (d < nbins) {
+                local_start[d] = ls;
+                global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x];
+                wave_cnt[0][d] = ls; wave_cnt[1][d] = ls + c[k][0]; wave_cnt[2][d] = ls + c[k][0] + c[k][1]; wave_cnt[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
+            }
+            ls += tot[k]; gb += gtot[k];
         }
     }
     __syncthreads();
@@ -324,11 +336,15 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint
 
 }  // namespace
 
-// small inputs (the per-Gaussian depth sort) use 1024-item chunks so that every CU gets several workgroups;
-// large ones (the per-instance tile sort) 4096-item chunks
-static inline int rs_items_for(uint32_t n) { return n <= (2u << 20) ? 4 : RS_ITEMS; }
+// small inputs (the per-Gaussian depth sort) use 1024-item chunks so that every CU gets several workgroups, and 9-bit digits
+// (512 bins): its passes are launch / latency bound, so one pass less is worth more than the two extra ballots per item;
+// large ones (the per-instance tile sort) 4096-item chunks and <= 8-bit digits
+#define RS_SMALL_ITEMS 8
+static inline int rs_items_for(uint32_t n) { return n <= (2u << 20) ? RS_SMALL_ITEMS : RS_ITEMS; }
 static inline uint32_t rs_blocks_for(uint32_t n) { const uint32_t c = RS_THREADS * rs_items_for(n); return (n + c - 1) / c; }
-size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)RS_BINS * rs_blocks_for(n) + RS_BINS; }
+static inline int rs_max_bits_for(uint32_t n) { return rs_items_for(n) == RS_SMALL_ITEMS ? 9 : 8; }
+size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)512 * rs_blocks_for(n) + 512; }
+int ex4d_radix_passes(uint32_t n, int end_bit) { const int mb = rs_max_bits_for(n); return (end_bit + mb - 1) / mb; }
 
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
     uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream)
@@ -336,18 +352,22 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
     *result_in_a = true;
     if (n == 0) return hipSuccess;
     const uint32_t nb = rs_blocks_for(n);
-    const bool small = rs_items_for(n) == 4;
+    const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
     // balanced digits (13 bits -> 7 + 6, not 8 + 5): a pass with fewer bins writes longer runs per digit and workgroup
-    const int npass = (end_bit + 7) / 8;
+    const int npass = ex4d_radix_passes(n, end_bit);
     for (int pass = 0, shift = 0; pass < npass; pass++) {
         const int nbits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);
         const uint32_t mask = (1u << nbits) - 1u;
-        if (small) hipLaunchKernelGGL(rs_histogram_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
-        else hipLaunchKernelGGL(rs_histogram_kernel<RS_ITEMS>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
-        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_BINS), dim3(256), 0, stream, nb, hist);
-        if (small) hipLaunchKernelGGL(rs_scatter_kernel<4>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
-        else hipLaunchKernelGGL(rs_scatter_kernel<RS_ITEMS>, dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+        if (small) {
+            hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+        } else {
+            hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+        }
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
         *result_in_a = !*result_in_a;

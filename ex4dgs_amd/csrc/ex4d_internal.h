@@ -69,7 +69,8 @@ struct ShSplitGrad { float *dc[2]; float *rest[2]; int n_static; };
 hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
-    int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split, hipStream_t stream);
+    int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
+    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream);
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);
@@ -85,6 +86,7 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
     uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream);
 size_t ex4d_radix_hist_words(uint32_t n);
+int ex4d_radix_passes(uint32_t n, int end_bit);      // number of passes ex4d_radix_sort_pairs will run (decides where the result lands)
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
     uint32_t *block_sums, int T, uint2 *ranges, hipStream_t stream);

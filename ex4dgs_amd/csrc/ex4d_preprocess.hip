@@ -160,6 +160,7 @@ __device__ __forceinline__ void wave_store_rows(float *__restrict__ dst_wave, co
 // (row stride 52 floats: conflict-free ds_read/write_b128 for 8-lane groups) and each lane then reads its row.
 #define SH_ROW 52
 #define SH_LDS_FLOATS_PER_WAVE (64 * SH_ROW)
+#define SH_SPLIT_DC_OFFSET (64 * 45)      // split layout: dc rows behind the 64 rest rows (see wave_load_sh_split)
 
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -182,6 +183,60 @@ __device__ __forceinline__ void wave_load_sh(const float *__restrict__ shs_wave,
     wave_sync_lds();
 }
 
+// The same copy in two halves, so that the global loads are IN FLIGHT while the projection / covariance arithmetic runs (a wave of
+// the forward kernel used to wait out three dependent memory round trips: means -> scale/rotation -> SH; now one):
+// issue = the 12 coalesced 16-byte loads into registers, commit = their transposition into the padded LDS slice.
+struct ShPrefetch { float4 v[13]; };
+__device__ __forceinline__ void wave_issue_sh(const float *__restrict__ shs_wave, ShPrefetch &pf, int nrows, int nvec, int lane)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane;
+        const int g = q / 12, v = q - 12 * g;
+        pf.v[it] = (g < nrows && v < nvec) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void wave_commit_sh(float *lds, const ShPrefetch &pf, int lane)
+{
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane;
+        const int g = q / 12, v = q - 12 * g;
+        *reinterpret_cast<float4 *>(lds + g * SH_ROW + 4 * v) = pf.v[it];
+    }
+    wave_sync_lds();
+}
+// split layout: the wave's rows of ONE (dc, rest) tensor pair as two linear 16-byte-aligned spans (rest: 64 x 45 floats = 720 float4,
+// dc: 64 x 3 floats = 48 float4); returns false (nothing issued) for the one wave that straddles the static/dynamic boundary or for
+// misaligned tensors -- those take wave_load_sh_split later
+__device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_first, int nrows, ShPrefetch &pf, int lane)
+{
+    const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
+    if (nrows <= 0 || !(all_dynamic || all_static)) return false;
+    const int part = all_dynamic ? 1 : 0;
+    const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
+    const float *rest = sp.rest[part] + r0 * 45, *dc = sp.dc[part] + r0 * 3;
+    if (((((uintptr_t)rest) | ((uintptr_t)dc)) & 15) != 0 || nrows != 64) return false;
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane;
+        pf.v[it] = q < 720 ? reinterpret_cast<const float4 *>(rest)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    pf.v[12] = lane < 48 ? reinterpret_cast<const float4 *>(dc)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return true;
+}
+__device__ __forceinline__ void wave_commit_sh_split(float *lds, const ShPrefetch &pf, int lane)
+{
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane;
+        if (q < 720) reinterpret_cast<float4 *>(lds)[q] = pf.v[it];
+    }
+    if (lane < 48) reinterpret_cast<float4 *>(lds + SH_SPLIT_DC_OFFSET)[lane] = pf.v[12];
+    wave_sync_lds();
+}
+
 // rows of the first `nrows` Gaussians are stored (all 12 float4 each)
 __device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, const float *lds, int nrows, int lane)
 {
@@ -201,7 +256,6 @@ __device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, cons
 // arithmetic, 16-byte accesses when the span is aligned.  The LDS slice keeps that linear layout (rest rows at stride 45,
 // dc rows at stride 3 behind them); a lane reads / writes its row with scalar LDS accesses at immediate offsets
 // (stride 45 is odd: conflict-free).  Only the single wave that straddles the static/dynamic boundary goes element by element.
-#define SH_SPLIT_DC_OFFSET (64 * 45)
 
 __device__ __forceinline__ void wave_copy_linear(float *__restrict__ dst, const float *__restrict__ src, int nfloats, int lane)
 {
@@ -271,7 +325,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int prefiltered, uint32_t *__restrict__ prefilter_violation,
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
-    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t *__restrict__ total_instances, const ShSplit sp)
+    uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
+    uint32_t *__restrict__ total_instances, const ShSplit sp)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -282,9 +337,34 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
 
+    // ---- every global load of the kernel is issued here, before any arithmetic depends on one of them: the wave's SH block (the
+    // bulk: 12 KB, coalesced), the Gaussian's own 12 + 32 + 12 bytes.  Culled Gaussians (~20 %) cost their bytes but no wave waits
+    // for a second or third memory round trip any more.
+    const int ncoef = (D + 1) * (D + 1);
+    const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
+    const bool staged = (shs != nullptr || split) && (M == 16);
+    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
+    ShPrefetch pf;
+    bool prefetched = false;
+    if (staged) {
+        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane);
+        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, (ncoef * 3 + 3) / 4, lane); prefetched = true; }
+    }
+    float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f, in_op = 0.f, in_d0 = 0.f, in_d1 = 0.f, in_d2 = 0.f;
+    if (in_range) {
+        if (!cov3D_precomp) {
+            in_q = reinterpret_cast<const float4 *>(rotations)[idx];
+            in_s0 = scales[3 * (size_t)idx]; in_s1 = scales[3 * (size_t)idx + 1]; in_s2 = scales[3 * (size_t)idx + 2];
+        }
+        in_op = opacities[idx];
+        if (dir3D) { in_d0 = dir3D[3 * (size_t)idx]; in_d1 = dir3D[3 * (size_t)idx + 1]; in_d2 = dir3D[3 * (size_t)idx + 2]; }
+    }
+
     int out_radius = 0;
     uint32_t out_tiles = 0;
-    uint32_t depth_key = 0xFFFFFFFFu;   // invisible Gaussians sort behind every visible one
+    uint32_t depth_key = depth_key_invisible;   // invisible Gaussians sort behind every visible one
     uint2 rect = make_uint2(0u, 0u);
     bool visible = false;
     float3 p = make_float3(0.f, 0.f, 0.f), conic = make_float3(0.f, 0.f, 0.f);
@@ -302,11 +382,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
         } else {
             // Sigma = (S R)^T (S R), CR/forward.cu:128-162; raw (un-normalised) quaternion
-            const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+            const float4 q = in_q;
             Mat3 S = from_columns(1.0f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f);
-            S.m[0][0] = scale_modifier * scales[3 * (size_t)idx];
-            S.m[1][1] = scale_modifier * scales[3 * (size_t)idx + 1];
-            S.m[2][2] = scale_modifier * scales[3 * (size_t)idx + 2];
+            S.m[0][0] = scale_modifier * in_s0;
+            S.m[1][1] = scale_modifier * in_s1;
+            S.m[2][2] = scale_modifier * in_s2;
             Mat3 R = rotation_from_quat(q.x, q.y, q.z, q.w);
             Mat3 Mx = mul(S, R);
             Mat3 Sigma = mul(transpose(Mx), Mx);
@@ -345,23 +425,20 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         depth = p_view.z;
         out_radius = ri;
         out_tiles = area;
-        // depth > min_depth >= 0 => unsigned order of the bit pattern == numeric order: the same bits the
-        // reference puts in the low key word (CR/rasterizer_impl.cu:106)
-        depth_key = __float_as_uint(p_view.z);
+        // depth > min_depth >= 0 => unsigned order of the bit pattern == numeric order: the same bits the reference puts in the low
+        // key word (CR/rasterizer_impl.cu:106).  Visible depths lie in (min_depth, max_depth], so their bit patterns lie in a range the
+        // host knows: keys are taken relative to its lower end (same order, fewer significant bits -> one radix pass less)
+        depth_key = __float_as_uint(p_view.z) - depth_key_base;
     } while (0);
 
     // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
-    const int ncoef = (D + 1) * (D + 1);
     float coefv[16][3];
-    const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
-    const bool staged = (shs != nullptr || split) && (M == 16);
     if (staged) {
         float *lds = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
-        const uint64_t need = __ballot(visible);
-        const int wave_first = blockIdx.x * 256 + wave * 64;
         float tmp[48];
         if (split) {
-            wave_load_sh_split(sp, wave_first, (P - wave_first) < 64 ? (P - wave_first) : 64, lds, lane);
+            if (prefetched) wave_commit_sh_split(lds, pf, lane);
+            else wave_load_sh_split(sp, wave_first, wave_rows, lds, lane);
 #pragma unroll
             for (int f = 0; f < 48; f++) tmp[f] = 0.f;
             if (visible) {
@@ -371,7 +448,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 for (int f = 3; f < 48; f++) if (f < ncoef * 3) tmp[f] = lds[lane * 45 + (f - 3)];
             }
         } else {
-            wave_load_sh(shs + (size_t)wave_first * 48, lds, need, (ncoef * 3 + 3) / 4, lane);
+            wave_commit_sh(lds, pf, lane);
             const float4 *row = reinterpret_cast<const float4 *>(lds + lane * SH_ROW);
             const int nvec = (ncoef * 3 + 3) / 4;
 #pragma unroll
@@ -436,7 +513,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         // instead of once per (Gaussian, tile, quadrant): tau = ln(255 w) + 1 % slack is the largest value of the quadratic
         // form q(d) that still reaches alpha >= 1/255; -inf = never contributes (w < 1/255), +inf = never cull (conic
         // not provably positive definite); k1, k2 = minimisers of q along a vertical / horizontal box edge
-        const float w_op = opacities[idx] * coef;
+        const float w_op = in_op * coef;
         float tau;
         if (w_op < (1.0f / 255.0f)) tau = -__builtin_inff();
         else if (!(conic.x > 0.f && conic.z > 0.f && conic.x * conic.z - conic.y * conic.y > 0.f)) tau = __builtin_inff();
@@ -445,8 +522,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
         rec[1] = make_float4(conic.z, tau, -conic.y / conic.z, -conic.y / conic.x);
         rec[2] = make_float4(depth, res[0], res[1], res[2]);
-        rec[3] = dir3D ? make_float4(dir3D[3 * (size_t)idx], dir3D[3 * (size_t)idx + 1], dir3D[3 * (size_t)idx + 2], w_op)
-                       : make_float4(0.f, 0.f, 0.f, w_op);
+        rec[3] = make_float4(in_d0, in_d1, in_d2, w_op);
     }
     if (in_range) {
         radii[idx] = out_radius;
@@ -509,14 +585,43 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_range = idx < P;
-    const bool visible = in_range && (radii[idx] > 0);
     const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
     const bool staged = (shs != nullptr || split) && (M == 16);
     float *lds_row_base = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
     const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
+    // ---- all global loads are issued before anything waits for one of them (see preprocess_fwd_kernel): the wave's SH block, the
+    // Gaussian's accumulator row, mean, covariance, scale / rotation, clamp bits -- also for the ~20 % culled Gaussians, whose rows
+    // are then simply not used
+    ShPrefetch pf;
+    bool prefetched = false;
     if (staged) {
-        if (split) wave_load_sh_split(sp, wave_first, (P - wave_first) < 64 ? (P - wave_first) : 64, lds_row_base, lane);
-        else wave_load_sh(shs + (size_t)wave_first * 48, lds_row_base, __ballot(visible), ((D + 1) * (D + 1) * 3 + 3) / 4, lane);
+        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane);
+        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, ((D + 1) * (D + 1) * 3 + 3) / 4, lane); prefetched = true; }
+    }
+    int in_radius = 0;
+    float4 in_r0 = make_float4(0.f, 0.f, 0.f, 0.f), in_r1 = in_r0, in_r2 = in_r0, in_r3 = in_r0, in_q = in_r0;
+    float in_mean[3] = { 0.f, 0.f, 0.f }, in_cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, in_s[3] = { 0.f, 0.f, 0.f };
+    uint8_t in_clamped = 0;
+    if (in_range) {
+        in_radius = radii[idx];
+        const float4 *row = reinterpret_cast<const float4 *>(acc16 + 16 * (size_t)idx);
+        in_r0 = row[0]; in_r1 = row[1]; in_r2 = row[2]; in_r3 = row[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) in_mean[i] = means3D[3 * (size_t)idx + i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) in_cov[i] = cov3Ds[6 * (size_t)idx + i];
+        if (scales) {
+            in_q = reinterpret_cast<const float4 *>(rotations)[idx];
+#pragma unroll
+            for (int i = 0; i < 3; i++) in_s[i] = scales[3 * (size_t)idx + i];
+        }
+        if (shs || split) in_clamped = clamped[idx];
+    }
+    const bool visible = in_range && (in_radius > 0);
+    if (staged) {
+        if (split) { if (prefetched) wave_commit_sh_split(lds_row_base, pf, lane); else wave_load_sh_split(sp, wave_first, wave_rows, lds_row_base, lane); }
+        else wave_commit_sh(lds_row_base, pf, lane);
     }
     float g_mean2D[3] = { 0, 0, 0 }, g_color[3] = { 0, 0, 0 }, g_dir[3] = { 0, 0, 0 }, g_opacity = 0;
     float g_mean3D[3] = { 0, 0, 0 }, g_cov[6] = { 0, 0, 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_rot[4] = { 0, 0, 0, 0 };
@@ -528,8 +633,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         float vm[16], pm[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
-        const float4 *row = reinterpret_cast<const float4 *>(acc16 + 16 * (size_t)idx);
-        const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        const float4 r0 = in_r0, r1 = in_r1, r2 = in_r2, r3 = in_r3;
         // factors the compositing backward defers to here (ex4d_composite.hip): ln2 W/2, ln2 H/2 (CR/backward.cu:548-549,
         // :669-670) and -1/2 (:673-675)
         if (acc_layout == 0) {
@@ -545,10 +649,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         g_color[0] = r1.w; g_color[1] = r2.x; g_color[2] = r2.y;
         g_dir[0] = r2.z; g_dir[1] = r2.w; g_dir[2] = r3.x;
 
-        const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+        const float3 mean = make_float3(in_mean[0], in_mean[1], in_mean[2]);
         float cov3D[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov3D[i] = cov3Ds[6 * (size_t)idx + i];
+        for (int i = 0; i < 6; i++) cov3D[i] = in_cov[i];
 
         // ---- computeCov2DCUDA, CR/backward.cu:144-300 (the coef-gradient block :201-218 affects no output)
         Cov2DCtx c;
@@ -591,7 +695,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
             // split layout: rest rows at stride 45 (coefficient k >= 1 at 3 (k - 1)); only k >= 1 is read below
             const float *sh = split ? (lds_row_base + lane * 45 - 3) : (staged ? (lds_row_base + lane * SH_ROW) : (shs + (size_t)idx * M * 3));
-            const uint8_t cl = clamped[idx];
+            const uint8_t cl = in_clamped;
             float dRGB[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) dRGB[ch] = g_color[ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
@@ -675,10 +779,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         }
         if (scales) {
             // cov3D backward, CR/backward.cu:304-367 (gradient w.r.t. the raw quaternion)
-            const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+            const float4 q = in_q;
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             Mat3 R = rotation_from_quat(r, x, y, z);
-            const float s[3] = { scale_modifier * scales[3 * (size_t)idx], scale_modifier * scales[3 * (size_t)idx + 1], scale_modifier * scales[3 * (size_t)idx + 2] };
+            const float s[3] = { scale_modifier * in_s[0], scale_modifier * in_s[1], scale_modifier * in_s[2] };
             Mat3 S = from_columns(1.0f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f);
             S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
             Mat3 Mx = mul(S, R);
@@ -765,7 +869,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
-    int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split, hipStream_t stream)
+    int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
+    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream)
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
@@ -774,7 +879,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, g.sort_keys_a, g.depth_order, g.block_totals, split);
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split);
     return hipGetLastError();
 }
 

@@ -528,3 +528,28 @@ def test_frame_sharding_and_gradient_allreduce_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o
+
+
+def test_integer_decisions_are_insensitive_to_fma_contraction():
+    """The parity oracle is a NO-FMA evaluation (-ffp-contract=off); the reference binary is built by nvcc with contraction on
+    (DGR/setup.py:21-29).  The same oracle source with gcc's contraction (-ffp-contract=fast -mfma) must take the same cull decisions
+    and (all but a few in 1e5 of) the same radii / tile counts -- the error bar on "bit-exact against the reference binary".
+    Full corpus: tools/fma_sensitivity.py -> profiles/r02_fma_sensitivity.json (0 cull flips, 6 radii, 1 tile count in 1.05 M visible)."""
+    import runpy
+    mod = runpy.run_path(os.path.join(h.ROOT, "tools", "fma_sensitivity.py"), run_name="fma_sensitivity")
+    from oracle import oracle
+    plain, fma = oracle.lib(), mod["load_fma"]()
+    tot = dict(vis=0, cull=0, radii=0, tiles=0, same_list=0, cases=0)
+    try:
+        for name, cfg, P, t, deg in list(mod["corpus"](12, 0))[:12] + [("cfg2@20k", "cfg2", 20000, 0, 3), ("cfg3@20k", "cfg3", 20000, 137, 3)]:
+            ins, st = h.scene_inputs(cfg, P=P, t=t, sh_degree=deg)
+            a, b = mod["run"](plain, ins, st), mod["run"](fma, ins, st)
+            va, vb = a["radii"] > 0, b["radii"] > 0
+            tot["vis"] += int(va.sum()); tot["cull"] += int((va != vb).sum()); tot["radii"] += int((a["radii"] != b["radii"]).sum())
+            tot["tiles"] += int((a["tiles_touched"] != b["tiles_touched"]).sum()); tot["cases"] += 1
+            tot["same_list"] += int(a["num_rendered"] == b["num_rendered"] and np.array_equal(a["point_list"], b["point_list"]))
+    finally:
+        oracle._LIB = plain
+    assert tot["cull"] == 0, tot
+    assert tot["radii"] <= 1e-4 * tot["vis"] + 1 and tot["tiles"] <= 1e-4 * tot["vis"] + 1, tot
+    assert tot["same_list"] >= tot["cases"] - 1, tot
