@@ -237,6 +237,33 @@ __device__ __forceinline__ void wave_commit_sh_split(float *lds, const ShPrefetc
     wave_sync_lds();
 }
 
+// The forward kernel transposes the prefetched block through HALF a slice, rows 32h .. 32h+31 at a time (commit half, the 32
+// lanes of that half read their rows, next half): 6.5 KB of LDS per wave instead of 13 -> twice the workgroups per CU.
+#define SH_HALF_FLOATS (32 * SH_ROW)              // >= 32 * 45 + 32 * 3 (split layout: rest rows, then dc rows)
+#define SH_HALF_DC_OFFSET (32 * 45)
+__device__ __forceinline__ void wave_commit_sh_half(float *lds, const ShPrefetch &pf, int lane, int h)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int it = 6 * h + i;                 // h is a compile-time constant at both call sites
+        const int q = it * 64 + lane;
+        const int g = q / 12 - 32 * h, v = q % 12;
+        *reinterpret_cast<float4 *>(lds + g * SH_ROW + 4 * v) = pf.v[it];
+    }
+    wave_sync_lds();
+}
+__device__ __forceinline__ void wave_commit_sh_split_half(float *lds, const ShPrefetch &pf, int lane, int h)
+{
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int q = it * 64 + lane - 360 * h;
+        if (q >= 0 && q < 360) reinterpret_cast<float4 *>(lds)[q] = pf.v[it];
+    }
+    const int d = lane - 24 * h;
+    if (d >= 0 && d < 24) reinterpret_cast<float4 *>(lds + SH_HALF_DC_OFFSET)[d] = pf.v[12];
+    wave_sync_lds();
+}
+
 // rows of the first `nrows` Gaussians are stored (all 12 float4 each)
 __device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, const float *lds, int nrows, int lane)
 {
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
     uint32_t *__restrict__ total_instances, const ShSplit sp)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_range = idx < P;
@@ -434,28 +461,46 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
     float coefv[16][3];
     if (staged) {
-        float *lds = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
+        float *lds = sh_lds + wave * SH_HALF_FLOATS;
         float tmp[48];
+#pragma unroll
+        for (int f = 0; f < 48; f++) tmp[f] = 0.f;
+        const int r = lane & 31;
         if (split) {
-            if (prefetched) wave_commit_sh_split(lds, pf, lane);
-            else wave_load_sh_split(sp, wave_first, wave_rows, lds, lane);
+            if (prefetched) {
 #pragma unroll
-            for (int f = 0; f < 48; f++) tmp[f] = 0.f;
-            if (visible) {
+                for (int h = 0; h < 2; h++) {
+                    wave_commit_sh_split_half(lds, pf, lane, h);
+                    if (visible && (lane >> 5) == h) {
 #pragma unroll
-                for (int f = 0; f < 3; f++) tmp[f] = lds[SH_SPLIT_DC_OFFSET + lane * 3 + f];
+                        for (int f = 0; f < 3; f++) tmp[f] = lds[SH_HALF_DC_OFFSET + r * 3 + f];
 #pragma unroll
-                for (int f = 3; f < 48; f++) if (f < ncoef * 3) tmp[f] = lds[lane * 45 + (f - 3)];
+                        for (int f = 3; f < 48; f++) if (f < ncoef * 3) tmp[f] = lds[r * 45 + (f - 3)];
+                    }
+                    wave_sync_lds();
+                }
+            } else if (visible) {
+                // the one wave that straddles the static / dynamic boundary (or misaligned tensors): rows straight from memory
+                const int part = idx >= sp.n_static;
+                const size_t row = (size_t)(idx - (part ? sp.n_static : 0));
+#pragma unroll
+                for (int f = 0; f < 3; f++) tmp[f] = sp.dc[part][row * 3 + f];
+#pragma unroll
+                for (int f = 3; f < 48; f++) if (f < ncoef * 3) tmp[f] = sp.rest[part][row * 45 + (f - 3)];
             }
         } else {
-            wave_commit_sh(lds, pf, lane);
-            const float4 *row = reinterpret_cast<const float4 *>(lds + lane * SH_ROW);
             const int nvec = (ncoef * 3 + 3) / 4;
 #pragma unroll
-            for (int v = 0; v < 12; v++) {
-                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (visible && v < nvec) t4 = row[v];
-                tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w;
+            for (int h = 0; h < 2; h++) {
+                wave_commit_sh_half(lds, pf, lane, h);
+                if (visible && (lane >> 5) == h) {
+                    const float4 *row = reinterpret_cast<const float4 *>(lds + r * SH_ROW);
+#pragma unroll
+                    for (int v = 0; v < 12; v++) {
+                        if (v < nvec) { const float4 t4 = row[v]; tmp[4 * v] = t4.x; tmp[4 * v + 1] = t4.y; tmp[4 * v + 2] = t4.z; tmp[4 * v + 3] = t4.w; }
+                    }
+                }
+                wave_sync_lds();
             }
         }
 #pragma unroll
