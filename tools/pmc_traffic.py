@@ -1,33 +1,92 @@
 #!/usr/bin/env python
-"""profiles/<tag>_pmc_FETCH_SIZE.txt + <tag>_pmc_WRITE_SIZE.txt (tools/pmc.sh, separate passes) -> profiles/r01_pmc_traffic.json.
+"""Per-kernel HBM traffic and roofline fractions from separate rocprofv3 --pmc passes (tools/prof_r02.sh):
+
+    pmc_traffic.py FETCH.txt WRITE.txt SQ_valu.txt kernel_stats.txt out.json [iter_FETCH iter_WRITE iter_stats knn_FETCH knn_WRITE knn_stats]
+
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B
-(MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is in KB."""
-import json, re, sys
-fetch, write, out = sys.argv[1], sys.argv[2], sys.argv[3]
+(MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is in KB.  achieved = bytes / average launch duration of the
+kernel-trace pass; frac = achieved / 8 TB/s.  valu_busy_frac = 4 * SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs * duration * 2.4 GHz)."""
+import json
+import re
+import sys
 
 
-def parse(path):
+def parse_table(path):
+    lines = open(path).read().splitlines()
+    hdr = lines[0].split()
+    cols = hdr[2:]
     d = {}
-    for line in open(path).read().splitlines()[1:]:
-        m = re.match(r"^(.*?)\s+(\d+)\s+([0-9.e+]+)\s*$", line)
+    for line in lines[1:]:
+        m = re.match(r"^(.*?)\s+(\d+)((?:\s+[0-9.e+-]+)+)\s*$", line)
         if m:
-            name = m.group(1)
-            key = re.search(r"(\w+_kernel|\w+)(<[^>]*>)?\(", name)
-            d[(key.group(1) + (key.group(2) or "")) if key else name] = float(m.group(3))
+            vals = [float(x) for x in m.group(3).split()]
+            d[m.group(1).strip()] = dict(zip(cols, vals))
     return d
 
 
-f, w = parse(fetch), parse(write)
-alias = {"composite_bwd_kernel<4>": "composite_bwd", "composite_fwd_kernel<4>": "composite_fwd", "preprocess_fwd_kernel": "preprocess_fwd",
-         "preprocess_bwd_kernel": "preprocess_bwd", "duplicate_kernel": "duplicate", "rs_scatter_kernel<16>": "tile_sort_scatter_pass",
-         "rs_scatter_kernel<4>": "depth_sort_scatter_pass", "rs_histogram_kernel<16>": "tile_sort_histogram_pass",
-         "tile_ranges_kernel": "tile_ranges", "scan_tiles_local_kernel": "scan_tiles"}
-kernels = {}
-for k in sorted(set(f) | set(w)):
-    if k in alias:
-        fk, wk = f.get(k, 0.0), w.get(k, 0.0)
-        kernels[alias[k]] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes): {fetch}, {write}; bench.py cfg3 1.0M Gaussians",
-           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
-           "kernels": kernels}, open(out, "w"), indent=1)
-print(json.dumps(kernels, indent=1))
+def parse_stats(path):
+    d = {}
+    for line in open(path).read().splitlines()[2:]:
+        name, rest = line[:70].strip(), line[70:].split()
+        if len(rest) >= 3:
+            d[name] = float(rest[2])          # avg_us
+    return d
+
+
+ALIAS = [("composite_bwd_scan_kernel", "composite_bwd"), ("composite_bwd_kernel", "composite_bwd_per_pixel"), ("composite_fwd_kernel", "composite_fwd"),
+         ("preprocess_fwd_kernel", "preprocess_fwd"), ("preprocess_bwd_kernel", "preprocess_bwd"), ("duplicate_kernel", "duplicate"),
+         ("rs_scatter_kernel<16", "tile_sort_scatter_pass"), ("rs_scatter_kernel<8", "depth_sort_scatter_pass"),
+         ("rs_histogram_kernel<16", "tile_sort_histogram_pass"), ("rs_histogram_kernel<8", "depth_sort_histogram_pass"),
+         ("rs_scan_rows_kernel", "radix_row_scan"), ("tile_ranges_kernel", "tile_ranges"), ("scan_tiles_local_kernel", "scan_tiles"),
+         ("radam_kernel", "radam"), ("l1_ssim_fwd", "l1_ssim_forward"), ("l1_ssim_bwd", "l1_ssim_backward"),
+         ("l1_ssim_finish", "l1_ssim_finish"), ("attributes_fwd", "attributes_forward"), ("attributes_bwd", "attributes_backward"),
+         ("features_kernel", "attributes_sh_gather"), ("knn3_kernel", "knn3_search"), ("morton_kernel", "knn_morton"),
+         ("gather_kernel", "knn_gather"), ("boxes_kernel", "knn_boxes")]
+
+
+def alias(name):
+    for pat, a in ALIAS:
+        if pat in name:
+            return a
+    return None
+
+
+def collect(fetch, write, stats, sq=None):
+    f, w, st = parse_table(fetch), parse_table(write), parse_stats(stats)
+    s = parse_table(sq) if sq else {}
+    out = {}
+    for name in sorted(set(f) | set(w)):
+        a = alias(name)
+        if a is None or a in out:
+            continue
+        fk, wk = f.get(name, {}).get("FETCH_SIZE", 0.0), w.get(name, {}).get("WRITE_SIZE", 0.0)
+        us = next((v for k, v in st.items() if k[:50] == name[:50]), None)
+        row = {"kernel": name[:60], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+        if us:
+            row["avg_us"] = us
+            row["hbm_GBps"] = round(row["hbm_bytes_per_launch"] / us / 1e3, 1)
+            row["frac_of_8TBps"] = round(row["hbm_GBps"] / 8000.0, 3)
+        if name in s and us:
+            row["SQ_INSTS_VALU"] = s[name].get("SQ_INSTS_VALU")
+            row["valu_busy_frac"] = round(4 * s[name].get("SQ_ACTIVE_INST_VALU", 0.0) / (1024 * us * 1e-6 * 2.4e9), 3)
+        out[a] = row
+    return out
+
+
+def main():
+    a = sys.argv[1:]
+    kernels = collect(a[0], a[1], a[3], a[2])
+    if len(a) >= 8:
+        kernels.update({k: v for k, v in collect(a[5], a[6], a[7]).items() if k not in kernels})
+    if len(a) >= 11:
+        kernels.update({k: v for k, v in collect(a[8], a[9], a[10]).items() if k not in kernels})
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, tools/prof_r02.sh): bench.py cfg3 1.0M Gaussians; "
+                         "tools/dev/dev_iter_profile.py (fused training iteration at 1.0M); tools/dev/dev_knn_time.py",
+               "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
+               "kernels": kernels}, open(a[4], "w"), indent=1)
+    for k, v in kernels.items():
+        print(f"{k:28s} {v.get('avg_us', 0):9.2f} us  {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  {v.get('hbm_GBps', 0):8.1f} GB/s  frac {v.get('frac_of_8TBps', 0):.3f}  valu_busy {v.get('valu_busy_frac', '')}")
+
+
+if __name__ == "__main__":
+    main()
