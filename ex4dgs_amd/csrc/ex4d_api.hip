@@ -259,7 +259,7 @@ static int forward_impl(
     uint32_t *keys1 = start_in_b ? g.sort_keys_a : g.sort_keys_b, *vals1 = start_in_b ? g.depth_order : g.sort_vals_b;
 
     g_prof.begin(0, stream);
-    HIP_TRY(hipMemsetAsync(g.total, 0, 2 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(g.total, 0, 4 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, g, g.total + 1, split,
@@ -313,7 +313,7 @@ static int forward_impl(
     MARK(0, "tile_ranges");
     // 8. compositing
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
-                                    out_color, out_depth, out_acc, out_flow, out_idx, b.cull_masks, stream), prm, stream);
+                                    out_color, out_depth, out_acc, out_flow, out_idx, b.cull_masks, g.total, stream), prm, stream);
     MARK(0, "composite_fwd");
     return EX4D_OK;
 }

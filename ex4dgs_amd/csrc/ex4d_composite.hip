@@ -137,22 +137,19 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
+// FLOW = false: no Gaussian of the frame carries a non-zero dir3D (the training loop passes the all-zero gradient-trap tensor,
+// gaussian_renderer/__init__.py:66-70): the flow image is zero, its three accumulations per pair and the staging of dir3D are skipped
+template <int WPB, bool FLOW>
+__device__ __forceinline__ void composite_fwd_body(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks)
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
+    float4 (*s_q0)[64], float2 (*s_q1)[64], float4 (*s_q2)[64], float4 (*s_q3)[64], uint32_t (*s_id)[64], uint32_t (*s_orig)[64])
 {
-    __shared__ float4 s_q0[WPB][64];      // x, y, A, B
-    __shared__ float2 s_q1[WPB][64];      // C, w
-    __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
-    __shared__ float4 s_q3[WPB][64];      // dir xyz
-    __shared__ uint32_t s_id[WPB][64];
-    __shared__ uint32_t s_orig[WPB][64];
 
     int tile, quad;
     tile_of_block<WPB>(num_tiles, tile, quad);
@@ -195,7 +192,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
             s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
             s_q1[wave][slot] = make_float2(q1.x * kHalfLog2e, q3.w);
             s_q2[wave][slot] = r[2];
-            s_q3[wave][slot] = q3;
+            if (FLOW) s_q3[wave][slot] = q3;
             s_id[wave][slot] = id;
             s_orig[wave][slot] = (uint32_t)k;
         }
@@ -217,12 +214,11 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
             if (add == 0) continue;
             // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
             const float4 g2 = s_q2[wave][j];
-            const float4 g3 = s_q3[wave][j];
             const float wgt = select_f(add, alpha * T, 0.f);
             C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
             Dm += g2.x * wgt;
             acc += wgt;
-            F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt;
+            if (FLOW) { const float4 g3 = s_q3[wave][j]; F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
             const lanemask brighter = LANES(wgt > max_vis);
             best_j = select_i(brighter, j, best_j);
             max_vis = select_f(brighter, wgt, max_vis);
@@ -249,6 +245,32 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
         out_flow[p.pix_id] = Fx; out_flow[HW + p.pix_id] = Fy; out_flow[2 * HW + p.pix_id] = Fz;
         out_idx[p.pix_id] = best;
     }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
+    int W, int H, int gx, int num_tiles,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+    const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
+    const float *__restrict__ bg, float max_depth,
+    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+    float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
+    const uint32_t *__restrict__ frame_flags)
+{
+    __shared__ float4 s_q0[WPB][64];      // x, y, A, B
+    __shared__ float2 s_q1[WPB][64];      // C, w
+    __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
+    __shared__ float4 s_q3[WPB][64];      // dir xyz
+    __shared__ uint32_t s_id[WPB][64];
+    __shared__ uint32_t s_orig[WPB][64];
+    // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
+    if (frame_flags[2] != 0u)
+        composite_fwd_body<WPB, true>(W, H, gx, num_tiles, ranges, point_list, subpixel_offset, records, bg, max_depth, final_T, n_contrib,
+                                      out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, s_q0, s_q1, s_q2, s_q3, s_id, s_orig);
+    else
+        composite_fwd_body<WPB, false>(W, H, gx, num_tiles, ranges, point_list, subpixel_offset, records, bg, max_depth, final_T, n_contrib,
+                                       out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, s_q0, s_q1, s_q2, s_q3, s_id, s_orig);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -782,13 +804,14 @@ hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks, hipStream_t stream)
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks,
+    const uint32_t *frame_flags, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
     hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
         prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, cull_masks);
+        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, frame_flags);
     return hipGetLastError();
 }
 

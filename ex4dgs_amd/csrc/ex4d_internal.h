@@ -32,7 +32,7 @@ struct GeomState {
     uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
-    uint32_t *total;                                     // [0] unused, [1] prefilter violation flag
+    uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0
     uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
 };
 struct BinState {
@@ -96,7 +96,8 @@ hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, 
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks, hipStream_t stream);
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks,
+    const uint32_t *frame_flags, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,

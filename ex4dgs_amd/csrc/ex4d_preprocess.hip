@@ -569,6 +569,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         rec[2] = make_float4(depth, res[0], res[1], res[2]);
         rec[3] = make_float4(in_d0, in_d1, in_d2, w_op);
     }
+    // frame flag for the compositing forward: does any visible Gaussian carry a flow vector?  (plain store of the same value by every
+    // wave that sees one: no atomic, no contention; the training loop's dir3D is the all-zero gradient trap and never sets it)
+    if (__ballot(visible && (in_d0 != 0.f || in_d1 != 0.f || in_d2 != 0.f)) != 0ull) {
+        if (lane == 0) prefilter_violation[1] = 1u;
+    }
     if (in_range) {
         radii[idx] = out_radius;
         tiles_touched[idx] = out_tiles;
