@@ -544,7 +544,9 @@ __device__ __forceinline__ float row_scan_add_asm(float x)
 //   2  every lane accumulates the 13 Gaussian-centred partial sums of its 16 pixels in registers (15 VALU per step), the four
 //      pixel-slot lanes of a Gaussian are added in the epilogue                                            (default)
 //   4  = 2 plus the developer statistics of g_bwd_stats
-template <int MODE>
+// EXTRA = false: no pixel of the quadrant has an upstream depth or flow gradient (training on the image alone) -- the depth term of
+// dL_dalpha and four of the 13 sums drop out (compile-time, so the common all-gradients path carries no extra branches)
+template <int MODE, bool EXTRA>
 __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
                                           const float (&A1)[16], const float (&A2)[16], float *__restrict__ acc16)
 {
@@ -595,9 +597,13 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
         const float e = dcc * cgp;
         const float E = pc.z + row_scan_add_asm(e);
         // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha)
-        const float gdf = pa.w * flagf;
-        const float u = ((pb.x - dep) * gdf) * T;
-        float dLa = u * T + (cgp * T - (E - e) * inv);
+        float dLa = cgp * T - (E - e) * inv;
+        float gdf = 0.f;
+        if (EXTRA) {
+            gdf = pa.w * flagf;
+            const float u = ((pb.x - dep) * gdf) * T;
+            dLa += u * T;
+        }
         dLa += pb.y * inv;
         float s6 = G_m * dLa;
         const float sG = w * s6;                                        // dL_dG G = (w dL_dalpha) G
@@ -612,9 +618,9 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
             D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], sG, D2, 0, 0, 0);
             D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], s6, D3, 0, 0, 0);
         } else {
-            v[2] += dcc * gdf;
+            if (EXTRA) v[2] += dcc * gdf;
             v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
-            v[10] += dcc * pd.x; v[11] += dcc * pd.y; v[12] += dcc * pd.z;
+            if (EXTRA) { v[10] += dcc * pd.x; v[11] += dcc * pd.y; v[12] += dcc * pd.z; }
             v[0] += sG * dx; v[1] += sG * dy;
             const float sdx = sG * dx;
             v[3] += sdx * dx; v[4] += sdx * dy; v[5] += (sG * dy) * dy;
@@ -723,7 +729,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     L.pb[lane] = make_float4(final_depth, bgT, __uint_as_float(last_contributor), T_final);
     L.pc[lane] = make_float4(p.fx, p.fy, 0.f, gacc);
     if (MODE == 2 || MODE == 4) L.pd[lane] = make_float4(gflow0, gflow1, gflow2, 0.f);
-    const bool use_gacc = LANES(gacc != 0.0f) != 0;              // wave-uniform: dL_dacc takes part in this quadrant at all
+    // wave-uniform: which optional upstream gradients take part in this quadrant at all (training on the image alone has none of them)
+    const bool use_gacc = LANES(gacc != 0.0f) != 0;
+    const bool use_extra = LANES(gdepth != 0.0f || gflow0 != 0.0f || gflow1 != 0.0f || gflow2 != 0.0f) != 0;
 
     // ---- A operands: row i = lane & 15 of the per-pixel constant matrices, k = pixel 4s + g  ->  one register per step.
     // Transposed through the (not yet used) ring area: lane = pixel writes its column, lane = (i, g) reads its row entries.
@@ -785,7 +793,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
             wave_lds_sync();
             while (tail - head >= 16 || (c == 0 && tail > head)) {
                 const int nb = (tail - head) < 16 ? (tail - head) : 16;
-                bwd_batch<MODE>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                if (use_extra || MODE == 0) bwd_batch<MODE, true>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                else bwd_batch<MODE, false>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
                 head += nb;
                 wave_lds_sync();
             }
