@@ -389,6 +389,14 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         if (dir3D) { in_d0 = dir3D[3 * (size_t)idx]; in_d1 = dir3D[3 * (size_t)idx + 1]; in_d2 = dir3D[3 * (size_t)idx + 2]; }
     }
 
+    // rows 0..31 go to the LDS half-slice right away (their 26 staging registers are free during the projection arithmetic; rows
+    // 32..63 stay in registers until the first half has been consumed): peak register pressure = arithmetic + half a block
+    if (staged && prefetched) {
+        float *lds0 = sh_lds + wave * SH_HALF_FLOATS;
+        if (split) wave_commit_sh_split_half(lds0, pf, lane, 0);
+        else wave_commit_sh_half(lds0, pf, lane, 0);
+    }
+
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint32_t depth_key = depth_key_invisible;   // invisible Gaussians sort behind every visible one
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             if (prefetched) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    wave_commit_sh_split_half(lds, pf, lane, h);
+                    if (h == 1) wave_commit_sh_split_half(lds, pf, lane, 1);       // half 0 was committed before the arithmetic
                     if (visible && (lane >> 5) == h) {
 #pragma unroll
                         for (int f = 0; f < 3; f++) tmp[f] = lds[SH_HALF_DC_OFFSET + r * 3 + f];
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             const int nvec = (ncoef * 3 + 3) / 4;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                wave_commit_sh_half(lds, pf, lane, h);
+                if (h == 1) wave_commit_sh_half(lds, pf, lane, 1);                 // half 0 was committed before the arithmetic
                 if (visible && (lane >> 5) == h) {
                     const float4 *row = reinterpret_cast<const float4 *>(lds + r * SH_ROW);
 #pragma unroll
