@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--no-model-step", action="store_true", help="skip the training-iteration timings (profiling runs)")
     ap.add_argument("--train-core", action="store_true", help="N = 1: time the training-iteration core (what N > 1 and cfg4 time) instead of the rasterizer alone")
     ap.add_argument("--optimizer", default="none", choices=["none", "replicated", "sharded"], help="training-core steps: include the RAdam step")
+    ap.add_argument("--dense-keyframe-grads", action="store_true", help="training-core steps with the replicated optimizer: dense keyframe gradients instead of the 4 / 2 touched time slices")
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
@@ -344,7 +345,7 @@ def main():
         exchange = "none" if (world == 1 or args.no_allreduce) else ("sharded" if args.optimizer == "sharded" else "allreduce")
         if world == 1 and args.optimizer == "sharded":
             exchange = "sharded"
-        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"),
+        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if args.dense_keyframe_grads else None),
                           lrs={n: 1e-7 for n in model.PARAM_NAMES})       # tiny learning rates: the synthetic scene stays put
 
         def step(i):

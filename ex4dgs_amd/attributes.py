@@ -17,7 +17,7 @@ PARAM_ORDER = ("_xyz", "_xyz_disp", "_rotation", "_opacity", "_scaling", "_featu
                "_xyz_motion", "_rotation_motion", "_opacity_motion", "_opacity_duration_center",
                "_opacity_duration_var", "_scaling_motion", "_features_dc_motion", "_features_rest_motion")
 
-EXPORTS = ("ex4d_attributes_forward", "ex4d_attributes_backward", "ex4d_attributes_last_error")
+EXPORTS = ("ex4d_attributes_forward", "ex4d_attributes_backward", "ex4d_attributes_backward_sliced", "ex4d_attributes_last_error")
 
 
 class Ex4dAttrParams(C.Structure):
@@ -46,6 +46,8 @@ def _lib():
         lib.ex4d_attributes_backward.restype = C.c_int
         lib.ex4d_attributes_forward.argtypes = [C.POINTER(Ex4dAttrParams)] + [C.c_void_p] * 21
         lib.ex4d_attributes_backward.argtypes = [C.POINTER(Ex4dAttrParams)] + [C.c_void_p] * 28
+        lib.ex4d_attributes_backward_sliced.restype = C.c_int
+        lib.ex4d_attributes_backward_sliced.argtypes = [C.POINTER(Ex4dAttrParams)] + [C.c_void_p] * 27 + [C.POINTER(C.c_int32), C.c_void_p]
         lib._attr_ready = True
     return lib
 
@@ -80,8 +82,13 @@ def forward_raw(scal, params, with_shs=True):
     return outs
 
 
-def backward_raw(scal, params, grads_in, with_shs=True, out=None):
-    """One launch of ex4d_attributes_backward on the current stream.  grads_in: dL/d(means3D, rotations, opacities, scales, shs)
+SLICED_SHAPES = {"_xyz_motion": (4, 3), "_rotation_motion": (2, 4)}     # [Nd, slices, C] of ex4d_attributes_backward_sliced
+
+
+def backward_raw(scal, params, grads_in, with_shs=True, out=None, sliced=False):
+    """One launch of ex4d_attributes_backward on the current stream (sliced=True: ex4d_attributes_backward_sliced -- the gradients of
+    `_xyz_motion` / `_rotation_motion` come back as [Nd,4,3] / [Nd,2,4] slices and the call returns (gradients, slice hint) with
+    slice hint = (xyz first keyframe, 4, rotation first keyframe, 2)).  grads_in: dL/d(means3D, rotations, opacities, scales, shs)
     (None = zeros; the shs entry is ignored when with_shs is False).  out: optional list of 15 preallocated gradient tensors
     (PARAM_ORDER; None entries are allocated) -- every one is written exactly once, dense.  Returns the 15 gradients (None for the
     feature tensors when with_shs is False: their gradient comes out of the rasterizer's SplitSH path)."""
@@ -97,20 +104,27 @@ def backward_raw(scal, params, grads_in, with_shs=True, out=None):
     for i, (n, x) in enumerate(zip(PARAM_ORDER, params)):
         if not with_shs and n in FEATURE_NAMES:
             gout.append(None)
-        elif out is not None and out[i] is not None:
-            if out[i].shape != x.shape or out[i].dtype != torch.float32 or out[i].device != dev or not out[i].is_contiguous():
-                raise RuntimeError(f"gradient buffer for {n} must be a contiguous float32 tensor of shape {tuple(x.shape)} on {dev}")
-            gout.append(out[i])
         else:
-            gout.append(torch.empty_like(x))
+            shape = (x.shape[0],) + SLICED_SHAPES[n] if (sliced and n in SLICED_SHAPES) else tuple(x.shape)
+            if out is not None and out[i] is not None:
+                if tuple(out[i].shape) != shape or out[i].dtype != torch.float32 or out[i].device != dev or not out[i].is_contiguous():
+                    raise RuntimeError(f"gradient buffer for {n} must be a contiguous float32 tensor of shape {shape} on {dev}")
+                gout.append(out[i])
+            else:
+                gout.append(torch.empty(shape, **f32))
     byname = dict(zip(PARAM_ORDER, params))
+    hint = (C.c_int32 * 4)()
     with torch.cuda.device(dev):
-        rc = lib.ex4d_attributes_backward(
-            C.byref(scal), *[_ptr(byname[n]) for n in _BWD_INPUTS],
-            *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if sliced:
+            rc = lib.ex4d_attributes_backward_sliced(C.byref(scal), *[_ptr(byname[n]) for n in _BWD_INPUTS],
+                                                     *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], hint, stream)
+        else:
+            rc = lib.ex4d_attributes_backward(C.byref(scal), *[_ptr(byname[n]) for n in _BWD_INPUTS],
+                                              *[_ptr(g) for g in gin], *[_ptr(g) for g in gout], stream)
     if rc:
         raise RuntimeError(lib.ex4d_attributes_last_error().decode())
-    return gout
+    return (gout, tuple(int(v) for v in hint)) if sliced else gout
 
 
 class _EvaluateAttributes(torch.autograd.Function):

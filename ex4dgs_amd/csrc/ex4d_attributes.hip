@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void attributes_bwd_kernel(Ex4dAttrParams a,
     float *__restrict__ g_xyz, float *__restrict__ g_xyz_disp, float *__restrict__ g_rotation, float *__restrict__ g_opacity,
     float *__restrict__ g_scaling, float *__restrict__ g_xyz_motion, float *__restrict__ g_rotation_motion,
     float *__restrict__ g_opacity_motion, float *__restrict__ g_dur_center, float *__restrict__ g_dur_var,
-    float *__restrict__ g_scaling_motion)
+    float *__restrict__ g_scaling_motion, int sliced)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int N = a.Ns + a.Nd;
@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void attributes_bwd_kernel(Ex4dAttrParams a,
     } else {
         const size_t j = (size_t)(i - a.Ns);
         // Hermite weights back onto the four keyframes (the other K-4 slices were zero-filled by the host memset)
-        float *gy = g_xyz_motion + (j * a.K + (a.k - 1)) * 3;
+        // sliced: g_xyz_motion is [Nd,4,3] (keyframes k-1..k+2), g_rotation_motion [Nd,2,4] (keyframes k, k+1): nothing else exists
+        float *gy = g_xyz_motion + (sliced ? j * 12 : (j * a.K + (a.k - 1)) * 3);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             gy[c] = -(a.h10 * gm[c]) / 2.0f;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void attributes_bwd_kernel(Ex4dAttrParams a,
         const float G[4] = { gq.x, gq.y, gq.z, gq.w };
         float gq1[4], gq2[4];
         slerp_backward(c, a.delta, G, gq1, gq2);
-        float4 *grq = reinterpret_cast<float4 *>(g_rotation_motion) + j * a.K + a.k;
+        float4 *grq = reinterpret_cast<float4 *>(g_rotation_motion) + (sliced ? j * 2 : j * a.K + a.k);
         grq[0] = make_float4(gq1[0], gq1[1], gq1[2], gq1[3]);
         grq[1] = make_float4(gq2[0], gq2[1], gq2[2], gq2[3]);
         // opacity = bigaussian(centres, log-widths, tau) * sigmoid(o)   (c_gaussian_model.py:363-366)
@@ -280,7 +281,7 @@ int ex4d_attributes_forward(const Ex4dAttrParams *a,
     return EX4D_OK;
 }
 
-int ex4d_attributes_backward(const Ex4dAttrParams *a,
+static int attributes_backward_impl(const Ex4dAttrParams *a, int sliced,
     const float *opacity, const float *scaling, const float *rotation_motion, const float *opacity_motion,
     const float *dur_center, const float *dur_var, const float *scaling_motion,
     const float *g_means3D, const float *g_rotations, const float *g_opacities, const float *g_scales, const float *g_shs,
@@ -296,15 +297,15 @@ int ex4d_attributes_backward(const Ex4dAttrParams *a,
     if (a->Nd > 0) {
         if (a->k < 1 || a->k + 2 >= a->K) { snprintf(g_attr_err, sizeof(g_attr_err), "keyframe index out of range"); return EX4D_ERR_ARG; }
         // dense gradients of the keyframe tensors: only 4 (xyz) / 2 (rotation) of the K slices are non-zero
-        if (hipMemsetAsync(g_xyz_motion, 0, (size_t)a->Nd * a->K * 3 * sizeof(float), stream) != hipSuccess ||
-            hipMemsetAsync(g_rotation_motion, 0, (size_t)a->Nd * a->K * 4 * sizeof(float), stream) != hipSuccess) {
+        if (!sliced && (hipMemsetAsync(g_xyz_motion, 0, (size_t)a->Nd * a->K * 3 * sizeof(float), stream) != hipSuccess ||
+            hipMemsetAsync(g_rotation_motion, 0, (size_t)a->Nd * a->K * 4 * sizeof(float), stream) != hipSuccess)) {
             snprintf(g_attr_err, sizeof(g_attr_err), "memset failed"); return EX4D_ERR_HIP;
         }
     }
     hipLaunchKernelGGL(attributes_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, *a, opacity, scaling, rotation_motion, opacity_motion,
         dur_center, dur_var, scaling_motion, g_means3D, g_rotations, g_opacities, g_scales,
         g_xyz, g_xyz_disp, g_rotation, g_opacity, g_scaling, g_xyz_motion, g_rotation_motion, g_opacity_motion, g_dur_center, g_dur_var,
-        g_scaling_motion);
+        g_scaling_motion, sliced);
     if (g_shs) {     // NULL: dL/dsh was written into the four gradient tensors by the rasterizer itself (Ex4dSplitSHGrad)
         const size_t total = (size_t)N * 12;
         const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -314,6 +315,33 @@ int ex4d_attributes_backward(const Ex4dAttrParams *a,
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_attr_err, sizeof(g_attr_err), "launch failed: %s", hipGetErrorString(e)); return EX4D_ERR_HIP; }
     return EX4D_OK;
+}
+
+int ex4d_attributes_backward(const Ex4dAttrParams *a,
+    const float *opacity, const float *scaling, const float *rotation_motion, const float *opacity_motion,
+    const float *dur_center, const float *dur_var, const float *scaling_motion,
+    const float *g_means3D, const float *g_rotations, const float *g_opacities, const float *g_scales, const float *g_shs,
+    float *g_xyz, float *g_xyz_disp, float *g_rotation, float *g_opacity, float *g_scaling, float *g_features_dc, float *g_features_rest,
+    float *g_xyz_motion, float *g_rotation_motion, float *g_opacity_motion, float *g_dur_center, float *g_dur_var,
+    float *g_scaling_motion, float *g_features_dc_motion, float *g_features_rest_motion, void *stream_)
+{
+    return attributes_backward_impl(a, 0, opacity, scaling, rotation_motion, opacity_motion, dur_center, dur_var, scaling_motion, g_means3D, g_rotations,
+        g_opacities, g_scales, g_shs, g_xyz, g_xyz_disp, g_rotation, g_opacity, g_scaling, g_features_dc, g_features_rest, g_xyz_motion,
+        g_rotation_motion, g_opacity_motion, g_dur_center, g_dur_var, g_scaling_motion, g_features_dc_motion, g_features_rest_motion, stream_);
+}
+
+int ex4d_attributes_backward_sliced(const Ex4dAttrParams *a,
+    const float *opacity, const float *scaling, const float *rotation_motion, const float *opacity_motion,
+    const float *dur_center, const float *dur_var, const float *scaling_motion,
+    const float *g_means3D, const float *g_rotations, const float *g_opacities, const float *g_scales, const float *g_shs,
+    float *g_xyz, float *g_xyz_disp, float *g_rotation, float *g_opacity, float *g_scaling, float *g_features_dc, float *g_features_rest,
+    float *g_xyz_motion_slices, float *g_rotation_motion_slices, float *g_opacity_motion, float *g_dur_center, float *g_dur_var,
+    float *g_scaling_motion, float *g_features_dc_motion, float *g_features_rest_motion, int32_t *slices, void *stream_)
+{
+    if (a && slices) { slices[0] = a->k - 1; slices[1] = 4; slices[2] = a->k; slices[3] = 2; }
+    return attributes_backward_impl(a, 1, opacity, scaling, rotation_motion, opacity_motion, dur_center, dur_var, scaling_motion, g_means3D, g_rotations,
+        g_opacities, g_scales, g_shs, g_xyz, g_xyz_disp, g_rotation, g_opacity, g_scaling, g_features_dc, g_features_rest, g_xyz_motion_slices,
+        g_rotation_motion_slices, g_opacity_motion, g_dur_center, g_dur_var, g_scaling_motion, g_features_dc_motion, g_features_rest_motion, stream_);
 }
 
 }  // extern "C"

@@ -217,6 +217,50 @@ class ParamGradExchange:
             self._grads = None
 
 
+class SliceGather:
+    """Exchange of the keyframe-gradient SLICES of ex4d_attributes_backward_sliced: every rank contributes its [Nd, count, C] window
+    (16 MB at 0.2 M dynamic Gaussians instead of a 196 MB dense all-reduce) plus its first keyframe index; after wait() every rank holds
+    all W windows and their positions and feeds them to ex4d_radam_step_sliced, which adds them per element in rank order -- the same
+    sum as the dense all-reduce.  (The union of W random timestamps covers most of the K keyframes, so a dense "union" tensor would
+    save little; W small windows do.)"""
+
+    def __init__(self, shape, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.all = torch.zeros((self.world,) + tuple(shape), dtype=torch.float32, device=device)
+        self.first = torch.zeros(self.world, dtype=torch.int32, device=device)
+        self.pending = []
+        self._native = _backend(group) == "nccl"
+
+    def launch(self, window, first):
+        self.wait()
+        self.all[self.rank].copy_(window)
+        self._first_host = int(first)
+        if self.world > 1:
+            self.first[self.rank] = int(first)
+            if self._native:
+                self.pending = [dist.all_gather_into_tensor(self.all, self.all[self.rank], group=self.group, async_op=True),
+                                dist.all_gather_into_tensor(self.first, self.first[self.rank:self.rank + 1], group=self.group, async_op=True)]
+            else:
+                self.pending = [dist.all_gather([self.all[r] for r in range(self.world)], self.all[self.rank].clone(), group=self.group, async_op=True),
+                                dist.all_gather([self.first[r:r + 1] for r in range(self.world)], self.first[self.rank:self.rank + 1].clone(), group=self.group, async_op=True)]
+        return self
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def windows(self, count):
+        """[(first keyframe, count, device pointer of the [Nd, count, C] block)] for all ranks (call after wait())."""
+        firsts = self.first.tolist() if self.world > 1 else [self._first_host]      # one rank: no device round trip
+        return [(int(firsts[r]), int(count), self.all[r].data_ptr()) for r in range(self.world)]
+
+    def bytes_on_wire(self):
+        return 4 * self.all[0].numel()
+
+
 class ShardedRAdam:
     """RAdam over a fixed list of parameter tensors with the update and the optimizer state sharded over ranks
     ("fused RAdam tied to the reduce-scatter of 8e").  Per step and tensor:

@@ -13,7 +13,9 @@ import torch
 
 from . import _C
 
-EXPORTS = ("ex4d_optim_last_error", "ex4d_radam_step")
+EXPORTS = ("ex4d_optim_last_error", "ex4d_radam_step", "ex4d_radam_step_sliced")
+MAX_WINDOWS = 8
+MAX_SLICED = 4
 MAX_TENSORS = 32
 
 
@@ -22,9 +24,17 @@ class Ex4dRadamTensor(C.Structure):
                 ("numel", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
 
 
+class Ex4dRadamSlicedTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("rows", C.c_int64), ("K", C.c_int32), ("C", C.c_int32),
+                ("lr", C.c_double), ("step", C.c_int64), ("n_windows", C.c_int32), ("first", C.c_int32 * 8), ("count", C.c_int32 * 8),
+                ("grad", C.c_void_p * 8)]
+
+
 def _lib():
     lib = _C.load()
     if not getattr(lib, "_optim_ready", False):
+        lib.ex4d_radam_step_sliced.restype = C.c_int
+        lib.ex4d_radam_step_sliced.argtypes = [C.POINTER(Ex4dRadamSlicedTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
         lib.ex4d_optim_last_error.restype = C.c_char_p
         lib.ex4d_radam_step.restype = C.c_int
         lib.ex4d_radam_step.argtypes = [C.POINTER(Ex4dRadamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
@@ -44,6 +54,30 @@ def radam_step_raw(items, betas, eps, device):
             chunk = descs[i:i + MAX_TENSORS]
             arr = (Ex4dRadamTensor * len(chunk))(*chunk)
             if lib.ex4d_radam_step(arr, len(chunk), betas[0], betas[1], eps, stream):
+                raise RuntimeError(lib.ex4d_optim_last_error().decode())
+
+
+def radam_step_sliced_raw(items, betas, eps, device):
+    """ex4d_radam_step_sliced over keyframe tensors [rows, K, C] with windowed gradients.  items: iterable of
+    (param_ptr, exp_avg_ptr, exp_avg_sq_ptr, rows, K, C, lr, step, windows) with windows = [(first, count, grad_ptr), ...] (<= 8),
+    grad_ptr -> [rows, count, C] floats.  Bit-identical to radam_step_raw on the dense gradient the windows add up to."""
+    lib = _lib()
+    descs = []
+    for (p, m, v, rows, K, Cc, lr, step, windows) in items:
+        if rows <= 0:
+            continue
+        if len(windows) > MAX_WINDOWS:
+            raise RuntimeError(f"at most {MAX_WINDOWS} gradient windows per tensor and step")
+        first = (C.c_int32 * 8)(*([w[0] for w in windows] + [0] * (8 - len(windows))))
+        count = (C.c_int32 * 8)(*([w[1] for w in windows] + [0] * (8 - len(windows))))
+        grad = (C.c_void_p * 8)(*([int(w[2]) for w in windows] + [None] * (8 - len(windows))))
+        descs.append(Ex4dRadamSlicedTensor(int(p), int(m), int(v), int(rows), int(K), int(Cc), float(lr), int(step), len(windows), first, count, grad))
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for i in range(0, len(descs), MAX_SLICED):
+            chunk = descs[i:i + MAX_SLICED]
+            arr = (Ex4dRadamSlicedTensor * len(chunk))(*chunk)
+            if lib.ex4d_radam_step_sliced(arr, len(chunk), betas[0], betas[1], eps, stream):
                 raise RuntimeError(lib.ex4d_optim_last_error().decode())
 
 

@@ -57,6 +57,20 @@ int ex4d_attributes_backward(const Ex4dAttrParams *a,
     float *g_xyz_motion, float *g_rotation_motion, float *g_opacity_motion, float *g_opacity_duration_center,
     float *g_opacity_duration_var, float *g_scaling_motion, float *g_features_dc_motion, float *g_features_rest_motion, void *stream);
 
+/* The same backward with the keyframe gradients as SLICES instead of dense tensors: g_xyz_motion_slices[Nd,4,3] holds the gradients of
+ * keyframes slices[0] .. slices[0]+3, g_rotation_motion_slices[Nd,2,4] those of keyframes slices[2], slices[2]+1 -- every other time
+ * slice of the dense gradient is zero for this timestamp.  slices = int32[4] {xyz first, xyz count (4), rotation first, rotation count (2)},
+ * written on the host (the slice hint an optimizer / gradient exchange needs).  No zero fill of 7 K floats per dynamic Gaussian, and
+ * ex4d_radam_step_sliced (ex4d_optim.h) consumes the slices directly. */
+int ex4d_attributes_backward_sliced(const Ex4dAttrParams *a,
+    const float *opacity, const float *scaling, const float *rotation_motion, const float *opacity_motion,
+    const float *opacity_duration_center, const float *opacity_duration_var, const float *scaling_motion,
+    const float *g_means3D, const float *g_rotations, const float *g_opacities, const float *g_scales, const float *g_shs,
+    float *g_xyz, float *g_xyz_disp, float *g_rotation, float *g_opacity, float *g_scaling, float *g_features_dc, float *g_features_rest,
+    float *g_xyz_motion_slices, float *g_rotation_motion_slices, float *g_opacity_motion, float *g_opacity_duration_center,
+    float *g_opacity_duration_var, float *g_scaling_motion, float *g_features_dc_motion, float *g_features_rest_motion,
+    int32_t *slices, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

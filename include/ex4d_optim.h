@@ -39,6 +39,29 @@ const char *ex4d_optim_last_error(void);
 /* tensors: HOST array of `count` descriptors (count <= EX4D_RADAM_MAX_TENSORS per call).  stream: hipStream_t. */
 int ex4d_radam_step(const Ex4dRadamTensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream);
 
+/* The same step for a keyframe tensor param[rows, K, C] (C = 3 or 4) whose gradient is known to be zero outside a few time slices:
+ * gradient(row, k, c) = sum over the windows w with first[w] <= k < first[w] + count[w] of grad[w][row, k - first[w], c]
+ * (ex4d_attributes_backward_sliced writes such windows; several windows = several frames / ranks accumulated).  Every element is
+ * still updated -- RAdam moves zero-gradient elements by their momentum -- but the dense gradient is neither zero-filled nor read:
+ * 24 instead of 28 bytes per element, and no 7 K-float memset per dynamic Gaussian in the backward.  Bit-identical to ex4d_radam_step
+ * on the equivalent dense gradient (windows summed in index order). */
+#define EX4D_RADAM_MAX_WINDOWS 8
+#define EX4D_RADAM_MAX_SLICED 4
+typedef struct Ex4dRadamSlicedTensor {
+    float *param;            /* device [rows, K, C], updated in place (a row range of a larger tensor is fine: pass offset pointers) */
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t rows;
+    int32_t K, C;
+    double lr;
+    int64_t step;
+    int32_t n_windows;       /* 0 .. EX4D_RADAM_MAX_WINDOWS */
+    int32_t first[EX4D_RADAM_MAX_WINDOWS], count[EX4D_RADAM_MAX_WINDOWS];
+    const float *grad[EX4D_RADAM_MAX_WINDOWS];      /* device [rows, count[w], C] */
+} Ex4dRadamSlicedTensor;
+
+int ex4d_radam_step_sliced(const Ex4dRadamSlicedTensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,19 @@ for name, p in zip(PARAM_ORDER, m2.parameters()):
     torch.distributed.broadcast(q, src=0)
     assert torch.equal(p, q), (name, float((p - q).abs().max()), int((p != q).sum()), p.numel(), tr2.exchange.small[list(PARAM_ORDER).index(name)])
     assert torch.isfinite(p).all()
+
+# (4) replicated optimizer with SLICED keyframe gradients: the ranks' windows are all-gathered and summed inside ex4d_radam_step_sliced
+m3, _, _ = make_scene("cfg3", P=20000, device="cuda", fused=True)
+tr3 = FrameTrainer(m3, exchange="allreduce", optimizer=True, lrs={n: 1e-6 for n in PARAM_ORDER})
+assert tr3.sliced and len(tr3.kf_gather) == 2
+for k in range(3):
+    tr3.step(cam, bg, stamps[(2 * k + rank) % len(stamps)], up)
+tr3.flush(); torch.cuda.synchronize()
+for name, p in zip(PARAM_ORDER, m3.parameters()):
+    q = p.clone()
+    torch.distributed.broadcast(q, src=0)
+    assert torch.equal(p, q) and torch.isfinite(p).all(), name
+assert tr3.kf_gather[0].bytes_on_wire() == 4 * m3.num_dynamic * 12 and tr3.exchange.bytes_on_wire() < 4 * sum(p.numel() for p in m3.parameters()) - 4 * m3.num_dynamic * 35 * 7 + 1
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 print("OK", rank)
 """

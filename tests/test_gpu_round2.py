@@ -103,3 +103,83 @@ def test_native_calls_reject_short_tensors(hip_lib):
         _C.mark_visible(d["means3D"], s.viewmatrix.double(), s.projmatrix, 4.0)
     with pytest.raises(RuntimeError):
         _C.mark_visible(d["means3D"], s.viewmatrix.cpu(), s.projmatrix, 4.0)
+
+
+def test_sliced_keyframe_gradients_equal_the_dense_ones(hip_lib):
+    """ex4d_attributes_backward_sliced returns exactly the 4 / 2 non-zero time slices of the dense keyframe gradients (and the slice
+    hint says where they sit); every other gradient is identical."""
+    from ex4dgs_amd import attributes as attr
+    from ex4dgs_amd.scene import make_scene
+    model, cam, bg = make_scene("cfg3", P=5000, device="cuda", fused=True)
+    params = [getattr(model, n) for n in attr.PARAM_ORDER]
+    g = torch.Generator().manual_seed(3)
+    N = model.num_static + model.num_dynamic
+    gin = [torch.randn(N, 3, generator=g).cuda(), torch.randn(N, 4, generator=g).cuda(), torch.randn(N, 1, generator=g).cuda(), torch.randn(N, 3, generator=g).cuda(), None]
+    for t in (0, 7, 137, 299):
+        scal = attr.time_scalars(t, model.num_static, model.num_dynamic, model._xyz_motion.shape[1], model.duration, model.interval, model.time_shift, model.var_pad)
+        dense = attr.backward_raw(scal, params, gin, with_shs=False)
+        sliced, hint = attr.backward_raw(scal, params, gin, with_shs=False, sliced=True)
+        assert hint == (scal.k - 1, 4, scal.k, 2)
+        for i, n in enumerate(attr.PARAM_ORDER):
+            if dense[i] is None:
+                assert sliced[i] is None
+            elif n in ("_xyz_motion", "_rotation_motion"):
+                lo, cnt = (hint[0], 4) if n == "_xyz_motion" else (hint[2], 2)
+                assert torch.equal(sliced[i], dense[i][:, lo:lo + cnt])
+                rest = dense[i].clone(); rest[:, lo:lo + cnt] = 0
+                assert float(rest.abs().max()) == 0.0            # every other time slice of the dense gradient is zero
+            else:
+                assert torch.equal(sliced[i], dense[i]), n
+
+
+def test_sliced_radam_is_bit_identical_to_the_dense_step(hip_lib):
+    """ex4d_radam_step_sliced (keyframe tensor + windowed gradients, incl. two overlapping windows = two frames) against ex4d_radam_step
+    on the dense gradient the windows add up to: parameters and both moments bit-identical over 9 steps (crossing rho_t > 5)."""
+    from ex4dgs_amd.optim import radam_step_raw, radam_step_sliced_raw
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    for rows, K, Cc in ((1003, 35, 3), (777, 35, 4), (5, 7, 3)):
+        p0 = torch.randn(rows, K, Cc, generator=g).cuda()
+        A, B = p0.clone(), p0.clone()
+        mA, vA, mB, vB = [torch.zeros_like(p0) for _ in range(4)]
+        for step in range(1, 10):
+            wins = []
+            dense = torch.zeros_like(p0)
+            for w in range(1 + step % 3):                       # 1..3 windows, possibly overlapping
+                cnt = 4 if Cc == 3 else 2
+                first = int(torch.randint(0, K - cnt + 1, (1,), generator=g))
+                blk = torch.randn(rows, cnt, Cc, generator=g).cuda() * (0.0 if (step == 4 and w == 0) else 1.0)
+                wins.append((first, cnt, blk))
+                dense[:, first:first + cnt] += blk               # same order as the kernel: windows added in index order
+            radam_step_raw([(A.data_ptr(), dense.data_ptr(), mA.data_ptr(), vA.data_ptr(), A.numel(), 1e-2, step)], (0.9, 0.999), 1e-8, dev)
+            radam_step_sliced_raw([(B.data_ptr(), mB.data_ptr(), vB.data_ptr(), rows, K, Cc, 1e-2, step, [(f, c, b.data_ptr()) for f, c, b in wins])],
+                                  (0.9, 0.999), 1e-8, dev)
+            torch.cuda.synchronize()
+            assert torch.equal(A, B) and torch.equal(mA, mB) and torch.equal(vA, vB), (rows, K, Cc, step)
+    with pytest.raises(RuntimeError):
+        radam_step_sliced_raw([(A.data_ptr(), mA.data_ptr(), vA.data_ptr(), 5, 7, 3, 1e-2, 1, [(6, 4, A.data_ptr())])], (0.9, 0.999), 1e-8, dev)   # window outside [0, K)
+
+
+def test_trainer_with_sliced_optimizer_tracks_the_dense_one(hip_lib):
+    """FrameTrainer with the replicated optimizer: sliced keyframe gradients (default) against dense ones on two copies of one model --
+    equal to the rounding of the rasterizer's float atomics after several steps, and no dense keyframe gradient buffer exists."""
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.trainer import FrameTrainer
+    ma, cam, bg = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    mb, _, _ = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    w = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5)).cuda()
+    up = lambda out: ([out["render"]], [w])
+    lrs = {n: 1e-6 for n in ma.PARAM_NAMES}
+    ta = FrameTrainer(ma, optimizer=True, lrs=lrs)
+    tb = FrameTrainer(mb, optimizer=True, lrs=lrs, sliced=False)
+    assert ta.sliced and not tb.sliced
+    assert ta.pgrad[ta.names.index("_xyz_motion")].shape[1:] == (4, 3) and tb.pgrad[tb.names.index("_xyz_motion")].shape == mb._xyz_motion.shape
+    p0 = {n: getattr(ma, n).clone() for n in ma.PARAM_NAMES}
+    for t in (0, 137, 41, 299, 7):
+        ta.step(cam, bg, t, up); tb.step(cam, bg, t, up)
+    ta.flush(); tb.flush(); torch.cuda.synchronize()
+    for n in ma.PARAM_NAMES:
+        a, b = getattr(ma, n), getattr(mb, n)
+        moved = float((a - p0[n]).abs().max())
+        assert moved > 0 and torch.isfinite(a).all(), n
+        assert float((a - b).abs().max()) <= 1e-3 * moved + 1e-12, (n, float((a - b).abs().max()), moved)
