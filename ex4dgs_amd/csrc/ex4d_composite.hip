@@ -57,6 +57,13 @@ __device__ __forceinline__ int select_i(lanemask m, int if_set, int if_clear)
     return r;
 }
 
+// power * log2(e) of CR/forward.cu:368-372 from the pre-scaled conic (a' = -0.5 log2e A, b' = -log2e B, c' = -0.5 log2e C).  ONE
+// spelled-out contraction for every kernel that takes the alpha decisions (forward, both backward kernels): identical bits, so
+// the backward re-derives exactly the contributor set the forward composited (left to -ffp-contract the compiler fused the
+// forward and the backward expressions differently).  b' dy and (c' dy) dy depend on the Gaussian and the pixel ROW only.
+__device__ __forceinline__ float power2_rows(float dx, float ap, float bdy, float cdydy) { return __builtin_fmaf(dx, __builtin_fmaf(dx, ap, bdy), cdydy); }
+__device__ __forceinline__ float power2_of(float dx, float dy, float ap, float bp, float cp) { return power2_rows(dx, ap, bp * dy, (cp * dy) * dy); }
+
 __device__ __forceinline__ float wave_min(float v)
 {
 #pragma unroll
@@ -204,7 +211,7 @@ __device__ __forceinline__ void composite_fwd_body(
             const float2 g1 = s_q1[wave][j];
             // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
             const float dx = g0.x - p.fx, dy = g0.y - p.fy;
-            const float power2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;
+            const float power2 = power2_of(dx, dy, g0.z, g0.w, g1.x);
             const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(power2));
             const float test_T = T * (1.f - alpha);
             const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
             // CR/backward.cu:575-590, one flat predicate (same arithmetic as the forward kernel: identical decisions)
             const float dx = g0.x - p.fx, dy = g0.y - p.fy;
             const float adx = g0.z * dx, bdy = g0.w * dy, cdy = g1.x * dy;
-            const float power2 = dx * (adx + bdy) + cdy * dy;
+            const float power2 = power2_of(dx, dy, g0.z, g0.w, g1.x);
             const float G = __builtin_amdgcn_exp2f(power2);                   // exp(power)
             const float araw = g1.y * G;
             const float alpha = fminf(0.99f, araw);
@@ -546,7 +553,8 @@ __device__ __forceinline__ float row_scan_add_asm(float x)
 //   4  = 2 plus the developer statistics of g_bwd_stats
 // EXTRA = false: no pixel of the quadrant has an upstream depth or flow gradient (training on the image alone) -- the depth term of
 // dL_dalpha and four of the 13 sums drop out (compile-time, so the common all-gradients path carries no extra branches)
-template <int MODE, bool EXTRA>
+// SEP = true: every pixel of the quadrant sits at its integer coordinates (no sub-pixel offsets), so dx / dy are not read per pixel
+template <int MODE, bool EXTRA, bool SEP>
 __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
                                           const float (&A1)[16], const float (&A2)[16], float *__restrict__ acc16)
 {
@@ -559,6 +567,7 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
     // `valid && ...` and pays a v_cndmask + v_cmp per step to re-materialise the lane mask)
     const uint32_t orig = (uint32_t)select_i(LANES(valid), (int)__float_as_uint(g2.w), -1);
     const float flagf = dep > min_depth ? 1.f : 0.f;       // CR/backward.cu:603
+    const float depflag = dep * flagf;
     f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f}, D3 = {0.f, 0.f, 0.f, 0.f};
     float v[13];
 #pragma unroll
@@ -572,6 +581,8 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
     float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = L.pc[g], pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 2 || MODE == 4) pd_n = L.pd[g];
     unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
+    const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
+    float dyr = 0.f, bdy = 0.f, cdydy = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
         const float4 pa = pa_n, pb = pb_n, pc = pc_n, pd = pd_n;
@@ -579,9 +590,18 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
             pa_n = L.pa[4 * s + 4 + g]; pb_n = L.pb[4 * s + 4 + g]; pc_n = L.pc[4 * s + 4 + g];
             if (MODE == 2 || MODE == 4) pd_n = L.pd[4 * s + 4 + g];
         }
-        const float dx = g0.x - pc.x, dy = g0.y - pc.y;        // the forward kernel's arithmetic: identical alpha, identical decisions
-        const float adx = ap * dx, cdy = cp * dy;
-        const float power2 = dx * (adx + bp * dy) + cdy * dy;
+        // the forward kernel's arithmetic: identical alpha, identical decisions.  Pixel 4s+g sits in column 4(s&1)+g, row s>>1 of
+        // the quadrant: without sub-pixel offsets (SEP) dx takes two values per batch, dy / b'dy / (c'dy)dy change every other step
+        float dx, dy;
+        if (SEP) {
+            dx = (s & 1) ? dxo : dxe;
+            if ((s & 1) == 0) { dyr = g0.y - (oy + (float)(s >> 1)); bdy = bp * dyr; cdydy = (cp * dyr) * dyr; }
+            dy = dyr;
+        } else {
+            dx = g0.x - pc.x; dy = g0.y - pc.y;
+            bdy = bp * dy; cdydy = (cp * dy) * dy;
+        }
+        const float power2 = power2_rows(dx, ap, bdy, cdydy);
         const float G = __builtin_amdgcn_exp2f(power2);
         const float alpha = fminf(0.99f, w * G);
         const lanemask ok = LANES(orig < __float_as_uint(pb.z)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
@@ -596,21 +616,21 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
         const float cgp = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z;      // c . dL_dpixel
         const float e = dcc * cgp;
         const float E = pc.z + row_scan_add_asm(e);
-        // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha)
-        float dLa = cgp * T - (E - e) * inv;
-        float gdf = 0.f;
+        // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha).
+        // With e inv = (c . dL_dpixel) T (inv - 1) the colour and background terms collapse to inv ((c . dL_dpixel) T - E + bgT)
+        // (E inclusive); the depth flag (0 or 1) is folded into per-Gaussian constants: (final_depth - dep) flag = final_depth flag - dep flag
+        float dLa = (cgp * T + (pb.y - E)) * inv;
+        float gdT = 0.f;
         if (EXTRA) {
-            gdf = pa.w * flagf;
-            const float u = ((pb.x - dep) * gdf) * T;
-            dLa += u * T;
+            gdT = pa.w * T;                                             // dL_ddepth T; the flag of the dL_dmean2D.z sum is applied per Gaussian
+            dLa += ((pb.x * flagf - depflag) * gdT) * T;
         }
-        dLa += pb.y * inv;
         float s6 = G_m * dLa;
         const float sG = w * s6;                                        // dL_dG G = (w dL_dalpha) G
         if (use_gacc) {             // wave-uniform
             // dL_dacc *= T for every contributor (CR/backward.cu:650), then dL_dopacity += G (dL_dalpha + dL_dacc)
             const float ga = pc.w * row_scan_mul(select_f(ok, T, 1.f));
-            s6 += G_m * ga;
+            if (MODE == 0) s6 += G_m * ga; else v[6] += G_m * ga;
             wG[16 * s] = ga;
         }
         if (MODE == 0) {
@@ -618,7 +638,7 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
             D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], sG, D2, 0, 0, 0);
             D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], s6, D3, 0, 0, 0);
         } else {
-            if (EXTRA) v[2] += dcc * gdf;
+            if (EXTRA) v[2] += alpha_m * gdT;
             v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
             if (EXTRA) { v[10] += dcc * pd.x; v[11] += dcc * pd.y; v[12] += dcc * pd.z; }
             v[0] += sG * dx; v[1] += sG * dy;
@@ -651,8 +671,9 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
             // with the pre-scaled conic -- linear in the moments, so the conic is applied once per Gaussian here
             out[0] = (2.f * ap) * v[0] + bp * v[1];
             out[1] = (2.f * cp) * v[1] + bp * v[0];
+            out[2] = v[2] * flagf;
 #pragma unroll
-            for (int q = 2; q < 13; q++) out[q] = v[q];
+            for (int q = 3; q < 13; q++) out[q] = v[q];
         }
     } else {
         // lane (n, g) holds rows 4g..4g+3 of column n: sums of ITS Gaussian; moments about the quadrant origin -> Gaussian-centred
@@ -731,6 +752,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     if (MODE == 2 || MODE == 4) L.pd[lane] = make_float4(gflow0, gflow1, gflow2, 0.f);
     // wave-uniform: which optional upstream gradients take part in this quadrant at all (training on the image alone has none of them)
     const bool use_gacc = LANES(gacc != 0.0f) != 0;
+    const bool sep = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
     const bool use_extra = LANES(gdepth != 0.0f || gflow0 != 0.0f || gflow1 != 0.0f || gflow2 != 0.0f) != 0;
 
     // ---- A operands: row i = lane & 15 of the per-pixel constant matrices, k = pixel 4s + g  ->  one register per step.
@@ -793,8 +815,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
             wave_lds_sync();
             while (tail - head >= 16 || (c == 0 && tail > head)) {
                 const int nb = (tail - head) < 16 ? (tail - head) : 16;
-                if (use_extra || MODE == 0) bwd_batch<MODE, true>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
-                else bwd_batch<MODE, false>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                if (MODE == 0) bwd_batch<MODE, true, false>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                else if (!sep) bwd_batch<MODE, true, false>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                else if (use_extra) bwd_batch<MODE, true, true>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
+                else bwd_batch<MODE, false, true>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
                 head += nb;
                 wave_lds_sync();
             }

@@ -226,13 +226,14 @@ def _stage(fwd_o, acc13):
 DERIVED = ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
 
 
-def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=3):
+def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=6):
     """Per-entry bound on the nine returned gradients implied by a per-entry bound `tol13` [P,13] on the accumulators.
     dL_dmeans2D / dL_dopacity / dL_dcolors / dL_ddir ARE accumulators; the other five are a LINEAR map J of nine of them per
     Gaussian (the per-Gaussian backward stage), so the bound is |J| tol -- obtained by pushing one accumulator channel at a time
     through the oracle's stage and adding absolute values -- plus the float32 evaluation noise of the stage itself (its matrix
     chains cancel internally: J can be small where its path terms are large), measured by re-evaluating the stage on the
-    accumulators perturbed by +-2 ulp (`acc13` given; worst of `noise_trials` draws, taken 8x)."""
+    accumulators perturbed by +-2 ulp (`acc13` given; worst of `noise_trials` draws and of the components of a Gaussian's row --
+    a single component's draws are a heavy-tailed estimate of its noise scale, the row shares one scale -- taken 8x)."""
     t = np.asarray(tol13, dtype=np.float64)
     out = {"dL_dmeans2D": t[:, 0:3].copy(), "dL_dopacity": t[:, 6:7].copy(), "dL_dcolors": t[:, 7:10].copy(), "dL_ddir": t[:, 10:13].copy()}
     derived = {k: 0.0 for k in DERIVED}
@@ -253,7 +254,9 @@ def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=3):
             for k in DERIVED:
                 noise[k] = np.maximum(noise[k], np.abs(r[k].astype(np.float64) - base[k].astype(np.float64)))
         for k in DERIVED:
-            derived[k] = derived[k] + 8.0 * noise[k]
+            n = np.asarray(noise[k], dtype=np.float64)
+            row = n.reshape(n.shape[0], -1).max(axis=1).reshape((n.shape[0],) + (1,) * (n.ndim - 1))
+            derived[k] = derived[k] + 8.0 * np.broadcast_to(row, n.shape)
     out.update(derived)
     return out
 
