@@ -83,6 +83,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+
 // Can this Gaussian reach alpha >= 1/255 at ANY sample position inside [bx0,bx1]x[by0,by1]?
 // alpha = w*exp(-q(d)), q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  =>  needs  min_box q <= ln(255 w) =: tau.
 // Conservative (never culls a pair the per-pixel test would accept): tau carries a slack of 1% in alpha, plus a
@@ -521,18 +528,21 @@ __device__ __forceinline__ float row_scan_mul(float x)
         "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
     return x;
 }
-#define RING 128                 // list entries staged per wave (<= 15 left over + 64 new)
+// list entries staged per wave (<= 15 left over + 64 new): 96 slots (indices wrap by a conditional subtraction) keep the wave's LDS at
+// 9.75 KB = 16 waves per CU, what the registers allow as well; the matrix-core variant also uses the ring as transposition scratch
+__host__ __device__ constexpr int ring_of(int MODE) { return MODE == 0 ? 128 : 96; }
+template <int R> __device__ __forceinline__ int ring_wrap(int i) { return i >= R ? i - R : i; }       // 0 <= i < 2 R
 #define DUMP_FLOATS 320          // per-wave scratch: junk target of the non-carry lanes (64 lanes + 15 steps x 16 floats), epilogue staging
 
 // developer statistics of the scan kernel (variant 8 only): [0] batches, [1] valid Gaussians, [2] steps run, [3] steps skipped,
 // [4] contributing (pixel, Gaussian) pairs, [5] Gaussians with at least one contributing pair in their batch
 __device__ unsigned long long g_bwd_stats[8];
 
-struct BwdLds {
+template <int RING> struct BwdLdsT {
     float4 ring[3][RING];        // [0] x y a' b'   [1] c' w depth id   [2] r g b list-position     (also: transposition scratch at setup)
     float4 pa[64];               // per pixel: gp0 gp1 gp2 gdepth
     float4 pb[64];               //            final_depth  bgT  last_contributor  T carry
-    float4 pc[64];               //            fx  fy  E carry  gacc carry
+    float4 pc[64];               //            fx  fy  (bgT - E) carry  gacc carry
     float4 pd[64];               //            gflow0 gflow1 gflow2 -                 (register-accumulation modes only)
     float dump[DUMP_FLOATS];
 };
@@ -554,12 +564,15 @@ __device__ __forceinline__ float row_scan_add_asm(float x)
 // EXTRA = false: no pixel of the quadrant has an upstream depth or flow gradient (training on the image alone) -- the depth term of
 // dL_dalpha and four of the 13 sums drop out (compile-time, so the common all-gradients path carries no extra branches)
 // SEP = true: every pixel of the quadrant sits at its integer coordinates (no sub-pixel offsets), so dx / dy are not read per pixel
-template <int MODE, bool EXTRA, bool SEP>
-__device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
+// NOLAST = true: the batch is full and all of its entries lie in front of every pixel's last contributor (wave-uniform, decided
+// by the caller from the first = deepest entry): the per-pair test `list position < last contributor` is dropped
+template <int MODE, bool EXTRA, bool SEP, bool NOLAST>
+__device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
                                           const float (&A1)[16], const float (&A2)[16], float *__restrict__ acc16)
 {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const int slot = (head + n) & (RING - 1);
+    constexpr int RING = ring_of(MODE);
+    const int slot = ring_wrap<RING>(head + n);
     const float4 g0 = L.ring[0][slot], g1 = L.ring[1][slot], g2 = L.ring[2][slot];
     const bool valid = n < nvalid;
     const float ap = g0.z, bp = g0.w, cp = g1.x, w = g1.y, dep = g1.z;
@@ -582,7 +595,8 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
     if (MODE == 2 || MODE == 4) pd_n = L.pd[g];
     unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
     const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
-    float dyr = 0.f, bdy = 0.f, cdydy = 0.f;
+    float dyr = 0.f, bdy = 0.f, cdydy = 0.f, dy2 = 0.f;
+    constexpr bool MOMENTS = SEP && MODE != 0;     // see the accumulation below
 #pragma unroll
     for (int s = 0; s < 16; s++) {
         const float4 pa = pa_n, pb = pb_n, pc = pc_n, pd = pd_n;
@@ -595,7 +609,7 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
         float dx, dy;
         if (SEP) {
             dx = (s & 1) ? dxo : dxe;
-            if ((s & 1) == 0) { dyr = g0.y - (oy + (float)(s >> 1)); bdy = bp * dyr; cdydy = (cp * dyr) * dyr; }
+            if ((s & 1) == 0) { dyr = g0.y - (oy + (float)(s >> 1)); bdy = bp * dyr; cdydy = (cp * dyr) * dyr; if (MOMENTS) dy2 = dyr * dyr; }
             dy = dyr;
         } else {
             dx = g0.x - pc.x; dy = g0.y - pc.y;
@@ -604,7 +618,8 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
         const float power2 = power2_rows(dx, ap, bdy, cdydy);
         const float G = __builtin_amdgcn_exp2f(power2);
         const float alpha = fminf(0.99f, w * G);
-        const lanemask ok = LANES(orig < __float_as_uint(pb.z)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
+        const lanemask ok = NOLAST ? (LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)))
+                                   : (LANES(orig < __float_as_uint(pb.z)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)));
         if (MODE == 4) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         const float alpha_m = select_f(ok, alpha, 0.f);
@@ -615,11 +630,12 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
         const float dcc = alpha_m * T;                                  // dchannel_dcolor
         const float cgp = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z;      // c . dL_dpixel
         const float e = dcc * cgp;
-        const float E = pc.z + row_scan_add_asm(e);
+        // the carry slot holds Q = bgT - E (E = sum of e over everything behind this batch): one subtraction gives bgT - E_inclusive
+        const float Q = pc.z - row_scan_add_asm(e);
         // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha).
-        // With e inv = (c . dL_dpixel) T (inv - 1) the colour and background terms collapse to inv ((c . dL_dpixel) T - E + bgT)
+        // With e inv = (c . dL_dpixel) T (inv - 1) the colour and background terms collapse to inv ((c . dL_dpixel) T + bgT - E)
         // (E inclusive); the depth flag (0 or 1) is folded into per-Gaussian constants: (final_depth - dep) flag = final_depth flag - dep flag
-        float dLa = (cgp * T + (pb.y - E)) * inv;
+        float dLa = (cgp * T + Q) * inv;
         float gdT = 0.f;
         if (EXTRA) {
             gdT = pa.w * T;                                             // dL_ddepth T; the flag of the dL_dmean2D.z sum is applied per Gaussian
@@ -641,13 +657,20 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
             if (EXTRA) v[2] += alpha_m * gdT;
             v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
             if (EXTRA) { v[10] += dcc * pd.x; v[11] += dcc * pd.y; v[12] += dcc * pd.z; }
-            v[0] += sG * dx; v[1] += sG * dy;
-            const float sdx = sG * dx;
-            v[3] += sdx * dx; v[4] += sdx * dy; v[5] += (sG * dy) * dy;
+            if (MOMENTS) {
+                // dx takes one value on the even steps and one on the odd steps of a batch: the sums over sG dx, sG dx^2, sG dx dy
+                // follow from S = sum sG and Y = sum sG dy kept separately for the two step parities (7 VALU per step -> 3)
+                if (s & 1) { v[3] += sG; v[4] += sG * dy; } else { v[0] += sG; v[1] += sG * dy; }
+                v[5] += sG * dy2;
+            } else {
+                v[0] += sG * dx; v[1] += sG * dy;
+                const float sdx = sG * dx;
+                v[3] += sdx * dx; v[4] += sdx * dy; v[5] += (sG * dy) * dy;
+            }
             v[6] += s6;
         }
         wT[16 * s] = T;
-        wE[16 * s] = E;
+        wE[16 * s] = Q;
     }
     // The sums leave the wave like in the per-pixel kernel -- one atomic instruction covers whole 64-byte accumulator rows
     // (13 neighbouring floats per Gaussian, 4 Gaussians per instruction) -- after a 1 KB transposition through LDS; 13 separate
@@ -660,6 +683,13 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
     wave_lds_sync();
     float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
     if (MODE == 2 || MODE == 4) {
+        if (MOMENTS) {
+            const float Se = v[0], Ye = v[1], So = v[3], Yo = v[4];
+            v[0] = dxe * Se + dxo * So;
+            v[1] = Ye + Yo;
+            v[3] = (dxe * dxe) * Se + (dxo * dxo) * So;
+            v[4] = dxe * Ye + dxo * Yo;
+        }
         // every lane holds partial sums over ITS 16 pixels: add the four pixel-slot lanes of a Gaussian (lanes n, n+16, n+32, n+48)
 #pragma unroll
         for (int q = 0; q < 13; q++) {
@@ -698,7 +728,7 @@ __device__ __forceinline__ void bwd_batch(BwdLds &L, int head, int nvalid, float
     for (int r = 0; r < 4; r++) {
         const int gn = 4 * r + g;                  // Gaussian of this lane in round r; accumulator slot = n
         const float val = L.dump[17 * gn + n];
-        const uint32_t gid = __float_as_uint(L.ring[1][(head + gn) & (RING - 1)].w);
+        const uint32_t gid = __float_as_uint(L.ring[1][ring_wrap<RING>(head + gn)].w);
         if (gn < nvalid && n < 13) unsafeAtomicAdd(acc16 + 16 * (size_t)gid + n, val);
     }
     wave_lds_sync();
@@ -716,18 +746,20 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
     float *__restrict__ acc16, const unsigned long long *__restrict__ cull_masks)
 {
-    __shared__ BwdLds lds[WPB];
+    constexpr int RING = ring_of(MODE);
+    __shared__ BwdLdsT<RING> lds[WPB];
     int tile, quad;
     tile_of_block<WPB>(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
     const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
-    BwdLds &L = lds[wave];
+    BwdLdsT<RING> &L = lds[wave];
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);      // setup: lane = pixel (x = lane & 7, y = lane >> 3)
     const uint2 range = ranges[tile];
     const size_t HW = (size_t)H * W;
     const uint32_t last_contributor = p.inside ? n_contrib[p.pix_id] : 0u;
     const uint32_t deepest = wave_max_u32(last_contributor);     // nothing behind it touches this quadrant
     if (deepest == 0) return;
+    const uint32_t min_last = wave_min_u32(last_contributor);    // entries in front of it are in front of every pixel's last contributor
 
     // ---- per-pixel constants, CR/backward.cu:489-549
     const float T_final = p.inside ? final_Ts[p.pix_id] : 0.f;
@@ -748,7 +780,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float xr = p.fx - ox, yr = p.fy - oy;
     L.pa[lane] = make_float4(gp0, gp1, gp2, gdepth);
     L.pb[lane] = make_float4(final_depth, bgT, __uint_as_float(last_contributor), T_final);
-    L.pc[lane] = make_float4(p.fx, p.fy, 0.f, gacc);
+    L.pc[lane] = make_float4(p.fx, p.fy, bgT, gacc);             // z: bgT - E carry (E = 0 behind the deepest contributor)
     if (MODE == 2 || MODE == 4) L.pd[lane] = make_float4(gflow0, gflow1, gflow2, 0.f);
     // wave-uniform: which optional upstream gradients take part in this quadrant at all (training on the image alone has none of them)
     const bool use_gacc = LANES(gacc != 0.0f) != 0;
@@ -788,7 +820,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
         wave_lds_sync();
     }
 
-    int head = 0, tail = 0;                                       // wave-uniform ring indices (monotonic; slot = index & (RING-1))
+    int head = 0, tail = 0, count = 0;                            // wave-uniform ring indices in [0, RING) and the number of staged entries
     {
         // The forward kernel walked this list in the same 64-entry chunks and left the survivors of its quadrant cull as one 64-bit
         // mask per chunk: no gather / test of the ~70 % of entries that miss the quadrant.  Chunks from the deepest contributor
@@ -806,20 +838,26 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
                 const uint32_t id = point_list[range.x + k];
                 const float4 *r = records + 4 * (size_t)id;
                 const float4 q0 = r[0], q2 = r[2];
-                const int slot = (tail + __popcll(b == 63 ? 0ull : (mask >> (b + 1)))) & (RING - 1);
+                const int slot = ring_wrap<RING>(tail + __popcll(b == 63 ? 0ull : (mask >> (b + 1))));
                 L.ring[0][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
                 L.ring[1][slot] = make_float4(r[1].x * kHalfLog2e, r[3].w, q2.x, __uint_as_float(id));
                 L.ring[2][slot] = make_float4(q2.y, q2.z, q2.w, __uint_as_float((uint32_t)k));
             }
-            tail += __popcll(mask);
+            tail = ring_wrap<RING>(tail + __popcll(mask));
+            count += __popcll(mask);
             wave_lds_sync();
-            while (tail - head >= 16 || (c == 0 && tail > head)) {
-                const int nb = (tail - head) < 16 ? (tail - head) : 16;
-                if (MODE == 0) bwd_batch<MODE, true, false>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
-                else if (!sep) bwd_batch<MODE, true, false>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
-                else if (use_extra) bwd_batch<MODE, true, true>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
-                else bwd_batch<MODE, false, true>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16);
-                head += nb;
+            while (count >= 16 || (c == 0 && count > 0)) {
+                const int nb = count < 16 ? count : 16;
+                // first entry of the batch = its deepest: wave-uniform read of its list position
+                const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(L.ring[2][head].w));
+                const bool nolast = nb == 16 && kfirst < min_last;
+#define BATCH(E, S, N) bwd_batch<MODE, E, S, N>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16)
+                if (MODE == 0 || !sep) BATCH(true, false, false);
+                else if (use_extra) { if (nolast) BATCH(true, true, true); else BATCH(true, true, false); }
+                else { if (nolast) BATCH(false, true, true); else BATCH(false, true, false); }
+#undef BATCH
+                head = ring_wrap<RING>(head + nb);
+                count -= nb;
                 wave_lds_sync();
             }
         }

@@ -255,8 +255,9 @@ def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=6):
                 noise[k] = np.maximum(noise[k], np.abs(r[k].astype(np.float64) - base[k].astype(np.float64)))
         for k in DERIVED:
             n = np.asarray(noise[k], dtype=np.float64)
-            row = n.reshape(n.shape[0], -1).max(axis=1).reshape((n.shape[0],) + (1,) * (n.ndim - 1))
+            row = n.reshape(n.shape[0], -1).max(axis=1, initial=0.0).reshape((n.shape[0],) + (1,) * (n.ndim - 1))
             derived[k] = derived[k] + 8.0 * np.broadcast_to(row, n.shape)
+            out.setdefault("_stage_noise_max", {})[k] = float(n.max(initial=0.0))
     out.update(derived)
     return out
 
@@ -294,9 +295,14 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
             continue
         ratio = np.abs(a - b) / (bound[k].reshape(P, -1) + 1e-30)
         rep["grads"][k]["worst_err_over_bound"] = float(ratio.max())
+        # float32 evaluation noise of the per-Gaussian stage itself (largest response to +-2 ulp on its inputs): the reference's own
+        # float32 stage carries it too, so the per-tensor bar of the five DERIVED gradients is rel_tol * magnitude + 8 x this
+        rep["grads"][k]["stage_noise_max"] = bound.get("_stage_noise_max", {}).get(k, 0.0)
     REPORT.append(dict(kind="backward", tag=tag, P=int(P), R=int(fwd_o["num_rendered"]), W=int(fwd_o["W"]), H=int(fwd_o["H"]), **rep))
     for k, r in rep["grads"].items():
         assert r["worst_err_over_bound"] <= 1.0, (f"{k}: error exceeds the propagated accumulator bound by x{r['worst_err_over_bound']:.2f} "
                                                   f"(max-abs {r['max_abs']:.3e}, tensor max {r['ref_max']:.3e})")
-        assert r["rel_to_tensor_max"] <= rel_tol, f"{k}: max-abs error {r['max_abs']:.3e} is {r['rel_to_tensor_max']:.2e} of the tensor's magnitude {r['ref_max']:.3e} (> {rel_tol})"
+        bar = rel_tol * max(1.0, r["ref_max"]) + 8.0 * r.get("stage_noise_max", 0.0)
+        assert r["max_abs"] <= bar, (f"{k}: max-abs error {r['max_abs']:.3e} is {r['rel_to_tensor_max']:.2e} of the tensor's magnitude {r['ref_max']:.3e} "
+                                     f"(> {rel_tol} + 8 x stage noise {r.get('stage_noise_max', 0.0):.3e})")
     return rep
