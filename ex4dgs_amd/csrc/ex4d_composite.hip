@@ -541,9 +541,9 @@ __device__ unsigned long long g_bwd_stats[8];
 template <int RING> struct BwdLdsT {
     float4 ring[3][RING];        // [0] x y a' b'   [1] c' w depth id   [2] r g b list-position     (also: transposition scratch at setup)
     float4 pa[64];               // per pixel: gp0 gp1 gp2 gdepth
-    float4 pb[64];               //            final_depth  bgT  last_contributor  T carry
-    float4 pc[64];               //            fx  fy  (bgT - E) carry  gacc carry
-    float4 pd[64];               //            gflow0 gflow1 gflow2 -                 (register-accumulation modes only)
+    float4 pb[64];               //            final_depth  last_contributor  T carry  (bgT - E) carry      (the two carries: one 8-byte store)
+    float4 pc[64];               //            gflow0 gflow1 gflow2  gacc carry      (read only with depth / flow / acc gradients)
+    float4 pd[64];               //            fx  fy  -  -                          (read only with sub-pixel offsets)
     float dump[DUMP_FLOATS];
 };
 
@@ -586,13 +586,14 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
 #pragma unroll
     for (int q = 0; q < 13; q++) v[q] = 0.f;
     // carries of pixel 4s+g are written by lane n == 15 of row g; the other lanes write into the dump area (no exec masking)
-    float *wT = (n == 15) ? (&L.pb[g].w) : (&L.dump[lane]);
-    float *wE = (n == 15) ? (&L.pc[g].z) : (&L.dump[lane]);
+    float2 *wTQ = (n == 15) ? reinterpret_cast<float2 *>(&L.pb[g].z) : reinterpret_cast<float2 *>(&L.dump[2 * (lane & 31)]);
     float *wG = (n == 15) ? (&L.pc[g].w) : (&L.dump[lane]);
+    const bool rd_pc = (EXTRA && MODE != 0) || use_gacc;       // wave-uniform
     // the per-pixel constants / carries of step s + 1 are requested before step s runs (its LDS latency hides behind the step;
     // the carries of pixels 4(s+1)+g are last written one batch earlier, so the early read sees the right values)
-    float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = L.pc[g], pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 2 || MODE == 4) pd_n = L.pd[g];
+    float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = make_float4(0.f, 0.f, 0.f, 0.f), pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rd_pc) pc_n = L.pc[g];
+    if (!SEP) pd_n = L.pd[g];
     unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
     const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
     float dyr = 0.f, bdy = 0.f, cdydy = 0.f, dy2 = 0.f;
@@ -601,8 +602,9 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
     for (int s = 0; s < 16; s++) {
         const float4 pa = pa_n, pb = pb_n, pc = pc_n, pd = pd_n;
         if (s < 15) {
-            pa_n = L.pa[4 * s + 4 + g]; pb_n = L.pb[4 * s + 4 + g]; pc_n = L.pc[4 * s + 4 + g];
-            if (MODE == 2 || MODE == 4) pd_n = L.pd[4 * s + 4 + g];
+            pa_n = L.pa[4 * s + 4 + g]; pb_n = L.pb[4 * s + 4 + g];
+            if (rd_pc) pc_n = L.pc[4 * s + 4 + g];
+            if (!SEP) pd_n = L.pd[4 * s + 4 + g];
         }
         // the forward kernel's arithmetic: identical alpha, identical decisions.  Pixel 4s+g sits in column 4(s&1)+g, row s>>1 of
         // the quadrant: without sub-pixel offsets (SEP) dx takes two values per batch, dy / b'dy / (c'dy)dy change every other step
@@ -612,26 +614,26 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
             if ((s & 1) == 0) { dyr = g0.y - (oy + (float)(s >> 1)); bdy = bp * dyr; cdydy = (cp * dyr) * dyr; if (MOMENTS) dy2 = dyr * dyr; }
             dy = dyr;
         } else {
-            dx = g0.x - pc.x; dy = g0.y - pc.y;
+            dx = g0.x - pd.x; dy = g0.y - pd.y;
             bdy = bp * dy; cdydy = (cp * dy) * dy;
         }
         const float power2 = power2_rows(dx, ap, bdy, cdydy);
         const float G = __builtin_amdgcn_exp2f(power2);
         const float alpha = fminf(0.99f, w * G);
         const lanemask ok = NOLAST ? (LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)))
-                                   : (LANES(orig < __float_as_uint(pb.z)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)));
+                                   : (LANES(orig < __float_as_uint(pb.y)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)));
         if (MODE == 4) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         const float alpha_m = select_f(ok, alpha, 0.f);
         const float G_m = select_f(ok, G, 0.f);
         const float inv = __builtin_amdgcn_rcpf(1.f - alpha_m);
         // T_i = T_carry * prod_{j <= i} inv_j   (the carry is row-uniform: every lane of the row read it from LDS)
-        const float T = pb.w * row_scan_mul(inv);
+        const float T = pb.z * row_scan_mul(inv);
         const float dcc = alpha_m * T;                                  // dchannel_dcolor
         const float cgp = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z;      // c . dL_dpixel
         const float e = dcc * cgp;
         // the carry slot holds Q = bgT - E (E = sum of e over everything behind this batch): one subtraction gives bgT - E_inclusive
-        const float Q = pc.z - row_scan_add_asm(e);
+        const float Q = pb.w - row_scan_add_asm(e);
         // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha).
         // With e inv = (c . dL_dpixel) T (inv - 1) the colour and background terms collapse to inv ((c . dL_dpixel) T + bgT - E)
         // (E inclusive); the depth flag (0 or 1) is folded into per-Gaussian constants: (final_depth - dep) flag = final_depth flag - dep flag
@@ -656,7 +658,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
         } else {
             if (EXTRA) v[2] += alpha_m * gdT;
             v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
-            if (EXTRA) { v[10] += dcc * pd.x; v[11] += dcc * pd.y; v[12] += dcc * pd.z; }
+            if (EXTRA) { v[10] += dcc * pc.x; v[11] += dcc * pc.y; v[12] += dcc * pc.z; }
             if (MOMENTS) {
                 // dx takes one value on the even steps and one on the odd steps of a batch: the sums over sG dx, sG dx^2, sG dx dy
                 // follow from S = sum sG and Y = sum sG dy kept separately for the two step parities (7 VALU per step -> 3)
@@ -669,8 +671,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
             }
             v[6] += s6;
         }
-        wT[16 * s] = T;
-        wE[16 * s] = Q;
+        wTQ[8 * s] = make_float2(T, Q);
     }
     // The sums leave the wave like in the per-pixel kernel -- one atomic instruction covers whole 64-byte accumulator rows
     // (13 neighbouring floats per Gaussian, 4 Gaussians per instruction) -- after a 1 KB transposition through LDS; 13 separate
@@ -779,9 +780,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
     const float xr = p.fx - ox, yr = p.fy - oy;
     L.pa[lane] = make_float4(gp0, gp1, gp2, gdepth);
-    L.pb[lane] = make_float4(final_depth, bgT, __uint_as_float(last_contributor), T_final);
-    L.pc[lane] = make_float4(p.fx, p.fy, bgT, gacc);             // z: bgT - E carry (E = 0 behind the deepest contributor)
-    if (MODE == 2 || MODE == 4) L.pd[lane] = make_float4(gflow0, gflow1, gflow2, 0.f);
+    L.pb[lane] = make_float4(final_depth, __uint_as_float(last_contributor), T_final, bgT);     // w: bgT - E, E = 0 behind the deepest contributor
+    L.pc[lane] = make_float4(gflow0, gflow1, gflow2, gacc);
+    L.pd[lane] = make_float4(p.fx, p.fy, 0.f, 0.f);
     // wave-uniform: which optional upstream gradients take part in this quadrant at all (training on the image alone has none of them)
     const bool use_gacc = LANES(gacc != 0.0f) != 0;
     const bool sep = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
