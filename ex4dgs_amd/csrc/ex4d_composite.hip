@@ -547,6 +547,19 @@ template <int RING> struct BwdLdsT {
     float dump[DUMP_FLOATS];
 };
 
+// a reduced over lane ^ 32 in lanes 0-31, b in lanes 32-63 (v_permlane32_swap: lanes 32-63 of the first operand trade places with
+// lanes 0-31 of the second); the same over lane ^ 16 with rows: a in rows 0 and 2, b in rows 1 and 3
+__device__ __forceinline__ float halves_sum(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rows_sum(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ float row_scan_add_asm(float x)
 {
     asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -691,20 +704,35 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
             v[3] = (dxe * dxe) * Se + (dxo * dxo) * So;
             v[4] = dxe * Ye + dxo * Yo;
         }
-        // every lane holds partial sums over ITS 16 pixels: add the four pixel-slot lanes of a Gaussian (lanes n, n+16, n+32, n+48)
-#pragma unroll
-        for (int q = 0; q < 13; q++) {
-            v[q] += __shfl_xor(v[q], 16, 64);
-            v[q] += __shfl_xor(v[q], 32, 64);
+        // accumulator layout 0 (what the per-pixel kernel writes): dL_dmean2D.xy as sums of sG (2 a' dx + b' dy), sG (2 c' dy + b' dx)
+        // with the pre-scaled conic -- linear in the moments, so the conic is applied once per lane here
+        {
+            const float m0 = v[0], m1 = v[1];
+            v[0] = (2.f * ap) * m0 + bp * m1;
+            v[1] = (2.f * cp) * m1 + bp * m0;
+            v[2] *= flagf;
         }
-        if (g == 0) {
-            // accumulator layout 0 (what the per-pixel kernel writes): dL_dmean2D.xy as sums of sG (2 a' dx + b' dy), sG (2 c' dy + b' dx)
-            // with the pre-scaled conic -- linear in the moments, so the conic is applied once per Gaussian here
-            out[0] = (2.f * ap) * v[0] + bp * v[1];
-            out[1] = (2.f * cp) * v[1] + bp * v[0];
-            out[2] = v[2] * flagf;
+        // every lane holds partial sums over ITS 16 pixels: add the four pixel-slot lanes of a Gaussian (lanes n, n+16, n+32, n+48).
+        // Half / row exchanges reduce two values per instruction: v_permlane32_swap(a, b) leaves a.lo | b.lo and a.hi | b.hi, whose
+        // sum holds a reduced over the halves in lanes 0-31 and b in lanes 32-63; v_permlane16_swap does the same for odd / even
+        // rows.  Four sums (a, b, c, d) end up fully reduced in ONE register: row 0 a, row 1 c, row 2 b, row 3 d.
+        // 12 exchanges + 12 additions instead of 26 ds_bpermute + 26 additions.
 #pragma unroll
-            for (int q = 3; q < 13; q++) out[q] = v[q];
+        for (int j = 0; j < 4; j++) {
+            float quad4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) quad4[q] = (4 * j + q < 13) ? v[4 * j + q] : 0.f;
+            float x, y;
+            if (j < 3) {
+                x = halves_sum(quad4[0], quad4[1]);
+                y = halves_sum(quad4[2], quad4[3]);
+            } else {
+                x = halves_sum(quad4[0], quad4[0]);            // only v[12]: reduced in both halves ...
+                y = x;
+            }
+            const float r = rows_sum(x, y);                     // ... and in all four rows
+            const int q = 4 * j + ((g & 1) << 1) + (g >> 1);    // rows 0 1 2 3 hold sums a c b d
+            if (q < 13) out[q] = r;
         }
     } else {
         // lane (n, g) holds rows 4g..4g+3 of column n: sums of ITS Gaussian; moments about the quadrant origin -> Gaussian-centred
