@@ -16,6 +16,7 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 static inline int acc_layout_of(int variant) { return variant == 2 ? 1 : 0; }
 std::atomic<int> g_bwd_variant{4};
+std::atomic<int> g_tile_ids{0};      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...)
@@ -144,6 +145,15 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     return g;
 }
 
+// number of key bits needed for tile ids 0..T-1 (the reference's getHigherMsb over-estimates by design,
+// rasterizer_impl.cu:35-50; any bit count covering every tile id yields the identical stable order)
+int tile_bits(int T)
+{
+    int b = 1;
+    while ((1 << b) < T) b++;
+    return b;
+}
+
 BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *lay, size_t *total)
 {
     const int T = ((W + EX4D_TILE - 1) / EX4D_TILE) * ((H + EX4D_TILE - 1) / EX4D_TILE);
@@ -155,7 +165,10 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(n);
     b.vals_tmp = c.take<uint32_t>(n);
     b.keys_tmp = c.take<uint32_t>(n);
-    b.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words(R));
+    const int tb = tile_bits(T);
+    const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
+    b.sort_hist = c.take<uint32_t>(hw > hw2 ? hw : hw2);
+    b.ts_table = c.take<uint32_t>(ex4d_tile_sort_table_words(R, tb));
     b.cull_masks = c.take<unsigned long long>(ex4d_cull_mask_words(R, T));
     l.total = c.off;
     if (lay) *lay = l;
@@ -177,15 +190,6 @@ ImgState carve_img(void *buf, int W, int H, Ex4dImgLayout *lay, size_t *total)
     if (lay) *lay = l;
     if (total) *total = c.off;
     return s;
-}
-
-// number of key bits needed for tile ids 0..T-1 (the reference's getHigherMsb over-estimates by design,
-// rasterizer_impl.cu:35-50; any bit count covering every tile id yields the identical stable order)
-int tile_bits(int T)
-{
-    int b = 1;
-    while ((1 << b) < T) b++;
-    return b;
 }
 
 }  // namespace
@@ -302,15 +306,26 @@ static int forward_impl(
     uint32_t *v0 = (passes % 2 == 0) ? b.point_list : b.vals_tmp;
     uint32_t *k1 = (passes % 2 == 0) ? b.keys_tmp : b.tile_ids;
     uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
-    if (R > 0) {
-        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, k0, v0, stream), prm, stream);
+    if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
+        // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
+        // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, b.tile_ids, b.vals_tmp, stream), prm, stream);
         MARK(0, "duplicate");
-        bool res_a = true;
-        STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);
+        STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
+                                 R, tile_bits(T), b.sort_hist, b.ts_table, im.ranges, stream), prm, stream);
+        MARK(0, "tile_sort");
+        MARK(0, "tile_ranges");
+    } else {
+        if (R > 0) {
+            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, k0, v0, stream), prm, stream);
+            MARK(0, "duplicate");
+            bool res_a = true;
+            STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);
+        }
+        MARK(0, "tile_sort");
+        STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
+        MARK(0, "tile_ranges");
     }
-    MARK(0, "tile_sort");
-    STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
-    MARK(0, "tile_ranges");
     // 8. compositing
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
                                     out_color, out_depth, out_acc, out_flow, out_idx, b.cull_masks, g.total, stream), prm, stream);
@@ -448,6 +463,7 @@ int ex4d_backward_split_sh(
 int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 0 || value == 2 || value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }
 
@@ -457,6 +473,7 @@ int ex4d_get_option(const char *name)
 {
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "acc_layout")) return acc_layout_of(g_bwd_variant.load());
+    if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     return -1;
 }
 

@@ -36,10 +36,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t
     for (int b = threadIdx.x; b < BINS; b += RS_THREADS) h[b] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
-#pragma unroll 4
+    // all loads in flight before the first LDS atomic (clamped index instead of a branch per load)
+    uint32_t k[ITEMS];
+#pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+        k[it] = keys[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t i = base + it * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(k[it] >> shift) & mask], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < BINS; b += RS_THREADS) hist[(size_t)b * nblocks + blockIdx.x] = h[b];
@@ -80,10 +87,17 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
 //  phase 2  one barrier: per digit, exclusive scan over the 4 waves + block-local digit starts + global bases;
 //  phase 3  items go to their block-local sorted slot in LDS, one barrier, then the block streams the staged
 //           chunk out: neighbouring threads write neighbouring addresses of the same digit run (coalesced).
-template <int ITEMS, int BINS>
+// MODE 0: (key, value) pairs in, pairs out.
+// MODE 1: pairs in, ONE packed word out: (key & low_mask) << (32 - low_bits) | value  (pass A of the tile sort, below).
+// MODE 2: packed words in (digit = word >> shift), values out; the workgroup's item range and bucket come from the block table, its
+//         global digit starts from the bucket's span of the row-scanned histogram; also writes the tile ranges (pass B).
+struct TsBlock { uint32_t start, count, bucket, pad; };
+#define TS_FB_WORDS 260          // bk[0 .. 256]: first block of every bucket (fb[nbuckets ..] = number of blocks); bk[260 ..]: bucket starts
+template <int ITEMS, int BINS, int MODE>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-    uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist)
+    uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
+    int low_bits, const uint32_t *__restrict__ bk, const TsBlock *__restrict__ table, uint2 *__restrict__ ranges)
 {
     __shared__ uint32_t wave_cnt[4][BINS];        // per-wave digit counts -> exclusive block-local offsets
     __shared__ uint32_t local_start[BINS];        // first block-local slot of each digit
@@ -99,7 +113,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     constexpr uint32_t CHUNK = RS_THREADS * ITEMS;
-    const uint32_t base = blockIdx.x * CHUNK + wave * (CHUNK / 4);
+    uint32_t block_first = blockIdx.x * CHUNK, block_end = n, bucket = 0;
+    if (MODE == 2) {
+        const TsBlock tb = table[blockIdx.x];
+        if (tb.count == 0) return;                  // past the last block of the table (wave-uniform: whole workgroup)
+        block_first = tb.start; block_end = tb.start + tb.count; bucket = tb.bucket;
+    }
+    const uint32_t base = block_first + wave * (CHUNK / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
 #pragma unroll
@@ -107,14 +127,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         // unconditional loads from a clamped index (no exec-masked branch per item): the waits before the first ranking steps
         // can then count outstanding loads instead of draining all 32
         const uint32_t i = base + it * 64 + lane;
-        const uint32_t ic = i < n ? i : n - 1;
+        const uint32_t ic = i < block_end ? i : block_end - 1;
         key[it] = keys_in[ic];
-        val[it] = vals_in[ic];
+        val[it] = (MODE == 2) ? 0u : vals_in[ic];
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
-        const bool valid = i < n;
+        const bool valid = i < block_end;
         const uint32_t d = (key[it] >> shift) & mask;
         // lanes holding the same digit: per bit keep the ballot if my bit is set, its complement otherwise -- written as
         // ballot ^ (bit - 1) on 32-bit halves (plain xor/and; a select here compiles to the VOP2 v_cndmask that issues in ~24
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         // thread t owns the BPT consecutive digits t*BPT .. : exclusive scan over waves per digit, then exclusive scan over digits of
         // the block totals (and of the global digit totals, which gives every digit's global start)
         constexpr int BPT = BINS / RS_THREADS;
-        uint32_t c[BPT][4], tot[BPT], gtot[BPT];
+        uint32_t c[BPT][4], tot[BPT], gtot[BPT], pf[BPT];
         uint32_t tsum = 0, gsum = 0;
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
@@ -156,7 +176,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 #pragma unroll
             for (int w = 0; w < 4; w++) c[k][w] = live ? wave_cnt[w][d] : 0u;
             tot[k] = c[k][0] + c[k][1] + c[k][2] + c[k][3];
-            gtot[k] = live ? hist[(size_t)BINS * nblocks + d] : 0u;
+            if (MODE == 2) {
+                // items of this digit inside the bucket = difference of the row's exclusive prefix at the bucket's first block and
+                // at the next bucket's first block (blocks past the table hold zero counts, so the prefix there is the row total)
+                pf[k] = live ? hist[(size_t)d * nblocks + bk[bucket]] : 0u;
+                gtot[k] = live ? hist[(size_t)d * nblocks + bk[bucket + 1]] - pf[k] : 0u;
+            } else {
+                pf[k] = 0u;
+                gtot[k] = live ? hist[(size_t)BINS * nblocks + d] : 0u;
+            }
             tsum += tot[k]; gsum += gtot[k];
         }
         uint32_t x = tsum, gx = gsum;
@@ -169,12 +197,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         __syncthreads();
         uint32_t ls = x - tsum, gb = gx - gsum;
         for (int w = 0; w < wave; w++) { ls += scan_tmp[w]; gb += scan_tmp[4 + w]; }
+        if (MODE == 2) gb += bk[TS_FB_WORDS + bucket];          // the bucket's first output position
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
             const int d = tid * BPT + k;
             if (d < nbins) {
                 local_start[d] = ls;
-                global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x];
+                global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x] - pf[k];
+                // tile (bucket, d) occupies [gb, gb + gtot): identifyTileRanges (CR/rasterizer_impl.cu:118-140) without reading the keys
+                if (MODE == 2 && blockIdx.x == bk[bucket] && gtot[k] != 0u) ranges[((size_t)bucket << nbits) + d] = make_uint2(gb, gb + gtot[k]);
                 wave_cnt[0][d] = ls; wave_cnt[1][d] = ls + c[k][0]; wave_cnt[2][d] = ls + c[k][0] + c[k][1]; wave_cnt[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
             }
             ls += tot[k]; gb += gtot[k];
@@ -184,23 +215,98 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
-        if (i < n) {
+        if (i < block_end) {
             const uint32_t d = (key[it] >> shift) & mask;
             stage[wave_cnt[wave][d] + pos[it]] = make_uint2(key[it], val[it]);
         }
     }
     __syncthreads();
-    const uint32_t block_first = blockIdx.x * CHUNK;
-    const uint32_t count = (n - block_first) < CHUNK ? (n - block_first) : CHUNK;
+    const uint32_t count = (block_end - block_first) < CHUNK ? (block_end - block_first) : CHUNK;
 #pragma unroll 4
     for (uint32_t p = tid; p < count; p += RS_THREADS) {
         const uint2 kv = stage[p];
         const uint32_t d = (kv.x >> shift) & mask;
         const uint32_t dst = global_base[d] + (p - local_start[d]);
-        keys_out[dst] = kv.x;
-        vals_out[dst] = kv.y;
+        if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; }
+        if (MODE == 1) keys_out[dst] = ((kv.x & ((1u << low_bits) - 1u)) << (32 - low_bits)) | kv.y;
+        if (MODE == 2) {
+            vals_out[dst] = kv.x & (0xFFFFFFFFu >> nbits);
+            if (keys_out) keys_out[dst] = (bucket << nbits) | d;        // the sorted tile ids, on request only
+        }
     }
 }
+
+// Tile sort, MSD first (the instance count R is ~7.5x the Gaussian count; the sort is HBM-bound):
+//   pass A  stable partition by the HIGH digit of the tile id (buckets), writing ONE packed word per instance -- the low digit in the
+//           top bits, the Gaussian id below (4 bytes instead of the 8 of a key/value pair);
+//   table   the bucket starts (exclusive scan of the high-digit totals) and a block table: every bucket is cut into blocks of
+//           <= 4096 items, so no block straddles two buckets;
+//   pass B  per bucket, stable counting sort by the LOW digit: block histograms -> row scan -> scatter of the Gaussian ids alone.
+//           The (bucket, digit) counts are the tile ranges, so identifyTileRanges never reads 4 R bytes of keys.
+// Same result as the reference's single stable sort by (tile | depth): stable by high digit, then stable by low digit inside each
+// bucket = stable by the whole tile id.  HBM traffic per instance: 8 written by the duplication + (4 + 8 + 4) + (4 + 4 + 4) = 36 bytes
+// instead of 8 + 2 x (4 + 8 + 8) + 4 = 52.
+__global__ __launch_bounds__(256) void ts_block_table_kernel(const uint32_t *__restrict__ hist_totals, int nbuckets, uint32_t max_blocks,
+    uint32_t *__restrict__ bk, TsBlock *__restrict__ table)
+{
+    __shared__ uint32_t cnt_s[257], fb_s[257], st_s[257];
+    __shared__ uint32_t wave_sums[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cnt = tid < nbuckets ? hist_totals[tid] : 0u;
+    const uint32_t nblk = (cnt + RS_CHUNK - 1) / RS_CHUNK;
+    uint32_t x = cnt, y = nblk;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(x, o, 64), b = __shfl_up(y, o, 64); if (lane >= o) { x += a; y += b; } }
+    if (lane == 63) { wave_sums[wave] = x; wave_sums[4 + wave] = y; }
+    __syncthreads();
+    uint32_t st = x - cnt, fb = y - nblk;
+    for (int w = 0; w < wave; w++) { st += wave_sums[w]; fb += wave_sums[4 + w]; }
+    cnt_s[tid] = cnt; fb_s[tid] = fb; st_s[tid] = st;
+    if (tid == 255) { fb_s[256] = fb + nblk; st_s[256] = st + cnt; cnt_s[256] = 0; }
+    __syncthreads();
+    bk[tid] = fb_s[tid]; bk[TS_FB_WORDS + tid] = st_s[tid];
+    if (tid == 0) { bk[256] = fb_s[256]; bk[TS_FB_WORDS + 256] = st_s[256]; }
+    const uint32_t nb = fb_s[256];
+    for (uint32_t b = tid; b < max_blocks; b += 256) {
+        TsBlock t = { 0u, 0u, 0u, 0u };
+        if (b < nb) {
+            // the bucket owning block b: the LAST h with fb[h] <= b (empty buckets share their successor's first block and precede it)
+            uint32_t h = 0;
+#pragma unroll
+            for (uint32_t step = 128; step > 0; step >>= 1) if (fb_s[h + step] <= b) h += step;
+            const uint32_t within = (b - fb_s[h]) * RS_CHUNK;
+            t.start = st_s[h] + within;
+            t.count = cnt_s[h] - within < RS_CHUNK ? cnt_s[h] - within : RS_CHUNK;
+            t.bucket = h;
+        }
+        table[b] = t;
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t *__restrict__ words, const TsBlock *__restrict__ table,
+    int shift, uint32_t nblocks, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const TsBlock tb = table[blockIdx.x];
+    if (tb.count != 0) {
+        uint32_t k[RS_ITEMS];
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) {
+            const uint32_t i = it * RS_THREADS + threadIdx.x;
+            k[it] = words[tb.start + (i < tb.count ? i : tb.count - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) {
+            const uint32_t i = it * RS_THREADS + threadIdx.x;
+            if (i < tb.count) atomicAdd(&h[k[it] >> shift], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
 
 // ---------------------------------------------------------------- scan of tiles_touched in depth order
 __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint2 *__restrict__ rects,
@@ -362,17 +468,50 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         if (small) {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr);
         } else {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr);
         }
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
         *result_in_a = !*result_in_a;
         shift += nbits;
     }
+    return hipGetLastError();
+}
+
+// ---- MSD tile sort (see ts_block_table_kernel).  Applies when the tile id needs 9..16 bits and the Gaussian ids fit under the low digit.
+bool ex4d_tile_sort_msd_applies(int P, int tile_bits)
+{
+    if (tile_bits < 9 || tile_bits > 16) return false;
+    const int low_bits = (tile_bits + 1) / 2;
+    return (uint64_t)P <= (1ull << (32 - low_bits));
+}
+static inline uint32_t ts_max_blocks(uint32_t R, int tile_bits) { return rs_num_blocks(R) + (1u << (tile_bits - (tile_bits + 1) / 2)) + 1u; }
+size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits) { return (size_t)256 * (ts_max_blocks(R, tile_bits > 16 ? 16 : (tile_bits < 2 ? 2 : tile_bits)) + 1); }
+size_t ex4d_tile_sort_table_words(uint32_t R, int tile_bits) { return 2 * TS_FB_WORDS + 8 + 4 * (size_t)ts_max_blocks(R, tile_bits > 16 ? 16 : (tile_bits < 2 ? 2 : tile_bits)); }
+
+// keys / vals: the instances in depth order (from the duplication); packed: R words of scratch; point_list: the result; tile_ids_out:
+// optional (nullptr = not materialised); ranges must be zero (tiles without instances are never written)
+hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
+    uint32_t R, int tile_bits, uint32_t *hist, uint32_t *table_words, uint2 *ranges, hipStream_t stream)
+{
+    if (R == 0) return hipSuccess;
+    const int low_bits = (tile_bits + 1) / 2, high_bits = tile_bits - low_bits;
+    const uint32_t nbA = rs_num_blocks(R), nbB = ts_max_blocks(R, tile_bits);
+    uint32_t *bk = table_words;
+    TsBlock *table = reinterpret_cast<TsBlock *>(table_words + 2 * TS_FB_WORDS + 8);
+    hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist);
+    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << high_bits), dim3(256), 0, stream, nbA, hist, 256u);
+    hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 1>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, vals, packed, (uint32_t *)nullptr,
+        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, (const TsBlock *)nullptr, (uint2 *)nullptr);
+    hipLaunchKernelGGL(ts_block_table_kernel, dim3(1), dim3(256), 0, stream, hist + (size_t)256 * nbA, 1 << high_bits, nbB, bk, table);
+    hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, table, 32 - low_bits, nbB, hist);
+    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, hist, 256u);
+    hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list,
+        R, 32 - low_bits, low_bits, nbB, hist, low_bits, bk, table, ranges);
     return hipGetLastError();
 }
 

@@ -176,7 +176,8 @@ typedef struct Ex4dGeomLayout {
 } Ex4dGeomLayout;
 typedef struct Ex4dBinningLayout {
     size_t point_list;      /* uint32[R]           Gaussian ids sorted by (tile, depth, id): == reference point_list */
-    size_t tile_ids;        /* uint32[R]           tile id of every sorted instance (high word of the reference key) */
+    size_t tile_ids;        /* uint32[R]           tile id of every sorted instance (high word of the reference key); with option
+                                                   "binning_tile_ids" = 1 only, see ex4d_set_option */
     size_t total;
 } Ex4dBinningLayout;
 typedef struct Ex4dImgLayout {
@@ -199,6 +200,10 @@ size_t ex4d_backward_scratch_acc_offset(int32_t P);
 /* Tuning knobs (process-wide; results are the same within float rounding whatever the setting):
  *   "composite_bwd_variant"  0 = per-pixel lanes + LDS reduction, 2 = (Gaussian, pixel-slot) lanes with the sums on the matrix
  *                            cores, 4 = the same lanes with register accumulation (default), 8 = 4 + developer statistics
+ *   "binning_tile_ids"       1 = also write the sorted tile ids (Ex4dBinningLayout.tile_ids); 0 (default) = that region is scratch of
+ *                            the tile sort -- nothing downstream reads the ids, the tile ranges carry the same information.  (Images with
+ *                            <= 256 or > 65536 tiles, or more than 2^(32 - ceil(tile bits / 2)) Gaussians, take the key/value sort,
+ *                            which always writes them.)
  * ex4d_get_option additionally answers "acc_layout" (see above).  Returns EX4D_OK / the value, or an error / -1. */
 int ex4d_set_option(const char *name, int value);
 int ex4d_get_option(const char *name);

@@ -17,7 +17,11 @@ def hip_lib():
     """Builds (if stale) and loads libex4d_hip.so; GPU tests fail loudly if that is impossible."""
     from ex4dgs_amd import build, _C
     build.build()
-    return _C.load()
+    lib = _C.load()
+    # the parity tests compare the sorted tile ids with the oracle's: have the tile sort materialise them (default: ranges only);
+    # tests/test_gpu_round2.py checks that point_list and ranges are the same without them
+    _C.set_option("binning_tile_ids", 1)
+    return lib
 
 
 def pytest_sessionfinish(session, exitstatus):

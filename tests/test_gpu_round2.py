@@ -183,3 +183,30 @@ def test_trainer_with_sliced_optimizer_tracks_the_dense_one(hip_lib):
         moved = float((a - p0[n]).abs().max())
         assert moved > 0 and torch.isfinite(a).all(), n
         assert float((a - b).abs().max()) <= 1e-3 * moved + 1e-12, (n, float((a - b).abs().max()), moved)
+
+
+def test_tile_sort_without_materialised_tile_ids(hip_lib):
+    """Default setting of the MSD tile sort ("binning_tile_ids" = 0): point_list, the tile ranges and every output are the same as
+    with the ids written (what the parity tests run with), and the ids follow from the ranges.  Covers both sort paths: 1352x1014
+    (13 tile-id bits: MSD on packed words) and 128x96 (6 bits: key/value LSD sort, which always writes the ids)."""
+    from ex4dgs_amd import _C
+    from ex4dgs_amd.scene import SceneConfig
+    for cfg, P in (("cfg2", 30_000), (SceneConfig("small image", 3000, 128, 96, 110.0, seed=5), None)):
+        ins, st = h.scene_inputs(cfg, P=P)
+        assert _C.get_option("binning_tile_ids") == 1
+        a = h.gpu_forward_raw(ins, st)
+        try:
+            _C.set_option("binning_tile_ids", 0)
+            b = h.gpu_forward_raw(ins, st)
+        finally:
+            _C.set_option("binning_tile_ids", 1)
+        assert a["num_rendered"] == b["num_rendered"] > 0
+        for k in ("point_list", "ranges", "color", "depth", "acc", "flow", "idx", "n_contrib"):
+            assert torch.equal(a[k], b[k]), k
+        ranges = a["ranges"].long().cpu()
+        T = ranges.shape[0]
+        counts = ranges[:, 1] - ranges[:, 0]
+        ids = torch.repeat_interleave(torch.arange(T), counts)
+        assert torch.equal(ids, a["tile_ids"].long().cpu())
+        occupied = counts > 0
+        assert bool((ranges[occupied][1:, 0] == ranges[occupied][:-1, 1]).all()) and int(counts.sum()) == a["num_rendered"]
