@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
 //         global digit starts from the bucket's span of the row-scanned histogram; also writes the tile ranges (pass B).
 struct TsBlock { uint32_t start, count, bucket, pad; };
 #define TS_FB_WORDS 260          // bk[0 .. 256]: first block of every bucket (fb[nbuckets ..] = number of blocks); bk[260 ..]: bucket starts
-template <int ITEMS, int BINS, int MODE>
+// NBITS > 0: digit width known at compile time -- the match loop below unrolls (5 VALU per bit instead of a 12-slot loop body with
+// its scalar bookkeeping); 0 = any width at run time.
+template <int ITEMS, int BINS, int MODE, int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __shared__ uint32_t scan_tmp[8];
     __shared__ uint2 stage[RS_THREADS * ITEMS];             // (key, value) in block-local sorted order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (NBITS > 0) nbits = NBITS;
     const uint32_t mask = (1u << nbits) - 1u;
     const int nbins = 1 << nbits;
     for (int i = lane; i < BINS; i += 64) wave_cnt[wave][i] = 0;
@@ -141,12 +144,23 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         // cycles on gfx950 and made this loop the most expensive part of the pass)
         const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
         uint32_t plo = (uint32_t)vmask, phi = (uint32_t)(vmask >> 32);
-        for (int b = 0; b < nbits; b++) {
-            const uint32_t bit = (d >> b) & 1u;
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
-            const uint32_t flip = bit - 1u;                       // 0 when my bit is set, ~0 otherwise
-            plo &= (uint32_t)bal ^ flip;
-            phi &= (uint32_t)(bal >> 32) ^ flip;
+        if (NBITS > 0) {
+#pragma unroll
+            for (int b = 0; b < NBITS; b++) {
+                const uint64_t bal = __builtin_amdgcn_ballot_w64((d & (1u << b)) != 0u);
+                uint32_t flip;                                    // 0 when my bit is set, ~0 otherwise: my bit IS my lane's bit of the ballot
+                asm("v_cndmask_b32_e64 %0, -1, 0, %1" : "=v"(flip) : "s"(bal));
+                plo &= (uint32_t)bal ^ flip;
+                phi &= (uint32_t)(bal >> 32) ^ flip;
+            }
+        } else {
+            for (int b = 0; b < nbits; b++) {
+                const uint32_t bit = (d >> b) & 1u;
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
+                const uint32_t flip = bit - 1u;                   // 0 when my bit is set, ~0 otherwise
+                plo &= (uint32_t)bal ^ flip;
+                phi &= (uint32_t)(bal >> 32) ^ flip;
+            }
         }
         const uint64_t peers = ((uint64_t)phi << 32) | plo;
         const uint32_t rank = __popcll(peers & lt);
@@ -468,11 +482,13 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         if (small) {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr);
+#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr)
+            if (nbits == 9) RS_SMALL_SCATTER(9); else if (nbits == 8) RS_SMALL_SCATTER(8); else RS_SMALL_SCATTER(0);
+#undef RS_SMALL_SCATTER
         } else {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr);
         }
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
@@ -505,13 +521,17 @@ hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32
     TsBlock *table = reinterpret_cast<TsBlock *>(table_words + 2 * TS_FB_WORDS + 8);
     hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << high_bits), dim3(256), 0, stream, nbA, hist, 256u);
-    hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 1>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, vals, packed, (uint32_t *)nullptr,
-        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, (const TsBlock *)nullptr, (uint2 *)nullptr);
+#define TS_SCATTER_A(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 1, NB>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, vals, packed, (uint32_t *)nullptr, \
+        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, (const TsBlock *)nullptr, (uint2 *)nullptr)
+    if (high_bits == 6) TS_SCATTER_A(6); else if (high_bits == 7) TS_SCATTER_A(7); else if (high_bits == 8) TS_SCATTER_A(8); else TS_SCATTER_A(0);
+#undef TS_SCATTER_A
     hipLaunchKernelGGL(ts_block_table_kernel, dim3(1), dim3(256), 0, stream, hist + (size_t)256 * nbA, 1 << high_bits, nbB, bk, table);
     hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, table, 32 - low_bits, nbB, hist);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, hist, 256u);
-    hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list,
-        R, 32 - low_bits, low_bits, nbB, hist, low_bits, bk, table, ranges);
+#define TS_SCATTER_B(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2, NB>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list, \
+        R, 32 - low_bits, low_bits, nbB, hist, low_bits, bk, table, ranges)
+    if (low_bits == 7) TS_SCATTER_B(7); else if (low_bits == 8) TS_SCATTER_B(8); else TS_SCATTER_B(0);
+#undef TS_SCATTER_B
     return hipGetLastError();
 }
 
