@@ -13,11 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libex4d_hip.so")
 ARCH = "gfx950"
 
-# per-file flags: the per-Gaussian preprocess must not fuse multiply-adds (bit-exact integer decisions);
+# per-file flags: the per-Gaussian preprocess must not fuse multiply-adds (bit-exact integer decisions); its SLP-vectorised form
+# (v_pk_*_f32: the same IEEE results per element) needs 12-20 more VGPRs, which costs the backward kernel a wave per SIMD;
 # the compositing kernels are VALU-issue bound and v_pk_*_f32 is slower than two scalar ops there (measured:
 # -fno-slp-vectorize = -5 % kernel time), so the SLP vectoriser is off for that file
 SOURCES = {
-    "ex4d_preprocess.hip": ["-ffp-contract=off"],
+    "ex4d_preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "ex4d_binning.hip": [],
     "ex4d_composite.hip": ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"],
     "ex4d_api.hip": [],
@@ -55,7 +56,7 @@ def build(force=False, verbose=False, extra_flags=()):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + flags + list(extra_flags) + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + flags + list(extra_flags) + os.environ.get("EX4D_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

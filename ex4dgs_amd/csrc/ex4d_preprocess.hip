@@ -277,6 +277,74 @@ __device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, cons
     }
 }
 
+// half h of the wave's SH block straight into the half slice (no register prefetch): 6 coalesced 16-byte loads per lane
+__device__ __forceinline__ void wave_load_sh_half(const float *__restrict__ shs_wave, float *lds, int nrows, int nvec, int lane, int h)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
+    float4 t[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int q = (6 * h + i) * 64 + lane;
+        const int g = q / 12, v = q - 12 * g;
+        t[i] = (g < nrows && v < nvec) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int q = (6 * h + i) * 64 + lane;
+        const int g = q / 12 - 32 * h, v = q % 12;
+        *reinterpret_cast<float4 *>(lds + g * SH_ROW + 4 * v) = t[i];
+    }
+    wave_sync_lds();
+}
+// split layout, full aligned wave (see wave_issue_sh_split for the conditions): rows 32h .. 32h+31 of the rest / dc spans
+__device__ __forceinline__ bool wave_sh_split_stageable(const ShSplit &sp, int wave_first, int nrows)
+{
+    const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
+    if (nrows != 64 || !(all_dynamic || all_static)) return false;
+    const int part = all_dynamic ? 1 : 0;
+    const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
+    return ((((uintptr_t)(sp.rest[part] + r0 * 45)) | ((uintptr_t)(sp.dc[part] + r0 * 3))) & 15) == 0;
+}
+__device__ __forceinline__ void wave_load_sh_split_half(const ShSplit &sp, int wave_first, float *lds, int lane, int h)
+{
+    const int part = wave_first >= sp.n_static ? 1 : 0;
+    const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0)) + 32 * h;
+    const float4 *rest = reinterpret_cast<const float4 *>(sp.rest[part] + r0 * 45), *dc = reinterpret_cast<const float4 *>(sp.dc[part] + r0 * 3);
+    float4 t[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const int q = i * 64 + lane; t[i] = q < 360 ? rest[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    const float4 d = lane < 24 ? dc[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const int q = i * 64 + lane; if (q < 360) reinterpret_cast<float4 *>(lds)[q] = t[i]; }
+    if (lane < 24) reinterpret_cast<float4 *>(lds + SH_HALF_DC_OFFSET)[lane] = d;
+    wave_sync_lds();
+}
+
+// split layout, 32 rows of a full, aligned, non-straddling wave (wave_sh_split_stageable): two linear 16-byte copies
+__device__ __forceinline__ void wave_store_sh_split_half(const ShSplitGrad &sp, int first, const float *lds, int lane)
+{
+    wave_sync_lds();
+    const int part = first >= sp.n_static ? 1 : 0;
+    const size_t r0 = (size_t)(first - (part ? sp.n_static : 0));
+    float4 *rest = reinterpret_cast<float4 *>(sp.rest[part] + r0 * 45), *dc = reinterpret_cast<float4 *>(sp.dc[part] + r0 * 3);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const int q = i * 64 + lane; if (q < 360) rest[q] = reinterpret_cast<const float4 *>(lds)[q]; }
+    if (lane < 24) dc[lane] = reinterpret_cast<const float4 *>(lds + SH_HALF_DC_OFFSET)[lane];
+}
+
+// 32 rows (the half slice of the backward kernel)
+__device__ __forceinline__ void wave_store_sh_half(float *__restrict__ dst_half, const float *lds, int nrows, int lane)
+{
+    wave_sync_lds();
+    float4 *dst = reinterpret_cast<float4 *>(dst_half);
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int q = it * 64 + lane;
+        const int g = q / 12, v = q - 12 * g;
+        if (g < nrows) dst[q] = *reinterpret_cast<const float4 *>(lds + g * SH_ROW + 4 * v);
+    }
+}
+
 // The same rows taken from the four tensors the model keeps (dc [n,1,3] + rest [n,15,3], static rows first, then dynamic) --
 // saves the [P,16,3] concatenation pass (scene/c_gaussian_model.py:351-353) and, in the backward, the split of dL_dsh.
 // Inside one tensor the rows of a wave are ONE contiguous span (64 x 45 or 64 x 3 floats), so the copy is linear: no index
@@ -288,10 +356,12 @@ __device__ __forceinline__ void wave_copy_linear(float *__restrict__ dst, const 
 {
     if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
         const int n4 = nfloats >> 2;
+#pragma unroll 1
         for (int q = lane; q < n4; q += 64) reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(src)[q];
         const int e = (n4 << 2) + lane;
         if (e < nfloats) dst[e] = src[e];
     } else {
+#pragma unroll 1
         for (int e = lane; e < nfloats; e += 64) dst[e] = src[e];
     }
 }
@@ -307,10 +377,12 @@ __device__ __forceinline__ void wave_load_sh_split(const ShSplit &sp, int wave_f
             wave_copy_linear(lds, sp.rest[part] + r0 * 45, nrows * 45, lane);
             wave_copy_linear(lds + SH_SPLIT_DC_OFFSET, sp.dc[part] + r0 * 3, nrows * 3, lane);
         } else {
+#pragma unroll 1
             for (int e = lane; e < nrows * 45; e += 64) {
                 const int R = wave_first + e / 45, part = R >= sp.n_static;
                 lds[e] = sp.rest[part][(size_t)(R - (part ? sp.n_static : 0)) * 45 + e % 45];
             }
+#pragma unroll 1
             for (int e = lane; e < nrows * 3; e += 64) {
                 const int R = wave_first + e / 3, part = R >= sp.n_static;
                 lds[SH_SPLIT_DC_OFFSET + e] = sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3];
@@ -320,7 +392,7 @@ __device__ __forceinline__ void wave_load_sh_split(const ShSplit &sp, int wave_f
     wave_sync_lds();
 }
 
-__device__ __forceinline__ void wave_store_sh_split(const ShSplitGrad &sp, int wave_first, int nrows, const float *lds, int lane)
+__device__ __forceinline__ void wave_store_sh_split(const ShSplitGrad &sp, int wave_first, int nrows, const float *lds, int dc_offset, int lane)
 {
     wave_sync_lds();
     if (nrows <= 0) return;
@@ -329,15 +401,17 @@ __device__ __forceinline__ void wave_store_sh_split(const ShSplitGrad &sp, int w
         const int part = all_dynamic ? 1 : 0;
         const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
         wave_copy_linear(sp.rest[part] + r0 * 45, lds, nrows * 45, lane);
-        wave_copy_linear(sp.dc[part] + r0 * 3, lds + SH_SPLIT_DC_OFFSET, nrows * 3, lane);
+        wave_copy_linear(sp.dc[part] + r0 * 3, lds + dc_offset, nrows * 3, lane);
     } else {
+#pragma unroll 1
         for (int e = lane; e < nrows * 45; e += 64) {
             const int R = wave_first + e / 45, part = R >= sp.n_static;
             sp.rest[part][(size_t)(R - (part ? sp.n_static : 0)) * 45 + e % 45] = lds[e];
         }
+#pragma unroll 1
         for (int e = lane; e < nrows * 3; e += 64) {
             const int R = wave_first + e / 3, part = R >= sp.n_static;
-            sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3] = lds[SH_SPLIT_DC_OFFSET + e];
+            sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3] = lds[dc_offset + e];
         }
     }
 }
@@ -603,6 +677,59 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     if (threadIdx.x == 0) total_instances[blockIdx.x] = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
 }
 
+// d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): the part that reads the SH VALUES (sh[3 k + ch], k >= 1).
+// One inlined function, so that every caller reads through its own address space (LDS slice or global row).
+__device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float x, float y, float z,
+                                                  float (&dRGBdx)[3], float (&dRGBdy)[3], float (&dRGBdz)[3])
+{
+#define SHK(k) sh[3 * (k) + ch]
+    if (D > 0) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dRGBdx[ch] = -kSH_C1 * SHK(3);
+            dRGBdy[ch] = -kSH_C1 * SHK(1);
+            dRGBdz[ch] = kSH_C1 * SHK(2);
+        }
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
+                dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
+                dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
+            }
+            if (D > 2) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] += (
+                        kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
+                        kSH_C3[1] * SHK(10) * yz +
+                        kSH_C3[2] * SHK(11) * -2.f * xy +
+                        kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
+                        kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
+                        kSH_C3[5] * SHK(14) * 2.f * xz +
+                        kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
+                    dRGBdy[ch] += (
+                        kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
+                        kSH_C3[1] * SHK(10) * xz +
+                        kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
+                        kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
+                        kSH_C3[4] * SHK(13) * -2.f * xy +
+                        kSH_C3[5] * SHK(14) * -2.f * yz +
+                        kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
+                    dRGBdz[ch] += (
+                        kSH_C3[1] * SHK(10) * xy +
+                        kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
+                        kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
+                        kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
+                        kSH_C3[5] * SHK(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SHK
+}
+
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, float min_depth, float max_depth,
     uint8_t *__restrict__ present)
@@ -627,7 +754,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *_
 //             sG = dL_dG G and d = mean2D - pixel; rest as layout 0.  dG/dmean2D = -G (A dx + B dy, C dy + B dx) (CR/backward.cu:
 //             :664-670), dG/dconic = -1/2 G (dx^2, dx dy, dy^2) (:673-675): linear in those sums, conic (A, B, C) from the record.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+__global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const int32_t *__restrict__ radii, const float *__restrict__ shs,
     const uint8_t *__restrict__ clamped, const float *__restrict__ scales, const float *__restrict__ rotations,
@@ -639,24 +766,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir, const ShSplit sp, const ShSplitGrad gsp)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_LDS_FLOATS_PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_range = idx < P;
     const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
     const bool staged = (shs != nullptr || split) && (M == 16);
-    float *lds_row_base = sh_lds + wave * SH_LDS_FLOATS_PER_WAVE;
+    float *lds_row_base = sh_lds + wave * SH_HALF_FLOATS;
     const int wave_first = blockIdx.x * 256 + wave * 64;
     const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
     // ---- all global loads are issued before anything waits for one of them (see preprocess_fwd_kernel): the wave's SH block, the
     // Gaussian's accumulator row, mean, covariance, scale / rotation, clamp bits -- also for the ~20 % culled Gaussians, whose rows
     // are then simply not used
-    ShPrefetch pf;
-    bool prefetched = false;
-    if (staged) {
-        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane);
-        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, ((D + 1) * (D + 1) * 3 + 3) / 4, lane); prefetched = true; }
-    }
+    // the SH block is NOT prefetched into registers here (the forward kernel does that; measured: no difference for this kernel, which
+    // streams at ~5.2 TB/s either way): the half slices are loaded where they are consumed.  "prefetched" = the wave's rows can be staged
+    const bool prefetched = staged && (split ? wave_sh_split_stageable(sp, wave_first, wave_rows) : true);
     int in_radius = 0;
     float4 in_r0 = make_float4(0.f, 0.f, 0.f, 0.f), in_r1 = in_r0, in_r2 = in_r0, in_r3 = in_r0, in_q = in_r0;
     float in_mean[3] = { 0.f, 0.f, 0.f }, in_cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, in_s[3] = { 0.f, 0.f, 0.f };
@@ -677,16 +801,65 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         if (shs || split) in_clamped = clamped[idx];
     }
     const bool visible = in_range && (in_radius > 0);
-    if (staged) {
-        if (split) { if (prefetched) wave_commit_sh_split(lds_row_base, pf, lane); else wave_load_sh_split(sp, wave_first, wave_rows, lds_row_base, lane); }
-        else wave_commit_sh(lds_row_base, pf, lane);
-    }
     float g_mean2D[3] = { 0, 0, 0 }, g_color[3] = { 0, 0, 0 }, g_dir[3] = { 0, 0, 0 }, g_opacity = 0;
     float g_mean3D[3] = { 0, 0, 0 }, g_cov[6] = { 0, 0, 0, 0, 0, 0 }, g_scale[3] = { 0, 0, 0 }, g_rot[4] = { 0, 0, 0, 0 };
-    float g_sh[16][3];
+    // ---- SH backward first (CR/backward.cu:20-139): it consumes the prefetched SH block, whose 52 registers are then free for the
+    // projection / covariance arithmetic.  Its contribution to dL_dmean3D (sh_j) is added behind the projection terms below.
+    float3 sh_dir = make_float3(0.f, 0.f, 0.f), sh_dir_orig = make_float3(0.f, 0.f, 0.f);
+    float sh_dRGB[3] = { 0.f, 0.f, 0.f }, sh_j[3] = { 0.f, 0.f, 0.f };
+    if (visible && (shs || split)) {
+        const float3 dir_orig = make_float3(in_mean[0] - campos[0], in_mean[1] - campos[1], in_mean[2] - campos[2]);
+        const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+        sh_dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+        sh_dir_orig = dir_orig;
+        const float gc[3] = { in_r1.w, in_r2.x, in_r2.y };       // dL_dcolor (accumulators 7..9)
 #pragma unroll
-    for (int k = 0; k < 16; k++) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
-
+        for (int ch = 0; ch < 3; ch++) sh_dRGB[ch] = gc[ch] * (((in_clamped >> ch) & 1) ? 0.f : 1.f);
+    }
+    // ---- the part of the SH backward that reads the SH values, CR/backward.cu:57-139.  The prefetched block goes through HALF a slice
+    // of LDS, rows 32h .. 32h+31 at a time (6.5 KB per wave instead of 13: twice the workgroups per CU, like the forward kernel);
+    // the 32 lanes of the half evaluate the sums while the other 32 idle -- the kernel waits on memory, not on the VALU.
+    if (shs || split) {
+        float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+        const int r = lane & 31;
+        if (staged && prefetched) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (split) wave_load_sh_split_half(sp, wave_first, lds_row_base, lane, h);
+                else wave_load_sh_half(shs + (size_t)wave_first * 48, lds_row_base, wave_rows, ((D + 1) * (D + 1) * 3 + 3) / 4, lane, h);
+                if (visible && (lane >> 5) == h) {
+                    // split layout: rest rows at stride 45 (coefficient k >= 1 at 3 (k - 1)); only k >= 1 is read
+                    if (split) sh_direction_sums(lds_row_base + r * 45 - 3, D, sh_dir.x, sh_dir.y, sh_dir.z, dRGBdx, dRGBdy, dRGBdz);
+                    else sh_direction_sums(lds_row_base + r * SH_ROW, D, sh_dir.x, sh_dir.y, sh_dir.z, dRGBdx, dRGBdy, dRGBdz);
+                }
+                wave_sync_lds();
+            }
+        } else if (visible) {
+            // rows straight from memory: the one wave that straddles the static / dynamic boundary, misaligned tensors, M != 16
+            if (split) {
+                const int part = idx >= sp.n_static;
+                sh_direction_sums(sp.rest[part] + (size_t)(idx - (part ? sp.n_static : 0)) * 45 - 3, D, sh_dir.x, sh_dir.y, sh_dir.z, dRGBdx, dRGBdy, dRGBdz);
+            } else {
+                sh_direction_sums(shs + (size_t)idx * M * 3, D, sh_dir.x, sh_dir.y, sh_dir.z, dRGBdx, dRGBdy, dRGBdz);
+            }
+        }
+        if (visible) {
+            const float *dRGB = sh_dRGB;
+            const float3 dir_orig = sh_dir_orig;
+            const float3 dL_ddirv = make_float3(
+                dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
+                dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
+                dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]);
+            // Jacobian of the direction normalisation, CR/auxiliary.h:235-245
+            const float3 v = dir_orig;
+            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float jx = ((+sum2 - v.x * v.x) * dL_ddirv.x - v.y * v.x * dL_ddirv.y - v.z * v.x * dL_ddirv.z) * invsum32;
+            const float jy = (-v.x * v.y * dL_ddirv.x + (sum2 - v.y * v.y) * dL_ddirv.y - v.z * v.y * dL_ddirv.z) * invsum32;
+            const float jz = (-v.x * v.z * dL_ddirv.x - v.y * v.z * dL_ddirv.y + (sum2 - v.z * v.z) * dL_ddirv.z) * invsum32;
+            sh_j[0] = jx; sh_j[1] = jy; sh_j[2] = jz;       // added to dL_dmean3D behind its projection terms (the reference's order)
+        }
+    }
     if (visible) {
         float vm[16], pm[16];
 #pragma unroll
@@ -746,95 +919,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         g_mean3D[1] = (pm[4] * m_w - pm[7] * mul1) * gx + (pm[5] * m_w - pm[7] * mul2) * gy + (pm[6] * m_w - pm[7] * mul3) * gz;
         g_mean3D[2] = (pm[8] * m_w - pm[11] * mul1) * gx + (pm[9] * m_w - pm[11] * mul2) * gy + (pm[10] * m_w - pm[11] * mul3) * gz;
 
-        if (shs || split) {
-            // SH backward, CR/backward.cu:20-139
-            const float3 dir_orig = make_float3(mean.x - campos[0], mean.y - campos[1], mean.z - campos[2]);
-            const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-            const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-            // split layout: rest rows at stride 45 (coefficient k >= 1 at 3 (k - 1)); only k >= 1 is read below
-            const float *sh = split ? (lds_row_base + lane * 45 - 3) : (staged ? (lds_row_base + lane * SH_ROW) : (shs + (size_t)idx * M * 3));
-            const uint8_t cl = in_clamped;
-            float dRGB[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) dRGB[ch] = g_color[ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
-            float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
-#define SHK(k) sh[3 * (k) + ch]
-#define DSH(k, coefexpr) { const float c_ = (coefexpr); g_sh[k][0] = c_ * dRGB[0]; g_sh[k][1] = c_ * dRGB[1]; g_sh[k][2] = c_ * dRGB[2]; }
-            DSH(0, kSH_C0)
-            if (D > 0) {
-                DSH(1, -kSH_C1 * y)
-                DSH(2, kSH_C1 * z)
-                DSH(3, -kSH_C1 * x)
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    dRGBdx[ch] = -kSH_C1 * SHK(3);
-                    dRGBdy[ch] = -kSH_C1 * SHK(1);
-                    dRGBdz[ch] = kSH_C1 * SHK(2);
-                }
-                if (D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    DSH(4, kSH_C2[0] * xy)
-                    DSH(5, kSH_C2[1] * yz)
-                    DSH(6, kSH_C2[2] * (2.f * zz - xx - yy))
-                    DSH(7, kSH_C2[3] * xz)
-                    DSH(8, kSH_C2[4] * (xx - yy))
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
-                        dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
-                        dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
-                    }
-                    if (D > 2) {
-                        DSH(9, kSH_C3[0] * y * (3.f * xx - yy))
-                        DSH(10, kSH_C3[1] * xy * z)
-                        DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy))
-                        DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy))
-                        DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy))
-                        DSH(14, kSH_C3[5] * z * (xx - yy))
-                        DSH(15, kSH_C3[6] * x * (xx - 3.f * yy))
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            dRGBdx[ch] += (
-                                kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
-                                kSH_C3[1] * SHK(10) * yz +
-                                kSH_C3[2] * SHK(11) * -2.f * xy +
-                                kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
-                                kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
-                                kSH_C3[5] * SHK(14) * 2.f * xz +
-                                kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
-                            dRGBdy[ch] += (
-                                kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
-                                kSH_C3[1] * SHK(10) * xz +
-                                kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
-                                kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
-                                kSH_C3[4] * SHK(13) * -2.f * xy +
-                                kSH_C3[5] * SHK(14) * -2.f * yz +
-                                kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
-                            dRGBdz[ch] += (
-                                kSH_C3[1] * SHK(10) * xy +
-                                kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
-                                kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
-                                kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
-                                kSH_C3[5] * SHK(14) * (xx - yy));
-                        }
-                    }
-                }
-            }
-#undef SHK
-#undef DSH
-            const float3 dL_ddirv = make_float3(
-                dRGBdx[0] * dRGB[0] + dRGBdx[1] * dRGB[1] + dRGBdx[2] * dRGB[2],
-                dRGBdy[0] * dRGB[0] + dRGBdy[1] * dRGB[1] + dRGBdy[2] * dRGB[2],
-                dRGBdz[0] * dRGB[0] + dRGBdz[1] * dRGB[1] + dRGBdz[2] * dRGB[2]);
-            // Jacobian of the direction normalisation, CR/auxiliary.h:235-245
-            const float3 v = dir_orig;
-            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-            const float jx = ((+sum2 - v.x * v.x) * dL_ddirv.x - v.y * v.x * dL_ddirv.y - v.z * v.x * dL_ddirv.z) * invsum32;
-            const float jy = (-v.x * v.y * dL_ddirv.x + (sum2 - v.y * v.y) * dL_ddirv.y - v.z * v.y * dL_ddirv.z) * invsum32;
-            const float jz = (-v.x * v.z * dL_ddirv.x - v.y * v.z * dL_ddirv.y + (sum2 - v.z * v.z) * dL_ddirv.z) * invsum32;
-            g_mean3D[0] += jx; g_mean3D[1] += jy; g_mean3D[2] += jz;
-        }
+    }
+    if (visible) {
+        g_mean3D[0] += sh_j[0]; g_mean3D[1] += sh_j[1]; g_mean3D[2] += sh_j[2];
         if (scales) {
             // cov3D backward, CR/backward.cu:304-367 (gradient w.r.t. the raw quaternion)
             const float4 q = in_q;
@@ -872,29 +959,89 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         }
     }
     // every output row written exactly once (replaces the ten torch::zeros of DGR/rasterize_points.cu:178-187)
-    if (M == 16) {
-        // dL_dsh of the wave = one contiguous 12 KB span: stage the rows in LDS, store fully coalesced
-        wave_sync_lds();                       // all lanes finished reading their SH rows
-        if (split) {
+    // dL_dsh rows, CR/backward.cu:45-131: basis(direction) x dL_dRGB -- formed here, not next to the sums above, so that the 48 values
+    // are not live across the covariance backward
+    float g_sh[16][3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) lds_row_base[SH_SPLIT_DC_OFFSET + lane * 3 + ch] = g_sh[0][ch];
+    for (int k = 0; k < 16; k++) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
+    if (visible && (shs || split)) {
+        const float x = sh_dir.x, y = sh_dir.y, z = sh_dir.z;
+        const float *dRGB = sh_dRGB;
+#define DSH(k, coefexpr) { const float c_ = (coefexpr); g_sh[k][0] = c_ * dRGB[0]; g_sh[k][1] = c_ * dRGB[1]; g_sh[k][2] = c_ * dRGB[2]; }
+        DSH(0, kSH_C0)
+        if (D > 0) {
+            DSH(1, -kSH_C1 * y)
+            DSH(2, kSH_C1 * z)
+            DSH(3, -kSH_C1 * x)
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                DSH(4, kSH_C2[0] * xy)
+                DSH(5, kSH_C2[1] * yz)
+                DSH(6, kSH_C2[2] * (2.f * zz - xx - yy))
+                DSH(7, kSH_C2[3] * xz)
+                DSH(8, kSH_C2[4] * (xx - yy))
+                if (D > 2) {
+                    DSH(9, kSH_C3[0] * y * (3.f * xx - yy))
+                    DSH(10, kSH_C3[1] * xy * z)
+                    DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy))
+                    DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy))
+                    DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy))
+                    DSH(14, kSH_C3[5] * z * (xx - yy))
+                    DSH(15, kSH_C3[6] * x * (xx - 3.f * yy))
+                }
+            }
+        }
+#undef DSH
+    }
+    bool store_staged = prefetched;              // the gradient tensors need the same 16-byte alignment of the wave's spans as the inputs
+    if (split && prefetched) {
+        const int part = wave_first >= gsp.n_static ? 1 : 0;
+        const size_t r0 = (size_t)(wave_first - (part ? gsp.n_static : 0));
+        store_staged = ((((uintptr_t)(gsp.rest[part] + r0 * 45)) | ((uintptr_t)(gsp.dc[part] + r0 * 3))) & 15) == 0;
+    }
+    if (M == 16 && split && !store_staged) {
+        // the one wave that straddles the static / dynamic boundary (or misaligned tensors): every lane stores its own row
+        if (in_range) {
+            const int part = idx >= gsp.n_static;
+            const size_t row = (size_t)(idx - (part ? gsp.n_static : 0));
+            float *dc = gsp.dc[part] + row * 3, *rest = gsp.rest[part] + row * 45;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dc[ch] = g_sh[0][ch];
 #pragma unroll
             for (int k = 1; k < 16; k++)
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) lds_row_base[lane * 45 + 3 * (k - 1) + ch] = g_sh[k][ch];
-        } else {
-            float4 *row = reinterpret_cast<float4 *>(lds_row_base + lane * SH_ROW);
-#pragma unroll
-            for (int v = 0; v < 12; v++) {
-                float t[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
-                row[v] = make_float4(t[0], t[1], t[2], t[3]);
-            }
+                for (int ch = 0; ch < 3; ch++) rest[3 * (k - 1) + ch] = g_sh[k][ch];
         }
-        const int nrows_sh = (P - wave_first) < 64 ? (P - wave_first) : 64;
-        if (split) wave_store_sh_split(gsp, wave_first, nrows_sh, lds_row_base, lane);
-        else wave_store_sh(dL_dsh + (size_t)wave_first * 48, lds_row_base, nrows_sh, lane);
+    } else if (M == 16) {
+        // dL_dsh of the wave = one contiguous 12 KB span: stage 32 rows at a time in LDS, store fully coalesced
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            wave_sync_lds();
+            if ((lane >> 5) == h) {
+                const int r = lane & 31;
+                if (split) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) lds_row_base[SH_HALF_DC_OFFSET + r * 3 + ch] = g_sh[0][ch];
+#pragma unroll
+                    for (int k = 1; k < 16; k++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) lds_row_base[r * 45 + 3 * (k - 1) + ch] = g_sh[k][ch];
+                } else {
+                    float4 *row = reinterpret_cast<float4 *>(lds_row_base + r * SH_ROW);
+#pragma unroll
+                    for (int v = 0; v < 12; v++) {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const int f = 4 * v + e; t[e] = g_sh[f / 3][f % 3]; }
+                        row[v] = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            }
+            const int first = wave_first + 32 * h;
+            const int nrows_sh = (P - first) < 32 ? (P - first) : 32;       // <= 0: nothing
+            if (split) wave_store_sh_split_half(gsp, first, lds_row_base, lane);
+            else wave_store_sh_half(dL_dsh + (size_t)first * 48, lds_row_base, nrows_sh, lane);
+        }
         wave_sync_lds();
     }
     {
