@@ -179,7 +179,49 @@ def model_step_timing(cfg_name, dev, grads, steps=20, warmup=5, points=None):
         torch.cuda.synchronize()
         out[tag + "_host_side_full_iter_with_radam_ms"] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
         del model, opt
-    out["what"] = ("*_getters_ms_per_frame: getters (xyz/rotation/opacity/scaling/features at t) + rasterizer fwd+bwd to the model "
+    # the same full iteration through the compiled host path (include/ex4d_trainer.h: one C++ call per iteration, persistent workspace,
+    # keyframe gradients as slices), at this size and at 300 k Gaussians where the Python host work used to bound the iteration
+    try:
+        from ex4dgs_amd.native_trainer import NativeTrainer
+        from ex4dgs_amd.trainer import FrameTrainer
+        from ex4dgs_amd.loss import l1_ssim_loss as _loss
+        for tag, npts in (("", points), ("_300k", 300_000)):
+            model, cam, bg = make_scene(cfg_name, P=npts, device=dev, fused=True)
+            cam = cam.to(dev); bg = bg.to(dev)
+            gt = torch.rand(3, cfg.height, cfg.width, device=dev)
+            lrs = {n: 1e-7 for n in model.PARAM_NAMES}
+            nt = NativeTrainer(model, cam, optimizer=True, lrs=lrs, near=cfg.min_depth, far=cfg.max_depth)
+            stamps = [0, 137, 299]
+            for i in range(warmup + 3):
+                nt.step(cam, bg, stamps[i % 3], gt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                nt.step(cam, bg, stamps[i % 3], gt)
+            t_host = time.perf_counter() - t0          # time the host needed to enqueue the iterations (the GPU runs behind)
+            torch.cuda.synchronize()
+            out["native_host_full_iter_with_radam_ms" + tag] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+            out["native_host_enqueue_ms" + tag] = round(1e3 * t_host / steps, 4)
+            out["native_host_workspace_MB" + tag] = round(nt.bytes() / 2 ** 20, 1)
+            nt.close()
+            if tag:
+                ft = FrameTrainer(model, optimizer=True, lrs=lrs)
+                upg = lambda o: ([_loss(o["render"], gt, 0.2)[0]], [None])
+                for i in range(warmup + 3):
+                    ft.step(cam, bg, stamps[i % 3], upg, near=cfg.min_depth, far=cfg.max_depth)
+                ft.flush(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    ft.step(cam, bg, stamps[i % 3], upg, near=cfg.min_depth, far=cfg.max_depth)
+                ft.flush(); torch.cuda.synchronize()
+                out["python_host_full_iter_with_radam_ms" + tag] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+                del ft
+            del model, nt
+    except Exception as e:      # reported, not fatal for the headline line
+        out["native_host_error"] = repr(e)
+    out["what"] = ("native_host_*: the full iteration (getters, render, L1+SSIM, backward, RAdam) through ex4d_trainer_step, "
+                   "python_host_*: the same kernels sequenced by trainer.FrameTrainer; "
+                   "*_getters_ms_per_frame: getters (xyz/rotation/opacity/scaling/features at t) + rasterizer fwd+bwd to the model "
                    "parameters; *_train_iter_ms: the same plus the L1+SSIM loss and error maps of train.py:144-151 "
                    "(torch = the reference's op composition, fused = ex4d_attributes + ex4d_l1_ssim); *_full_iter_with_radam_ms: plus "
                    "optimizer.step() + zero_grad (torch.optim.RAdam vs FusedRAdam); 1 GPU, same HIP rasterizer in both")

@@ -26,6 +26,7 @@ SOURCES = {
     "ex4d_loss.hip": [],
     "ex4d_optim.hip": ["-ffp-contract=off"],
     "ex4d_knn.hip": ["-ffp-contract=off"],
+    "ex4d_trainer.hip": [],          # host code only: the compiled host path of one training iteration (include/ex4d_trainer.h)
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
@@ -48,7 +49,7 @@ def build(force=False, verbose=False, extra_flags=()):
     """Compile every HIP source for gfx950 and link libex4d_hip.so.  Returns the library path."""
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "ex4d_internal.h"), os.path.join(HERE, "..", "include", "ex4d_rasterizer.h"),
-               os.path.join(HERE, "..", "include", "ex4d_attributes.h"), os.path.join(HERE, "..", "include", "ex4d_loss.h"), os.path.join(HERE, "..", "include", "ex4d_optim.h"), os.path.join(HERE, "..", "include", "ex4d_knn.h"),
+               os.path.join(HERE, "..", "include", "ex4d_attributes.h"), os.path.join(HERE, "..", "include", "ex4d_loss.h"), os.path.join(HERE, "..", "include", "ex4d_optim.h"), os.path.join(HERE, "..", "include", "ex4d_knn.h"), os.path.join(HERE, "..", "include", "ex4d_trainer.h"),
                os.path.abspath(__file__)]
     objs = []
     for src, flags in SOURCES.items():

@@ -451,7 +451,12 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     hdr5 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_knn.h")).read(), flags=re.S)
     declared5 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr5))
     assert declared5 == set(knn_mod.EXPORTS), declared5 ^ set(knn_mod.EXPORTS)
-    declared |= declared2 | declared3 | declared4 | declared5
+    from ex4dgs_amd import native_trainer as nt_mod
+    hdr6 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_trainer.h")).read(), flags=re.S)
+    declared6 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr6))
+    assert declared6 == set(nt_mod.EXPORTS), declared6 ^ set(nt_mod.EXPORTS)
+    assert ctypes.sizeof(nt_mod.Ex4dTrainerConfig) == 280 and nt_mod.Ex4dTrainerConfig.optimizer.offset == 272
+    declared |= declared2 | declared3 | declared4 | declared5 | declared6
     handle = ctypes.CDLL(lib)
     for name in declared:
         assert hasattr(handle, name), name

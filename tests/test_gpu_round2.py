@@ -210,3 +210,63 @@ def test_tile_sort_without_materialised_tile_ids(hip_lib):
         assert torch.equal(ids, a["tile_ids"].long().cpu())
         occupied = counts > 0
         assert bool((ranges[occupied][1:, 0] == ranges[occupied][:-1, 1]).all()) and int(counts.sum()) == a["num_rendered"]
+
+
+def test_compiled_host_path_matches_the_python_trainer(hip_lib):
+    """include/ex4d_trainer.h (one C++ call per iteration, persistent workspace) against trainer.FrameTrainer + loss.l1_ssim_loss (Python,
+    autograd) on two copies of one model: the same loss, the same parameter gradients, the same parameters after several RAdam steps --
+    equal to the rounding of the rasterizer's float atomics, since both sequence the same kernels."""
+    from ex4dgs_amd.loss import l1_ssim_loss
+    from ex4dgs_amd.native_trainer import NativeTrainer
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.trainer import FrameTrainer
+    ma, cam, bg = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    mb, _, _ = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    cam = cam.to("cuda"); bg = bg.cuda()
+    gt = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(11)).cuda()
+    lrs = {n: 1e-6 for n in ma.PARAM_NAMES}
+    # (1) gradients only
+    na = NativeTrainer(ma, cam, optimizer=False, lrs=lrs)
+    fb = FrameTrainer(mb, optimizer=False)
+    losses = []
+
+    def up(out):
+        loss = l1_ssim_loss(out["render"], gt, 0.2)[0]
+        losses.append(loss.detach())
+        return [loss], [None]
+    na.step(cam, bg, 137, gt)
+    out = fb.step(cam, bg, 137, up)
+    fb.flush(); torch.cuda.synchronize()
+    assert abs(float(na.output("loss")) - float(losses[0])) <= 1e-6
+    assert float((na.output("render") - out["render"]).abs().max()) <= 1e-6 and torch.equal(na.output("radii"), out["radii"])
+    assert na.num_rendered > 0
+    ref = fb.grads()
+    dense = {"_xyz_motion": 4, "_rotation_motion": 2}
+    for n in ma.PARAM_NAMES:
+        g, hint = na.grad(n)
+        r = ref[n]
+        if n in dense:          # FrameTrainer without an optimizer keeps dense keyframe gradients: compare the touched slices
+            first = hint[0] if n == "_xyz_motion" else hint[2]
+            assert float(r.abs().sum()) > 0 and float((r[:, first:first + dense[n]] - g).abs().max()) <= 1e-5 * max(1.0, float(r.abs().max()))
+            z = r.clone(); z[:, first:first + dense[n]] = 0
+            assert float(z.abs().max()) == 0.0
+        else:
+            assert g.shape == r.shape and float((g - r).abs().max()) <= 1e-5 * max(1.0, float(r.abs().max())), n
+    na.close()
+    # (2) with the optimizer, several timestamps
+    p0 = {n: getattr(ma, n).clone() for n in ma.PARAM_NAMES}
+    na = NativeTrainer(ma, cam, optimizer=True, lrs=lrs)
+    fb = FrameTrainer(mb, optimizer=True, lrs=lrs)
+    upg = lambda out: ([l1_ssim_loss(out["render"], gt, 0.2)[0]], [None])
+    for t in (0, 137, 41, 299, 7):
+        na.step(cam, bg, t, gt); fb.step(cam, bg, t, upg)
+    fb.flush(); torch.cuda.synchronize()
+    assert na.bytes() > 0
+    for n in ma.PARAM_NAMES:
+        a, b = getattr(ma, n), getattr(mb, n)
+        moved = float((a - p0[n]).abs().max())
+        assert moved > 0 and torch.isfinite(a).all(), n
+        assert float((a - b).abs().max()) <= 1e-3 * moved + 1e-12, (n, float((a - b).abs().max()), moved)
+    with pytest.raises(RuntimeError, match="gt_image"):
+        na.step(cam, bg, 0, gt[:, :10])
+    na.close()
