@@ -253,12 +253,14 @@ def test_compiled_host_path_matches_the_python_trainer(hip_lib):
         else:
             assert g.shape == r.shape and float((g - r).abs().max()) <= 1e-5 * max(1.0, float(r.abs().max())), n
     na.close()
-    # (2) with the optimizer, several timestamps
+    # (2) with the optimizer, several timestamps.  The loss gradient is ~1e-6 per parameter: RAdam's first five steps (p -= lr * mhat) move
+    # nothing representable, from the sixth on the step is ~lr whatever the gradient scale
+    lrs = {n: 1e-4 for n in ma.PARAM_NAMES}
     p0 = {n: getattr(ma, n).clone() for n in ma.PARAM_NAMES}
     na = NativeTrainer(ma, cam, optimizer=True, lrs=lrs)
     fb = FrameTrainer(mb, optimizer=True, lrs=lrs)
     upg = lambda out: ([l1_ssim_loss(out["render"], gt, 0.2)[0]], [None])
-    for t in (0, 137, 41, 299, 7):
+    for t in (0, 137, 41, 299, 7, 138, 40, 139):
         na.step(cam, bg, t, gt); fb.step(cam, bg, t, upg)
     fb.flush(); torch.cuda.synchronize()
     assert na.bytes() > 0
@@ -266,7 +268,8 @@ def test_compiled_host_path_matches_the_python_trainer(hip_lib):
         a, b = getattr(ma, n), getattr(mb, n)
         moved = float((a - p0[n]).abs().max())
         assert moved > 0 and torch.isfinite(a).all(), n
-        assert float((a - b).abs().max()) <= 1e-3 * moved + 1e-12, (n, float((a - b).abs().max()), moved)
+        ulp = 2.0 ** -23 * float(a.abs().max())          # the updates are a few ulp of the parameters: allow two of them
+        assert float((a - b).abs().max()) <= 1e-3 * moved + 2 * ulp, (n, float((a - b).abs().max()), moved)
     with pytest.raises(RuntimeError, match="gt_image"):
         na.step(cam, bg, 0, gt[:, :10])
     na.close()
