@@ -857,14 +857,24 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
         const int nchunks = ((int)deepest + 63) >> 6;
         const size_t mbase = (size_t)__builtin_amdgcn_readfirstlane((int)(4u * (uint32_t)tile + (uint32_t)quad));
         const uint32_t rx = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
+        // the survivor mask and the ids of chunk c - 1 are requested while chunk c is processed (ids for all 64 positions: one
+        // coalesced load, no dependence on the mask): a chunk then waits for ONE memory round trip (its records), not three
+        const int b = 63 - lane;
+        const uint32_t list_len = range.y - range.x;
+        uint64_t mask_n = cull_masks[mbase + 4 * (size_t)((rx + 64u * (uint32_t)(nchunks - 1)) >> 6)];
+        uint32_t id_n = 0;
+        { const uint32_t k = 64u * (uint32_t)(nchunks - 1) + (uint32_t)b; if (k < list_len) id_n = point_list[range.x + k]; }
         for (int c = nchunks - 1; c >= 0; c--) {
-            uint64_t mask = cull_masks[mbase + 4 * (size_t)((rx + 64u * (uint32_t)c) >> 6)];
+            uint64_t mask = mask_n;
+            const uint32_t id = id_n;
+            if (c > 0) {
+                mask_n = cull_masks[mbase + 4 * (size_t)((rx + 64u * (uint32_t)(c - 1)) >> 6)];
+                id_n = point_list[range.x + 64u * (uint32_t)(c - 1) + (uint32_t)b];          // chunk c - 1 lies wholly inside the list
+            }
             const int rem = (int)deepest - 64 * c;                // list positions of this chunk that are in front of the deepest contributor
             if (rem < 64) mask &= (1ull << rem) - 1ull;
-            const int b = 63 - lane;
             if ((mask >> b) & 1ull) {
                 const int k = 64 * c + b;
-                const uint32_t id = point_list[range.x + k];
                 const float4 *r = records + 4 * (size_t)id;
                 const float4 q0 = r[0], q2 = r[2];
                 const int slot = ring_wrap<RING>(tail + __popcll(b == 63 ? 0ull : (mask >> (b + 1))));
