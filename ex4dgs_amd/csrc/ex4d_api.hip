@@ -168,7 +168,6 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     const int tb = tile_bits(T);
     const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
     b.sort_hist = c.take<uint32_t>(hw > hw2 ? hw : hw2);
-    b.ts_table = c.take<uint32_t>(ex4d_tile_sort_table_words(R, tb));
     b.cull_masks = c.take<unsigned long long>(ex4d_cull_mask_words(R, T));
     l.total = c.off;
     if (lay) *lay = l;
@@ -312,7 +311,7 @@ static int forward_impl(
         STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, b.tile_ids, b.vals_tmp, stream), prm, stream);
         MARK(0, "duplicate");
         STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
-                                 R, tile_bits(T), b.sort_hist, b.ts_table, im.ranges, stream), prm, stream);
+                                 R, tile_bits(T), b.sort_hist, im.ranges, stream), prm, stream);
         MARK(0, "tile_sort");
         MARK(0, "tile_ranges");
     } else {

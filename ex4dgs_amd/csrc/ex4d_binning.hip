@@ -91,15 +91,47 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
 // MODE 1: pairs in, ONE packed word out: (key & low_mask) << (32 - low_bits) | value  (pass A of the tile sort, below).
 // MODE 2: packed words in (digit = word >> shift), values out; the workgroup's item range and bucket come from the block table, its
 //         global digit starts from the bucket's span of the row-scanned histogram; also writes the tile ranges (pass B).
-struct TsBlock { uint32_t start, count, bucket, pad; };
-#define TS_FB_WORDS 260          // bk[0 .. 256]: first block of every bucket (fb[nbuckets ..] = number of blocks); bk[260 ..]: bucket starts
+// Pass B of the tile sort cuts every bucket (= high digit) into blocks of <= 4096 items, so that no block straddles two buckets.
+// Every workgroup derives its own block from the <= 256 bucket totals of pass A (two scans + a 8-step search: cheaper than a
+// one-workgroup table kernel and its launch in the middle of the sort):
+//   fb[h] = first block of bucket h (fb[256] = number of blocks), st[h] = first output position of bucket h
+struct TsBlock { uint32_t start, count, bucket, fb_first, fb_next, bucket_start; };
+struct TsLocateLds { uint32_t cnt[257], fb[257], st[257], wave_sums[8]; };
+__device__ __forceinline__ TsBlock ts_locate_block(const uint32_t *__restrict__ totals, int nbuckets, uint32_t b, TsLocateLds &L)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;         // 256 threads
+    const uint32_t cnt = tid < nbuckets ? totals[tid] : 0u;
+    const uint32_t nblk = (cnt + RS_CHUNK - 1) / RS_CHUNK;
+    uint32_t x = cnt, y = nblk;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(x, o, 64), c = __shfl_up(y, o, 64); if (lane >= o) { x += a; y += c; } }
+    if (lane == 63) { L.wave_sums[wave] = x; L.wave_sums[4 + wave] = y; }
+    __syncthreads();
+    uint32_t st = x - cnt, fb = y - nblk;
+    for (int w = 0; w < wave; w++) { st += L.wave_sums[w]; fb += L.wave_sums[4 + w]; }
+    L.cnt[tid] = cnt; L.fb[tid] = fb; L.st[tid] = st;
+    if (tid == 255) { L.fb[256] = fb + nblk; L.st[256] = st + cnt; L.cnt[256] = 0; }
+    __syncthreads();
+    TsBlock t = { 0u, 0u, 0u, 0u, 0u, 0u };
+    if (b < L.fb[256]) {
+        // the bucket owning block b: the LAST h with fb[h] <= b (empty buckets share their successor's first block and precede it)
+        uint32_t h = 0;
+#pragma unroll
+        for (uint32_t step = 128; step > 0; step >>= 1) if (L.fb[h + step] <= b) h += step;
+        const uint32_t within = (b - L.fb[h]) * RS_CHUNK;
+        t.start = L.st[h] + within;
+        t.count = L.cnt[h] - within < RS_CHUNK ? L.cnt[h] - within : RS_CHUNK;
+        t.bucket = h; t.fb_first = L.fb[h]; t.fb_next = L.fb[h + 1]; t.bucket_start = L.st[h];
+    }
+    return t;
+}
 // NBITS > 0: digit width known at compile time -- the match loop below unrolls (5 VALU per bit instead of a 12-slot loop body with
 // its scalar bookkeeping); 0 = any width at run time.
 template <int ITEMS, int BINS, int MODE, int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
-    int low_bits, const uint32_t *__restrict__ bk, const TsBlock *__restrict__ table, uint2 *__restrict__ ranges)
+    int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges)
 {
     __shared__ uint32_t wave_cnt[4][BINS];        // per-wave digit counts -> exclusive block-local offsets
     __shared__ uint32_t local_start[BINS];        // first block-local slot of each digit
@@ -117,9 +149,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 
     constexpr uint32_t CHUNK = RS_THREADS * ITEMS;
     uint32_t block_first = blockIdx.x * CHUNK, block_end = n, bucket = 0;
+    TsBlock tb = { 0u, 0u, 0u, 0u, 0u, 0u };
     if (MODE == 2) {
-        const TsBlock tb = table[blockIdx.x];
-        if (tb.count == 0) return;                  // past the last block of the table (wave-uniform: whole workgroup)
+        TsLocateLds &loc = *reinterpret_cast<TsLocateLds *>(stage);          // the staging area is not in use yet (no extra LDS)
+        tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);
+        __syncthreads();                            // every thread has its copy before the area is reused
+        if (tb.count == 0) return;                  // past the last block (uniform: the whole workgroup)
         block_first = tb.start; block_end = tb.start + tb.count; bucket = tb.bucket;
     }
     const uint32_t base = block_first + wave * (CHUNK / 4);
@@ -193,8 +228,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
             if (MODE == 2) {
                 // items of this digit inside the bucket = difference of the row's exclusive prefix at the bucket's first block and
                 // at the next bucket's first block (blocks past the table hold zero counts, so the prefix there is the row total)
-                pf[k] = live ? hist[(size_t)d * nblocks + bk[bucket]] : 0u;
-                gtot[k] = live ? hist[(size_t)d * nblocks + bk[bucket + 1]] - pf[k] : 0u;
+                pf[k] = live ? hist[(size_t)d * nblocks + tb.fb_first] : 0u;
+                gtot[k] = live ? hist[(size_t)d * nblocks + tb.fb_next] - pf[k] : 0u;
             } else {
                 pf[k] = 0u;
                 gtot[k] = live ? hist[(size_t)BINS * nblocks + d] : 0u;
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         __syncthreads();
         uint32_t ls = x - tsum, gb = gx - gsum;
         for (int w = 0; w < wave; w++) { ls += scan_tmp[w]; gb += scan_tmp[4 + w]; }
-        if (MODE == 2) gb += bk[TS_FB_WORDS + bucket];          // the bucket's first output position
+        if (MODE == 2) gb += tb.bucket_start;                   // the bucket's first output position
 #pragma unroll
         for (int k = 0; k < BPT; k++) {
             const int d = tid * BPT + k;
@@ -219,7 +254,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
                 local_start[d] = ls;
                 global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x] - pf[k];
                 // tile (bucket, d) occupies [gb, gb + gtot): identifyTileRanges (CR/rasterizer_impl.cu:118-140) without reading the keys
-                if (MODE == 2 && blockIdx.x == bk[bucket] && gtot[k] != 0u) ranges[((size_t)bucket << nbits) + d] = make_uint2(gb, gb + gtot[k]);
+                if (MODE == 2 && blockIdx.x == tb.fb_first && gtot[k] != 0u) ranges[((size_t)bucket << nbits) + d] = make_uint2(gb, gb + gtot[k]);
                 wave_cnt[0][d] = ls; wave_cnt[1][d] = ls + c[k][0]; wave_cnt[2][d] = ls + c[k][0] + c[k][1]; wave_cnt[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
             }
             ls += tot[k]; gb += gtot[k];
@@ -253,57 +288,20 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 // Tile sort, MSD first (the instance count R is ~7.5x the Gaussian count; the sort is HBM-bound):
 //   pass A  stable partition by the HIGH digit of the tile id (buckets), writing ONE packed word per instance -- the low digit in the
 //           top bits, the Gaussian id below (4 bytes instead of the 8 of a key/value pair);
-//   table   the bucket starts (exclusive scan of the high-digit totals) and a block table: every bucket is cut into blocks of
-//           <= 4096 items, so no block straddles two buckets;
+//   blocks  every bucket is cut into blocks of <= 4096 items, so no block straddles two buckets; each workgroup of pass B derives its
+//           block from the bucket totals itself (ts_locate_block);
 //   pass B  per bucket, stable counting sort by the LOW digit: block histograms -> row scan -> scatter of the Gaussian ids alone.
 //           The (bucket, digit) counts are the tile ranges, so identifyTileRanges never reads 4 R bytes of keys.
 // Same result as the reference's single stable sort by (tile | depth): stable by high digit, then stable by low digit inside each
 // bucket = stable by the whole tile id.  HBM traffic per instance: 8 written by the duplication + (4 + 8 + 4) + (4 + 4 + 4) = 36 bytes
 // instead of 8 + 2 x (4 + 8 + 8) + 4 = 52.
-__global__ __launch_bounds__(256) void ts_block_table_kernel(const uint32_t *__restrict__ hist_totals, int nbuckets, uint32_t max_blocks,
-    uint32_t *__restrict__ bk, TsBlock *__restrict__ table)
-{
-    __shared__ uint32_t cnt_s[257], fb_s[257], st_s[257];
-    __shared__ uint32_t wave_sums[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t cnt = tid < nbuckets ? hist_totals[tid] : 0u;
-    const uint32_t nblk = (cnt + RS_CHUNK - 1) / RS_CHUNK;
-    uint32_t x = cnt, y = nblk;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(x, o, 64), b = __shfl_up(y, o, 64); if (lane >= o) { x += a; y += b; } }
-    if (lane == 63) { wave_sums[wave] = x; wave_sums[4 + wave] = y; }
-    __syncthreads();
-    uint32_t st = x - cnt, fb = y - nblk;
-    for (int w = 0; w < wave; w++) { st += wave_sums[w]; fb += wave_sums[4 + w]; }
-    cnt_s[tid] = cnt; fb_s[tid] = fb; st_s[tid] = st;
-    if (tid == 255) { fb_s[256] = fb + nblk; st_s[256] = st + cnt; cnt_s[256] = 0; }
-    __syncthreads();
-    bk[tid] = fb_s[tid]; bk[TS_FB_WORDS + tid] = st_s[tid];
-    if (tid == 0) { bk[256] = fb_s[256]; bk[TS_FB_WORDS + 256] = st_s[256]; }
-    const uint32_t nb = fb_s[256];
-    for (uint32_t b = tid; b < max_blocks; b += 256) {
-        TsBlock t = { 0u, 0u, 0u, 0u };
-        if (b < nb) {
-            // the bucket owning block b: the LAST h with fb[h] <= b (empty buckets share their successor's first block and precede it)
-            uint32_t h = 0;
-#pragma unroll
-            for (uint32_t step = 128; step > 0; step >>= 1) if (fb_s[h + step] <= b) h += step;
-            const uint32_t within = (b - fb_s[h]) * RS_CHUNK;
-            t.start = st_s[h] + within;
-            t.count = cnt_s[h] - within < RS_CHUNK ? cnt_s[h] - within : RS_CHUNK;
-            t.bucket = h;
-        }
-        table[b] = t;
-    }
-}
-
-__global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t *__restrict__ words, const TsBlock *__restrict__ table,
-    int shift, uint32_t nblocks, uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ bucket_totals,
+    int nbuckets, int shift, uint32_t nblocks, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t h[256];
+    __shared__ TsLocateLds loc;
     h[threadIdx.x] = 0;
-    __syncthreads();
-    const TsBlock tb = table[blockIdx.x];
+    const TsBlock tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);      // (contains the barriers that publish h = 0)
     if (tb.count != 0) {
         uint32_t k[RS_ITEMS];
 #pragma unroll
@@ -482,13 +480,13 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         if (small) {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
-#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr)
+#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr)
             if (nbits == 9) RS_SMALL_SCATTER(9); else if (nbits == 8) RS_SMALL_SCATTER(8); else RS_SMALL_SCATTER(0);
 #undef RS_SMALL_SCATTER
         } else {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, nullptr, nullptr);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr);
         }
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
@@ -505,31 +503,31 @@ bool ex4d_tile_sort_msd_applies(int P, int tile_bits)
     const int low_bits = (tile_bits + 1) / 2;
     return (uint64_t)P <= (1ull << (32 - low_bits));
 }
+static inline int ts_clamp_bits(int tile_bits) { return tile_bits > 16 ? 16 : (tile_bits < 2 ? 2 : tile_bits); }
 static inline uint32_t ts_max_blocks(uint32_t R, int tile_bits) { return rs_num_blocks(R) + (1u << (tile_bits - (tile_bits + 1) / 2)) + 1u; }
-size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits) { return (size_t)256 * (ts_max_blocks(R, tile_bits > 16 ? 16 : (tile_bits < 2 ? 2 : tile_bits)) + 1); }
-size_t ex4d_tile_sort_table_words(uint32_t R, int tile_bits) { return 2 * TS_FB_WORDS + 8 + 4 * (size_t)ts_max_blocks(R, tile_bits > 16 ? 16 : (tile_bits < 2 ? 2 : tile_bits)); }
+// two histograms: pass A's [256][nbA] + totals stays readable (bucket totals) while pass B fills its own [256][nbB] + totals
+size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits) { return (size_t)256 * (rs_num_blocks(R) + 1) + (size_t)256 * (ts_max_blocks(R, ts_clamp_bits(tile_bits)) + 1); }
 
 // keys / vals: the instances in depth order (from the duplication); packed: R words of scratch; point_list: the result; tile_ids_out:
 // optional (nullptr = not materialised); ranges must be zero (tiles without instances are never written)
 hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
-    uint32_t R, int tile_bits, uint32_t *hist, uint32_t *table_words, uint2 *ranges, hipStream_t stream)
+    uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream)
 {
     if (R == 0) return hipSuccess;
     const int low_bits = (tile_bits + 1) / 2, high_bits = tile_bits - low_bits;
     const uint32_t nbA = rs_num_blocks(R), nbB = ts_max_blocks(R, tile_bits);
-    uint32_t *bk = table_words;
-    TsBlock *table = reinterpret_cast<TsBlock *>(table_words + 2 * TS_FB_WORDS + 8);
+    uint32_t *histB = hist + (size_t)256 * (nbA + 1);
+    const uint32_t *totals = hist + (size_t)256 * nbA;
     hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << high_bits), dim3(256), 0, stream, nbA, hist, 256u);
 #define TS_SCATTER_A(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 1, NB>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, vals, packed, (uint32_t *)nullptr, \
-        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, (const TsBlock *)nullptr, (uint2 *)nullptr)
+        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, 0, (uint2 *)nullptr)
     if (high_bits == 6) TS_SCATTER_A(6); else if (high_bits == 7) TS_SCATTER_A(7); else if (high_bits == 8) TS_SCATTER_A(8); else TS_SCATTER_A(0);
 #undef TS_SCATTER_A
-    hipLaunchKernelGGL(ts_block_table_kernel, dim3(1), dim3(256), 0, stream, hist + (size_t)256 * nbA, 1 << high_bits, nbB, bk, table);
-    hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, table, 32 - low_bits, nbB, hist);
-    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, hist, 256u);
+    hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, totals, 1 << high_bits, 32 - low_bits, nbB, histB);
+    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, histB, 256u);
 #define TS_SCATTER_B(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2, NB>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list, \
-        R, 32 - low_bits, low_bits, nbB, hist, low_bits, bk, table, ranges)
+        R, 32 - low_bits, low_bits, nbB, histB, low_bits, totals, 1 << high_bits, ranges)
     if (low_bits == 7) TS_SCATTER_B(7); else if (low_bits == 8) TS_SCATTER_B(8); else TS_SCATTER_B(0);
 #undef TS_SCATTER_B
     return hipGetLastError();

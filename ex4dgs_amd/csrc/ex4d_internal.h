@@ -40,7 +40,6 @@ struct BinState {
     uint32_t *tile_ids;       // final sorted tile ids
     uint32_t *vals_tmp, *keys_tmp;   // ping-pong
     uint32_t *sort_hist;
-    uint32_t *ts_table;       // bucket starts + block table of the MSD tile sort
     // per (64-entry chunk of a tile list, quadrant): the lanes that survived the forward kernel's quadrant cull; the compositing
     // backward compacts its lists from these masks instead of gathering and testing every entry again.
     // slot of chunk c of tile t: 4 * (((range.x + 64 c) >> 6) + t) + quadrant   (unique: ranges are disjoint and ascending in t)
@@ -92,9 +91,8 @@ int ex4d_radix_passes(uint32_t n, int end_bit);      // number of passes ex4d_ra
 // MSD-first tile sort on packed words (ex4d_binning.hip); writes point_list, the tile ranges and, on request, the sorted tile ids
 bool ex4d_tile_sort_msd_applies(int P, int tile_bits);
 size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits);
-size_t ex4d_tile_sort_table_words(uint32_t R, int tile_bits);
 hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
-    uint32_t R, int tile_bits, uint32_t *hist, uint32_t *table_words, uint2 *ranges, hipStream_t stream);
+    uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream);
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
     uint32_t *block_sums, int T, uint2 *ranges, hipStream_t stream);
