@@ -31,6 +31,9 @@ ITER="python $root/tools/dev/dev_iter_profile.py 20"
 run_stats iter $ITER
 run_pmc iter_pmc_FETCH_SIZE "FETCH_SIZE" $ITER
 run_pmc iter_pmc_WRITE_SIZE "WRITE_SIZE" $ITER
+NATIVE="python $root/tools/dev/native_overhead.py 300000 40"
+run_stats native300k $NATIVE
+grep "native trainer" $out/${tag}_native300k.log >> $out/${tag}_native300k_kernel_stats.txt
 KNN="python $root/tools/dev/dev_knn_time.py"
 run_stats knn $KNN
 run_pmc knn_pmc_FETCH_SIZE "FETCH_SIZE" $KNN
