@@ -159,8 +159,6 @@ __device__ __forceinline__ void wave_store_rows(float *__restrict__ dst_wave, co
 // instead the wave copies the span with fully coalesced 16-byte accesses through a padded LDS slice
 // (row stride 52 floats: conflict-free ds_read/write_b128 for 8-lane groups) and each lane then reads its row.
 #define SH_ROW 52
-#define SH_LDS_FLOATS_PER_WAVE (64 * SH_ROW)
-#define SH_SPLIT_DC_OFFSET (64 * 45)      // split layout: dc rows behind the 64 rest rows (see wave_load_sh_split)
 
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -169,23 +167,9 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// rows (Gaussians) whose bit is set in `need` are loaded; nvec = float4s needed per Gaussian (<= 12)
-__device__ __forceinline__ void wave_load_sh(const float *__restrict__ shs_wave, float *lds, uint64_t need, int nvec, int lane)
-{
-    const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        const int q = it * 64 + lane;
-        const int g = q / 12, v = q - 12 * g;
-        if (((need >> g) & 1ull) && v < nvec)
-            *reinterpret_cast<float4 *>(lds + g * SH_ROW + 4 * v) = src[q];
-    }
-    wave_sync_lds();
-}
-
-// The same copy in two halves, so that the global loads are IN FLIGHT while the projection / covariance arithmetic runs (a wave of
-// the forward kernel used to wait out three dependent memory round trips: means -> scale/rotation -> SH; now one):
-// issue = the 12 coalesced 16-byte loads into registers, commit = their transposition into the padded LDS slice.
+// The forward kernel does that copy in two steps, so that the global loads are IN FLIGHT while its projection / covariance arithmetic
+// runs (a wave used to wait out three dependent memory round trips: means -> scale/rotation -> SH; now one):
+// issue = the 12 coalesced 16-byte loads into registers, commit = their transposition into half a padded LDS slice at a time.
 struct ShPrefetch { float4 v[13]; };
 __device__ __forceinline__ void wave_issue_sh(const float *__restrict__ shs_wave, ShPrefetch &pf, int nrows, int nvec, int lane)
 {
@@ -197,19 +181,9 @@ __device__ __forceinline__ void wave_issue_sh(const float *__restrict__ shs_wave
         pf.v[it] = (g < nrows && v < nvec) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-__device__ __forceinline__ void wave_commit_sh(float *lds, const ShPrefetch &pf, int lane)
-{
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        const int q = it * 64 + lane;
-        const int g = q / 12, v = q - 12 * g;
-        *reinterpret_cast<float4 *>(lds + g * SH_ROW + 4 * v) = pf.v[it];
-    }
-    wave_sync_lds();
-}
 // split layout: the wave's rows of ONE (dc, rest) tensor pair as two linear 16-byte-aligned spans (rest: 64 x 45 floats = 720 float4,
 // dc: 64 x 3 floats = 48 float4); returns false (nothing issued) for the one wave that straddles the static/dynamic boundary or for
-// misaligned tensors -- those take wave_load_sh_split later
+// misaligned tensors -- those lanes read their rows straight from memory
 __device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_first, int nrows, ShPrefetch &pf, int lane)
 {
     const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
@@ -225,16 +199,6 @@ __device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_
     }
     pf.v[12] = lane < 48 ? reinterpret_cast<const float4 *>(dc)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     return true;
-}
-__device__ __forceinline__ void wave_commit_sh_split(float *lds, const ShPrefetch &pf, int lane)
-{
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        const int q = it * 64 + lane;
-        if (q < 720) reinterpret_cast<float4 *>(lds)[q] = pf.v[it];
-    }
-    if (lane < 48) reinterpret_cast<float4 *>(lds + SH_SPLIT_DC_OFFSET)[lane] = pf.v[12];
-    wave_sync_lds();
 }
 
 // The forward kernel transposes the prefetched block through HALF a slice, rows 32h .. 32h+31 at a time (commit half, the 32
@@ -264,18 +228,6 @@ __device__ __forceinline__ void wave_commit_sh_split_half(float *lds, const ShPr
     wave_sync_lds();
 }
 
-// rows of the first `nrows` Gaussians are stored (all 12 float4 each)
-__device__ __forceinline__ void wave_store_sh(float *__restrict__ dst_wave, const float *lds, int nrows, int lane)
-{
-    wave_sync_lds();
-    float4 *dst = reinterpret_cast<float4 *>(dst_wave);
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        const int q = it * 64 + lane;
-        const int g = q / 12, v = q - 12 * g;
-        if (g < nrows) dst[q] = *reinterpret_cast<const float4 *>(lds + g * SH_ROW + 4 * v);
-    }
-}
 
 // half h of the wave's SH block straight into the half slice (no register prefetch): 6 coalesced 16-byte loads per lane
 __device__ __forceinline__ void wave_load_sh_half(const float *__restrict__ shs_wave, float *lds, int nrows, int nvec, int lane, int h)
@@ -352,69 +304,8 @@ __device__ __forceinline__ void wave_store_sh_half(float *__restrict__ dst_half,
 // dc rows at stride 3 behind them); a lane reads / writes its row with scalar LDS accesses at immediate offsets
 // (stride 45 is odd: conflict-free).  Only the single wave that straddles the static/dynamic boundary goes element by element.
 
-__device__ __forceinline__ void wave_copy_linear(float *__restrict__ dst, const float *__restrict__ src, int nfloats, int lane)
-{
-    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) {
-        const int n4 = nfloats >> 2;
-#pragma unroll 1
-        for (int q = lane; q < n4; q += 64) reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(src)[q];
-        const int e = (n4 << 2) + lane;
-        if (e < nfloats) dst[e] = src[e];
-    } else {
-#pragma unroll 1
-        for (int e = lane; e < nfloats; e += 64) dst[e] = src[e];
-    }
-}
 
-// nrows = rows of this wave that exist (<= 64)
-__device__ __forceinline__ void wave_load_sh_split(const ShSplit &sp, int wave_first, int nrows, float *lds, int lane)
-{
-    if (nrows > 0) {
-        const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
-        if (all_dynamic || all_static) {
-            const int part = all_dynamic ? 1 : 0;
-            const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
-            wave_copy_linear(lds, sp.rest[part] + r0 * 45, nrows * 45, lane);
-            wave_copy_linear(lds + SH_SPLIT_DC_OFFSET, sp.dc[part] + r0 * 3, nrows * 3, lane);
-        } else {
-#pragma unroll 1
-            for (int e = lane; e < nrows * 45; e += 64) {
-                const int R = wave_first + e / 45, part = R >= sp.n_static;
-                lds[e] = sp.rest[part][(size_t)(R - (part ? sp.n_static : 0)) * 45 + e % 45];
-            }
-#pragma unroll 1
-            for (int e = lane; e < nrows * 3; e += 64) {
-                const int R = wave_first + e / 3, part = R >= sp.n_static;
-                lds[SH_SPLIT_DC_OFFSET + e] = sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3];
-            }
-        }
-    }
-    wave_sync_lds();
-}
 
-__device__ __forceinline__ void wave_store_sh_split(const ShSplitGrad &sp, int wave_first, int nrows, const float *lds, int dc_offset, int lane)
-{
-    wave_sync_lds();
-    if (nrows <= 0) return;
-    const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
-    if (all_dynamic || all_static) {
-        const int part = all_dynamic ? 1 : 0;
-        const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
-        wave_copy_linear(sp.rest[part] + r0 * 45, lds, nrows * 45, lane);
-        wave_copy_linear(sp.dc[part] + r0 * 3, lds + dc_offset, nrows * 3, lane);
-    } else {
-#pragma unroll 1
-        for (int e = lane; e < nrows * 45; e += 64) {
-            const int R = wave_first + e / 45, part = R >= sp.n_static;
-            sp.rest[part][(size_t)(R - (part ? sp.n_static : 0)) * 45 + e % 45] = lds[e];
-        }
-#pragma unroll 1
-        for (int e = lane; e < nrows * 3; e += 64) {
-            const int R = wave_first + e / 3, part = R >= sp.n_static;
-            sp.dc[part][(size_t)(R - (part ? sp.n_static : 0)) * 3 + e % 3] = lds[dc_offset + e];
-        }
-    }
-}
 
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int D, int M,
