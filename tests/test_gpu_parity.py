@@ -747,6 +747,18 @@ def test_more_than_65535_tiles(hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("side,bits", [(2300, 15), (2900, 16)])
+def test_tile_sort_with_15_and_16_tile_bits(hip_lib, side, bits):
+    """144x144 = 20 736 and 182x182 = 33 124 tiles: the MSD tile sort with 8-bit low digits and 7- / 8-bit high digits (the compile-time
+    digit widths the 1352x1014 and 2048x1088 configurations do not reach)."""
+    from ex4dgs_amd.scene import SceneConfig
+    cfg = SceneConfig(f"{side}x{side}", 1200, side, side, side * 0.55, seed=37 + bits, sigma_px_med=22.0)
+    o, g, *_ = _fwd_bwd(cfg)
+    T = o["ranges"].shape[0]
+    assert T == ((side + 15) // 16) ** 2 and (1 << (bits - 1)) < T <= (1 << bits) and o["num_rendered"] > 10000
+
+
+@pytest.mark.gpu
 def test_edge_cases_of_the_fused_training_path(hip_lib):
     """Static-only model through attributes -> SplitSH render -> loss -> FusedRAdam (empty dynamic tensors everywhere), tiny
     images through the loss, coincident points through distCUDA2, P == 0 through the autograd surface."""
