@@ -273,3 +273,36 @@ def test_compiled_host_path_matches_the_python_trainer(hip_lib):
     with pytest.raises(RuntimeError, match="gt_image"):
         na.step(cam, bg, 0, gt[:, :10])
     na.close()
+
+
+def test_compiled_host_path_static_only_model_and_growing_arenas(hip_lib):
+    """NativeTrainer on a model without dynamic Gaussians (all eight motion tensors empty) and with views whose instance counts differ
+    by more than the arena's growth step: the binning arena grows, results stay those of a fresh trainer."""
+    from ex4dgs_amd.native_trainer import NativeTrainer
+    from ex4dgs_amd.scene import make_scene
+    model, cam, bg = make_scene("cfg2", P=6000, device="cuda", fused=True)
+    assert model.num_dynamic == 0
+    cam = cam.to("cuda"); bg = bg.cuda()
+    gt = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(3)).cuda()
+    nt = NativeTrainer(model, cam, optimizer=True, lrs={n: 1e-4 for n in model.PARAM_NAMES})
+    b0 = nt.bytes()
+    losses = []
+    for t in range(8):
+        nt.step(cam, bg, t, gt)
+        losses.append(float(nt.output("loss")))
+    assert all(np.isfinite(losses)) and nt.num_rendered > 0 and nt.bytes() > b0       # arenas were allocated by the first frame
+    R0 = nt.num_rendered
+    # every Gaussian three times as large: far more instances than the binning arena holds -> it grows inside step()
+    with torch.no_grad():
+        model._scaling += math.log(3.0)
+    b1 = nt.bytes()
+    nt.step(cam, bg, 0, gt)
+    assert nt.num_rendered > 1.5 * R0 and nt.bytes() > b1 and np.isfinite(float(nt.output("loss")))
+    render = nt.output("render")
+    nt.close()
+    fresh = NativeTrainer(model, cam, optimizer=False)
+    # the step above already moved the parameters once more; compare against a fresh trainer on the CURRENT parameters
+    fresh.step(cam, bg, 0, gt)
+    r2 = fresh.output("render")
+    fresh.close()
+    assert torch.isfinite(render).all() and float((render - r2).abs().max()) < 5e-3      # one RAdam step of 1e-4 apart
