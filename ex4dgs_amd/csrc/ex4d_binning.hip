@@ -52,29 +52,47 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t
     for (int b = threadIdx.x; b < BINS; b += RS_THREADS) hist[(size_t)b * nblocks + blockIdx.x] = h[b];
 }
 
-// one block per bin: exclusive scan of that bin's per-block counts; bin total to hist[RS_BINS*nblocks + bin]
+// one block per bin: exclusive scan of that bin's per-block counts; bin total to hist[RS_BINS*nblocks + bin].
+// 8 consecutive counts per thread (two 16-byte loads when the row is aligned), so rows of up to 2048 blocks take ONE load round trip
+// and one block-level scan (the kernel is pure latency: it used to loop over 256 counts at a time)
 __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uint32_t *__restrict__ hist, uint32_t bins)
 {
     __shared__ uint32_t wave_sums[4];
     __shared__ uint32_t carry_s;
     uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = ((((uintptr_t)row) & 15) == 0);
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? row[i] : 0;
-        uint32_t x = v;
+    for (uint32_t base = 0; base < nblocks; base += 2048) {
+        const uint32_t i0 = base + 8 * threadIdx.x;
+        uint32_t v[8];
+        if (vec && i0 + 8 <= nblocks) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(row + i0), b = *reinterpret_cast<const uint4 *>(row + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (i0 + k < nblocks) ? row[i0 + k] : 0u;
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const uint32_t t = v[k]; v[k] = run; run += t; }       // exclusive inside the thread
+        uint32_t x = run;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
         if (lane == 63) wave_sums[wave] = x;
         __syncthreads();
-        uint32_t woff = 0;
+        uint32_t woff = carry_s + x - run;
         for (int w = 0; w < wave; w++) woff += wave_sums[w];
-        const uint32_t carry = carry_s;
-        if (i < nblocks) row[i] = carry + woff + x - v;
+        if (vec && i0 + 8 <= nblocks) {
+            *reinterpret_cast<uint4 *>(row + i0) = make_uint4(woff + v[0], woff + v[1], woff + v[2], woff + v[3]);
+            *reinterpret_cast<uint4 *>(row + i0 + 4) = make_uint4(woff + v[4], woff + v[5], woff + v[6], woff + v[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (i0 + k < nblocks) row[i0 + k] = woff + v[k];
+        }
         __syncthreads();
-        if (threadIdx.x == 255) carry_s = carry + woff + x;
+        if (threadIdx.x == 255) carry_s = woff + run;
         __syncthreads();
     }
     if (threadIdx.x == 0) hist[(size_t)bins * nblocks + blockIdx.x] = carry_s;
