@@ -249,9 +249,11 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, acc_depth, acc, min_depth, max_depth,
                                  scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size,
                                  subpixel_offset, dL_dout_color, dL_dout_depth, dL_grad_out_flow, dL_grad_out_acc, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, need_colors=True, need_cov3D=True):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:135-234): 30 positional arguments ->
-    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dflow)."""
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dflow).
+    need_colors / need_cov3D = False: that gradient is not written at all (the C ABI takes NULL) and comes back as an empty tensor --
+    the autograd op passes False when the forward had no colors_precomp / cov3D_precomp input to receive it."""
     lib = load()
     _require_rocm(means3D, "means3D")
     dev = means3D.device
@@ -279,6 +281,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             outs0[5] = SplitSH(*[torch.zeros_like(t) for t in split])
         return tuple(outs0)
     outs = [torch.empty(*s, **f32) for s in shapes]
+    if not need_colors:
+        outs[1] = torch.empty(0, **f32)
+    if not need_cov3D:
+        outs[4] = torch.empty(0, **f32)
+    optr = lambda t: t.data_ptr() if t.numel() else None
     if split is not None:
         outs[5] = SplitSH(*[torch.empty_like(t, memory_format=torch.contiguous_format) for t in split])
     keep = []
@@ -305,7 +312,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ptr["subpixel_offset"], ptr["acc_depth"], ptr["acc"],
                 geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
                 ptr["dL_dout_color"], ptr["dL_dout_depth"], ptr["dL_grad_out_flow"], ptr["dL_grad_out_acc"],
-                outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(),
+                outs[0].data_ptr(), optr(outs[1]), outs[2].data_ptr(), outs[3].data_ptr(), optr(outs[4]),
                 C.byref(gst), outs[6].data_ptr(), outs[7].data_ptr(), outs[8].data_ptr(),
                 scratch.data_ptr(), C.c_void_p(stream))
             _check(code)
@@ -317,7 +324,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             ptr["subpixel_offset"], ptr["acc_depth"], ptr["acc"],
             geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
             ptr["dL_dout_color"], ptr["dL_dout_depth"], ptr["dL_grad_out_flow"], ptr["dL_grad_out_acc"],
-            outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(),
+            outs[0].data_ptr(), optr(outs[1]), outs[2].data_ptr(), outs[3].data_ptr(), optr(outs[4]),
             outs[5].data_ptr() if M > 0 else None, outs[6].data_ptr(), outs[7].data_ptr(), outs[8].data_ptr(),
             scratch.data_ptr(), C.c_void_p(stream))
     _check(code)

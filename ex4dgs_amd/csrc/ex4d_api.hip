@@ -16,7 +16,8 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 static inline int acc_layout_of(int variant) { return variant == 2 ? 1 : 0; }
 std::atomic<int> g_bwd_variant{4};
-std::atomic<int> g_tile_ids{0};      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
+std::atomic<int> g_tile_ids{0};
+std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...)
@@ -264,8 +265,10 @@ static int forward_impl(
     g_prof.begin(0, stream);
     HIP_TRY(hipMemsetAsync(g.total, 0, 4 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
+    GeomState gw = g;          // cov3D[P,6] / tiles_touched[P] are written on request only: nothing downstream reads them
+    if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                                     viewmatrix, projmatrix, campos, radii, g, g.total + 1, split,
+                                     viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
                                      keys0, vals0, key_base, key_invisible, stream), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
@@ -350,7 +353,7 @@ static int backward_impl(
     if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
     if (!geom_buffer || !binning_buffer || !img_buffer || !bwd_scratch) return fail(EX4D_ERR_ARG, "null state buffer");
     // any of the four upstream gradients may be NULL (= zeros: that output is not part of the loss)
-    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
+    if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
         return fail(EX4D_ERR_ARG, "null gradient output");
     GeomState g = carve_geom((void *)geom_buffer, P, nullptr, nullptr);
     BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, W, H, nullptr, nullptr);
@@ -367,7 +370,9 @@ static int backward_impl(
                                         out_depth, out_acc, im.final_T, im.n_contrib,
                                         dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, b.cull_masks, variant, stream), prm, stream);
     MARK(1, "composite_bwd");
-    const float *cov3D_ptr = cov3D_precomp ? cov3D_precomp : g.cov3D;            // rasterizer_impl.cu:460
+    // rasterizer_impl.cu:460 takes the forward's stored covariance when none was passed in; here the kernel recomputes it from
+    // scale / rotation with the forward's own function (identical bits), so only a caller-provided covariance is read
+    const float *cov3D_ptr = cov3D_precomp;
     STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16, acc_layout_of(variant),
                                      dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir,
                                      split, gsplit, stream), prm, stream);
@@ -463,6 +468,7 @@ int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 0 || value == 2 || value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }
 
@@ -473,6 +479,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "acc_layout")) return acc_layout_of(g_bwd_variant.load());
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
+    if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     return -1;
 }
 

@@ -153,6 +153,21 @@ __device__ __forceinline__ void wave_store_rows(float *__restrict__ dst_wave, co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sigma = (S R)^T (S R), CR/forward.cu:128-162; raw (un-normalised) quaternion.  ONE function for the forward kernel and for the backward
+// kernel's recomputation: identical operations in identical order (this file is compiled with -ffp-contract=off), identical bits.
+__device__ __forceinline__ void cov3d_from_scale_rotation(float scale_modifier, float s0, float s1, float s2, float4 q, float (&cov3D)[6])
+{
+    Mat3 S = from_columns(1.0f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f);
+    S.m[0][0] = scale_modifier * s0;
+    S.m[1][1] = scale_modifier * s1;
+    S.m[2][2] = scale_modifier * s2;
+    Mat3 R = rotation_from_quat(q.x, q.y, q.z, q.w);
+    Mat3 Mx = mul(S, R);
+    Mat3 Sigma = mul(transpose(Mx), Mx);
+    cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+    cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
 // ---- wave-cooperative SH staging -------------------------------------------------------------------
 // The SH block of the 64 Gaussians of a wave is one contiguous 12 KB span ([P,16,3] floats).  A lane reading
 // "its" 48 floats directly issues 12 loads whose 64 lanes are 192 B apart (64 cache lines per instruction);
@@ -381,19 +396,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
         } else {
-            // Sigma = (S R)^T (S R), CR/forward.cu:128-162; raw (un-normalised) quaternion
-            const float4 q = in_q;
-            Mat3 S = from_columns(1.0f, 0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 1.0f);
-            S.m[0][0] = scale_modifier * in_s0;
-            S.m[1][1] = scale_modifier * in_s1;
-            S.m[2][2] = scale_modifier * in_s2;
-            Mat3 R = rotation_from_quat(q.x, q.y, q.z, q.w);
-            Mat3 Mx = mul(S, R);
-            Mat3 Sigma = mul(transpose(Mx), Mx);
-            cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
-            cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+            cov3d_from_scale_rotation(scale_modifier, in_s0, in_s1, in_s2, in_q, cov3D);
+            // the array is only materialised on request (option "geom_debug_arrays"): the backward recomputes it from the same inputs
+            if (cov3Ds) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) cov3Ds[6 * (size_t)idx + i] = cov3D[i];
+                for (int i = 0; i < 6; i++) cov3Ds[6 * (size_t)idx + i] = cov3D[i];
+            }
         }
         Cov2DCtx c;
         cov2d_common(p, fx, fy, tanx, tany, cov3D, vm, c);
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     }
     if (in_range) {
         radii[idx] = out_radius;
-        tiles_touched[idx] = out_tiles;
+        if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
         rects[idx] = rect;
         depth_keys[idx] = depth_key;
         depth_vals[idx] = (uint32_t)idx;
@@ -682,8 +690,10 @@ __global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(
         in_r0 = row[0]; in_r1 = row[1]; in_r2 = row[2]; in_r3 = row[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) in_mean[i] = means3D[3 * (size_t)idx + i];
+        if (!scales) {          // precomputed covariance: the caller's tensor; otherwise recomputed below from scale / rotation
 #pragma unroll
-        for (int i = 0; i < 6; i++) in_cov[i] = cov3Ds[6 * (size_t)idx + i];
+            for (int i = 0; i < 6; i++) in_cov[i] = cov3Ds[6 * (size_t)idx + i];
+        }
         if (scales) {
             in_q = reinterpret_cast<const float4 *>(rotations)[idx];
 #pragma unroll
@@ -775,6 +785,7 @@ __global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(
         float cov3D[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) cov3D[i] = in_cov[i];
+        if (scales) cov3d_from_scale_rotation(scale_modifier, in_s[0], in_s[1], in_s[2], in_q, cov3D);      // == the forward's value, not re-read
 
         // ---- computeCov2DCUDA, CR/backward.cu:144-300 (the coef-gradient block :201-218 affects no output)
         Cov2DCtx c;
@@ -938,11 +949,11 @@ __global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(
     {
         const int nrows = (P - wave_first) < 64 ? (P - wave_first) : 64;    // <= 0 for waves past the end
         wave_store_rows<3>(dL_dmeans2D + 3 * (size_t)wave_first, g_mean2D, lds_row_base, nrows, lane);
-        wave_store_rows<3>(dL_dcolors + 3 * (size_t)wave_first, g_color, lds_row_base, nrows, lane);
+        if (dL_dcolors) wave_store_rows<3>(dL_dcolors + 3 * (size_t)wave_first, g_color, lds_row_base, nrows, lane);
         wave_store_rows<3>(dL_dmeans3D + 3 * (size_t)wave_first, g_mean3D, lds_row_base, nrows, lane);
         wave_store_rows<3>(dL_dscales + 3 * (size_t)wave_first, g_scale, lds_row_base, nrows, lane);
         wave_store_rows<3>(dL_ddir + 3 * (size_t)wave_first, g_dir, lds_row_base, nrows, lane);
-        wave_store_rows<6>(dL_dcov3D + 6 * (size_t)wave_first, g_cov, lds_row_base, nrows, lane);
+        if (dL_dcov3D) wave_store_rows<6>(dL_dcov3D + 6 * (size_t)wave_first, g_cov, lds_row_base, nrows, lane);
     }
     if (!in_range) return;
     dL_dopacity[idx] = g_opacity;

@@ -66,7 +66,7 @@ struct Ex4dTrainer {
     float *color = nullptr, *depth = nullptr, *acc = nullptr, *flow = nullptr, *loss = nullptr, *dmaps = nullptr, *loss_scratch = nullptr;
     float *grad_img = nullptr, *grad_loss = nullptr;
     int32_t *idx = nullptr, *radii = nullptr;
-    float *g_means2D = nullptr, *g_colors = nullptr, *g_opacity = nullptr, *g_means3D = nullptr, *g_cov3D = nullptr, *g_scales = nullptr,
+    float *g_means2D = nullptr, *g_opacity = nullptr, *g_means3D = nullptr, *g_scales = nullptr,
           *g_rotations = nullptr, *g_dir = nullptr;
     void *bwd_scratch = nullptr;
     Arena geom, binning, img;
@@ -133,8 +133,8 @@ Ex4dTrainer *ex4d_trainer_create(const Ex4dTrainerConfig *cfg, float *const *par
             && t->take(t->color, 3 * HW) && t->take(t->depth, HW) && t->take(t->acc, HW) && t->take(t->flow, 3 * HW) && t->take(t->idx, HW)
             && t->take(t->radii, P) && t->take(t->loss, 1) && t->take(t->dmaps, 9 * HW)
             && t->take(t->loss_scratch, ex4d_l1_ssim_scratch_floats(cfg->H, cfg->W)) && t->take(t->grad_img, 3 * HW) && t->take(t->grad_loss, 1)
-            && t->take(t->g_means2D, 3 * P) && t->take(t->g_colors, 3 * P) && t->take(t->g_opacity, P) && t->take(t->g_means3D, 3 * P)
-            && t->take(t->g_cov3D, 6 * P) && t->take(t->g_scales, 3 * P) && t->take(t->g_rotations, 4 * P) && t->take(t->g_dir, 3 * P);
+            && t->take(t->g_means2D, 3 * P) && t->take(t->g_opacity, P) && t->take(t->g_means3D, 3 * P)
+            && t->take(t->g_scales, 3 * P) && t->take(t->g_rotations, 4 * P) && t->take(t->g_dir, 3 * P);
     if (ok) {
         void *s = nullptr;
         ok = t->take(reinterpret_cast<unsigned char *&>(s), ex4d_backward_scratch_bytes(t->P));
@@ -200,7 +200,7 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
     gsh.dc[0] = t->grad[5]; gsh.rest[0] = t->grad[6]; gsh.dc[1] = t->grad[13]; gsh.rest[1] = t->grad[14]; gsh.n_static = c.Ns;
     rc = ex4d_backward_split_sh(&prm, R, background, t->means3D, t->radii, &sh, t->scales, t->rotations, nullptr, viewmatrix, projmatrix, campos,
                                 nullptr, t->depth, t->acc, t->geom.ptr, t->binning.ptr, t->img.ptr, t->grad_img, nullptr, nullptr, nullptr,
-                                t->g_means2D, t->g_colors, t->g_opacity, t->g_means3D, t->g_cov3D, &gsh, t->g_scales, t->g_rotations, t->g_dir,
+                                t->g_means2D, nullptr, t->g_opacity, t->g_means3D, nullptr, &gsh, t->g_scales, t->g_rotations, t->g_dir,
                                 t->bwd_scratch, stream);
     if (rc) return tfail(rc, "rasterizer backward: %s", ex4d_last_error());
 

@@ -99,9 +99,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 s.scale_modifier, cov3Ds_precomp, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size,
                 s.subpixel_offset, grad_out_color, grad_out_depth, grad_out_flow, grad_out_acc, sh, s.sh_degree, s.campos,
                 geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
+        # gradients of inputs the forward did not have are not even written (the reference fills dL_dcolors / dL_dcov3D and drops them)
+        need_colors, need_cov3D = colors_precomp.numel() != 0, cov3Ds_precomp.numel() != 0
+        native = lambda *a: _C.rasterize_gaussians_backward(*a, need_colors=need_colors, need_cov3D=need_cov3D)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-         grad_scales, grad_rotations, grad_dir3D) = _call_native(
-            _C.rasterize_gaussians_backward, args, s.debug, "snapshot_bw.dump", "backward")
+         grad_scales, grad_rotations, grad_dir3D) = _call_native(native, args, s.debug, "snapshot_bw.dump", "backward")
+        if not need_colors:
+            grad_colors_precomp = None
+        if not need_cov3D:
+            grad_cov3Ds_precomp = None
         # one gradient per forward input, in input order (reference :165-176)
         if ctx.split:
             return (grad_means3D, grad_means2D, grad_dir3D, None, grad_colors_precomp, grad_opacities,

@@ -99,6 +99,8 @@ int ex4d_forward(
  * Backward: replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:367-486) including the
  * zero-fill of the ten gradient tensors (rasterize_points.cu:178-187): every output below is fully
  * written for all P Gaussians (zeros for invisible ones), so the caller may pass uninitialised memory.
+ * dL_dcolors and dL_dcov3D may be NULL (a caller that rendered from SH / from scale + rotation has no tensor to receive them): they
+ * are then not written -- 36 bytes per Gaussian less HBM traffic; every other output is required.
  * `bwd_scratch` must hold ex4d_backward_scratch_bytes(P) bytes (internal per-Gaussian accumulators,
  * the reference's dL_dconic[P,2,2] among them).
  * Reference-specific semantics reproduced exactly: dL_dopacity is w.r.t. opacity*coef,
@@ -167,9 +169,9 @@ typedef struct Ex4dGeomLayout {
     size_t records;         /* float[P][16]        one 64-byte record per Gaussian:
                                                    [0..1] mean2D, [2..4] conic.xyz, [5..7] cull constants, [8] depth (p_view.z),
                                                    [9..11] rgb (SH colour or colors_precomp), [12..14] dir3D, [15] opacity*coef */
-    size_t cov3D;           /* float[6P] */
+    size_t cov3D;           /* float[6P]           with option "geom_debug_arrays" = 1 only */
     size_t clamped;         /* uint8[P]            bit c set <=> channel c clamped at 0 (forward.cu:67-69) */
-    size_t tiles_touched;   /* uint32[P] */
+    size_t tiles_touched;   /* uint32[P]           with option "geom_debug_arrays" = 1 only */
     size_t depth_order;     /* uint32[P]           Gaussian ids, stable-sorted by depth key (visible first) */
     size_t sorted_offsets;  /* uint32[P]           block-local inclusive scan of tiles_touched in depth order */
     size_t total;
@@ -204,6 +206,9 @@ size_t ex4d_backward_scratch_acc_offset(int32_t P);
  *                            the tile sort -- nothing downstream reads the ids, the tile ranges carry the same information.  (Images with
  *                            <= 256 or > 65536 tiles, or more than 2^(32 - ceil(tile bits / 2)) Gaussians, take the key/value sort,
  *                            which always writes them.)
+ *   "geom_debug_arrays"      1 = also write Ex4dGeomLayout.cov3D and .tiles_touched; 0 (default) = those regions stay untouched: the
+ *                            backward recomputes the covariance from scale / rotation (same function, same bits), the tile rect carries
+ *                            the count.
  * ex4d_get_option additionally answers "acc_layout" (see above).  Returns EX4D_OK / the value, or an error / -1. */
 int ex4d_set_option(const char *name, int value);
 int ex4d_get_option(const char *name);

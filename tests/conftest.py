@@ -21,6 +21,8 @@ def hip_lib():
     # the parity tests compare the sorted tile ids with the oracle's: have the tile sort materialise them (default: ranges only);
     # tests/test_gpu_round2.py checks that point_list and ranges are the same without them
     _C.set_option("binning_tile_ids", 1)
+    # likewise cov3D[P,6] / tiles_touched[P] of the geometry buffer (compared bit-exactly with the oracle's)
+    _C.set_option("geom_debug_arrays", 1)
     return lib
 
 

@@ -178,7 +178,8 @@ def test_wrapper_marshalling_matches_reference_golden(monkeypatch):
         return (17, z(3, H, W), z(P, dtype=torch.int32), z(11, dtype=torch.uint8), z(12, dtype=torch.uint8), z(13, dtype=torch.uint8),
                 z(1, H, W), z(1, H, W), z(3, H, W), z(1, H, W, dtype=torch.int32))
 
-    def bwd(*args):
+    def bwd(*args, **extension):      # need_colors / need_cov3D: keyword-only extension, the 30 positional arguments are the reference's
+        assert set(extension) <= {"need_colors", "need_cov3D"}
         rec["bwd"] = args
         P, M = args[1].shape[0], args[22].shape[1]
         return tuple(torch.full(s, float(i + 1)) for i, s in enumerate([(P, 3), (P, 3), (P, 1), (P, 3), (P, 6), (P, M, 3), (P, 3), (P, 4), (P, 3)]))

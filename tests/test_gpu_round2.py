@@ -306,3 +306,47 @@ def test_compiled_host_path_static_only_model_and_growing_arenas(hip_lib):
     r2 = fresh.output("render")
     fresh.close()
     assert torch.isfinite(render).all() and float((render - r2).abs().max()) < 5e-3      # one RAdam step of 1e-4 apart
+
+
+def test_lean_geometry_path_and_optional_gradient_outputs(hip_lib):
+    """Defaults of the library ("geom_debug_arrays" = 0: cov3D / tiles_touched not written, the backward recomputes the covariance;
+    dL_dcolors / dL_dcov3D not written when the caller has no input to receive them) against the fully materialised run the parity
+    tests use: identical forward, gradients equal to the rounding of the float atomics."""
+    from ex4dgs_amd import _C
+    ins, st = h.scene_inputs("cfg3", P=9000)
+    a = h.gpu_forward_raw(ins, st)
+    H, W = a["color"].shape[1:]
+    grads = h.upstream_grads(a["acc"].cpu(), H, W, seed=5)
+    ga = h.gpu_backward_raw(ins, a, grads)
+    assert _C.get_option("geom_debug_arrays") == 1
+    try:
+        _C.set_option("geom_debug_arrays", 0)
+        b = h.gpu_forward_raw(ins, st)
+        gb = h.gpu_backward_raw(ins, b, grads)
+    finally:
+        _C.set_option("geom_debug_arrays", 1)
+    for k in ("color", "depth", "acc", "flow", "idx", "radii", "point_list", "ranges", "n_contrib"):
+        assert torch.equal(a[k], b[k]), k
+    vis = a["radii"] > 0                                      # the records of culled Gaussians are never written
+    assert torch.equal(a["records"][vis], b["records"][vis])
+    for k in ga:
+        if k == "acc16":
+            continue
+        x, y = ga[k], gb[k]
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max())), k
+    # the C ABI accepts NULL for the two gradients nobody may need
+    s = a["settings"]
+    e = torch.Tensor([])
+    d = lambda k: ins[k].cuda() if ins.get(k) is not None else e
+    gc, gd, gf, gacc = [g.cuda() for g in grads]
+    outs = _C.rasterize_gaussians_backward(
+        s.bg, d("means3D"), a["radii"], d("colors_precomp"), d("scales"), d("rotations"), a["depth"], a["acc"], s.min_depth, s.max_depth,
+        s.scale_modifier, d("cov3D_precomp"), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size, s.subpixel_offset,
+        gc, gd, gf, gacc, d("shs"), s.sh_degree, s.campos, a["geomBuffer"], a["num_rendered"], a["binningBuffer"], a["imgBuffer"], s.debug,
+        need_colors=False, need_cov3D=False)
+    assert outs[1].numel() == 0 and outs[4].numel() == 0
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_ddir")
+    for n, o in zip(names, outs):
+        if n in ("dL_dcolors", "dL_dcov3D"):
+            continue
+        assert float((o - ga[n]).abs().max()) <= 1e-5 * max(1.0, float(ga[n].abs().max())), n
