@@ -38,6 +38,41 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libex4d_hip.so cannot be built")
 
 
+def _without_remarks(text):
+    """The compiler's other diagnostics (warnings, errors) without the resource-usage remarks and their source snippets."""
+    out, skip = [], 0
+    for line in text.splitlines():
+        if "-Rpass-analysis=kernel-resource-usage" in line:
+            skip = 2
+            continue
+        if skip and (line.strip().startswith("|") or line.split("|")[0].strip().isdigit()):
+            skip -= 1
+            continue
+        skip = 0
+        if "remark" in line and "generated" in line:      # "12 remarks generated."
+            continue
+        out.append(line + "\n")
+    return "".join(out)
+
+
+def _no_vgpr_spills(src, remarks, obj):
+    """No kernel of this library may spill vector registers: a build of preprocess_bwd_kernel that was forced to 128 VGPRs and
+    spilled 3 of them returned wrong gradients for a few Gaussians per 100 k (the wave-level LDS hand-offs of these kernels and
+    scratch reloads do not mix).  The compiler's resource remarks are checked at build time; the object is removed on a violation."""
+    name, bad = None, []
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[")[0].strip()
+        elif "VGPRs Spill:" in line:
+            n = int(line.split("VGPRs Spill:")[1].split("[")[0])
+            if n:
+                bad.append((name, n))
+    if bad:
+        if os.path.exists(obj):
+            os.remove(obj)
+        raise RuntimeError(f"{src}: vector-register spills in {bad}: restructure the kernel or relax its __launch_bounds__")
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -57,10 +92,16 @@ def build(force=False, verbose=False, extra_flags=()):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + flags + list(extra_flags) + os.environ.get("EX4D_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + flags + list(extra_flags) + os.environ.get("EX4D_EXTRA_HIPCC_FLAGS", "").split() + \
+                  ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            remarks = r.stderr or ""
+            sys.stderr.write(_without_remarks(remarks))
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            _no_vgpr_spills(src, remarks, o)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

@@ -245,7 +245,8 @@ __device__ __forceinline__ void wave_commit_sh_split_half(float *lds, const ShPr
 
 
 // half h of the wave's SH block straight into the half slice (no register prefetch): 6 coalesced 16-byte loads per lane
-__device__ __forceinline__ void wave_load_sh_half(const float *__restrict__ shs_wave, float *lds, int nrows, int nvec, int lane, int h)
+// need: bit L set <=> the Gaussian of lane L is visible; the 16-byte chunks of the other rows (~19 % of them) are not requested
+__device__ __forceinline__ void wave_load_sh_half(const float *__restrict__ shs_wave, float *lds, int nrows, int nvec, int lane, int h, uint64_t need)
 {
     const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
     float4 t[6];
@@ -253,7 +254,7 @@ __device__ __forceinline__ void wave_load_sh_half(const float *__restrict__ shs_
     for (int i = 0; i < 6; i++) {
         const int q = (6 * h + i) * 64 + lane;
         const int g = q / 12, v = q - 12 * g;
-        t[i] = (g < nrows && v < nvec) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        t[i] = (g < nrows && v < nvec && ((need >> g) & 1ull)) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -272,18 +273,24 @@ __device__ __forceinline__ bool wave_sh_split_stageable(const ShSplit &sp, int w
     const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0));
     return ((((uintptr_t)(sp.rest[part] + r0 * 45)) | ((uintptr_t)(sp.dc[part] + r0 * 3))) & 15) == 0;
 }
-__device__ __forceinline__ void wave_load_sh_split_half(const ShSplit &sp, int wave_first, float *lds, int lane, int h)
+// (the backward reads the coefficients k >= 1 only: the dc rows are not loaded at all; a 16-byte chunk of the rest span is requested
+// when one of the at most two rows it touches belongs to a visible Gaussian)
+__device__ __forceinline__ void wave_load_sh_split_half(const ShSplit &sp, int wave_first, float *lds, int lane, int h, uint64_t need)
 {
     const int part = wave_first >= sp.n_static ? 1 : 0;
     const size_t r0 = (size_t)(wave_first - (part ? sp.n_static : 0)) + 32 * h;
-    const float4 *rest = reinterpret_cast<const float4 *>(sp.rest[part] + r0 * 45), *dc = reinterpret_cast<const float4 *>(sp.dc[part] + r0 * 3);
+    const float4 *rest = reinterpret_cast<const float4 *>(sp.rest[part] + r0 * 45);
+    const uint32_t need_h = (uint32_t)(need >> (32 * h));
     float4 t[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { const int q = i * 64 + lane; t[i] = q < 360 ? rest[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
-    const float4 d = lane < 24 ? dc[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 6; i++) {
+        const int q = i * 64 + lane;
+        const int r_lo = (4 * q) / 45, r_hi = (4 * q + 3) / 45;       // q < 360: rows 0 .. 31
+        const bool want = q < 360 && (((need_h >> r_lo) | (need_h >> (r_hi & 31))) & 1u);
+        t[i] = want ? rest[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) { const int q = i * 64 + lane; if (q < 360) reinterpret_cast<float4 *>(lds)[q] = t[i]; }
-    if (lane < 24) reinterpret_cast<float4 *>(lds + SH_HALF_DC_OFFSET)[lane] = d;
     wave_sync_lds();
 }
 
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *_
 //             sG = dL_dG G and d = mean2D - pixel; rest as layout 0.  dG/dmean2D = -G (A dx + B dy, C dy + B dx) (CR/backward.cu:
 //             :664-670), dG/dconic = -1/2 G (dx^2, dx dy, dy^2) (:673-675): linear in those sums, conic (A, B, C) from the record.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const int32_t *__restrict__ radii, const float *__restrict__ shs,
     const uint8_t *__restrict__ clamped, const float *__restrict__ scales, const float *__restrict__ rotations,
@@ -723,11 +730,12 @@ __global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(
     if (shs || split) {
         float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
         const int r = lane & 31;
+        const uint64_t need_rows = __ballot(visible);
         if (staged && prefetched) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                if (split) wave_load_sh_split_half(sp, wave_first, lds_row_base, lane, h);
-                else wave_load_sh_half(shs + (size_t)wave_first * 48, lds_row_base, wave_rows, ((D + 1) * (D + 1) * 3 + 3) / 4, lane, h);
+                if (split) wave_load_sh_split_half(sp, wave_first, lds_row_base, lane, h, need_rows);
+                else wave_load_sh_half(shs + (size_t)wave_first * 48, lds_row_base, wave_rows, ((D + 1) * (D + 1) * 3 + 3) / 4, lane, h, need_rows);
                 if (visible && (lane >> 5) == h) {
                     // split layout: rest rows at stride 45 (coefficient k >= 1 at 3 (k - 1)); only k >= 1 is read
                     if (split) sh_direction_sums(lds_row_base + r * 45 - 3, D, sh_dir.x, sh_dir.y, sh_dir.z, dRGBdx, dRGBdy, dRGBdz);

@@ -425,6 +425,26 @@ def test_drop_in_packages_import_under_the_reference_names():
     assert lines[3] == "[]", lines[3]            # module names of the reference stay free
 
 
+def test_build_refuses_kernels_with_vector_register_spills(tmp_path):
+    """ex4dgs_amd.build parses the compiler's resource remarks of every object: a kernel with VGPR spills fails the build (a spilling
+    build of the per-Gaussian backward returned wrong gradients), and the remarks do not drown the compiler's real diagnostics."""
+    from ex4dgs_amd import build
+    ok = ("a.hip:3:1: remark: Function Name: k_fine [-Rpass-analysis=kernel-resource-usage]\n"
+          "a.hip:3:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    build._no_vgpr_spills("a.hip", ok, str(tmp_path / "a.o"))
+    obj = tmp_path / "b.o"
+    obj.write_bytes(b"x")
+    bad = ok + ("a.hip:9:1: remark: Function Name: k_spills [-Rpass-analysis=kernel-resource-usage]\n"
+                "a.hip:9:1: remark:     SGPRs Spill: 4 [-Rpass-analysis=kernel-resource-usage]\n"
+                "a.hip:9:1: remark:     VGPRs Spill: 3 [-Rpass-analysis=kernel-resource-usage]\n    9 | {\n      | ^\n")
+    with pytest.raises(RuntimeError, match="k_spills"):
+        build._no_vgpr_spills("a.hip", bad, str(obj))
+    assert not obj.exists()
+    text = bad + "a.hip:20:5: warning: unused variable 'x' [-Wunused-variable]\n   20 |     int x;\n      |         ^\n2 remarks generated.\n"
+    kept = build._without_remarks(text)
+    assert "unused variable" in kept and "int x;" in kept and "remark" not in kept and "Spill" not in kept
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
