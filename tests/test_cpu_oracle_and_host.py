@@ -579,3 +579,81 @@ def test_integer_decisions_are_insensitive_to_fma_contraction():
     assert tot["cull"] == 0, tot
     assert tot["radii"] <= 1e-4 * tot["vis"] + 1 and tot["tiles"] <= 1e-4 * tot["vis"] + 1, tot
     assert tot["same_list"] >= tot["cases"] - 1, tot
+
+
+def test_msd_tile_sort_index_arithmetic_against_a_stable_sort():
+    """The index arithmetic of the MSD-first tile sort (ex4d_binning.hip: pass A packed words, ts_locate_block, the bucket-relative offsets
+    of pass B and the tile ranges that fall out of them), restated with numpy and checked against a stable argsort -- including empty
+    buckets, buckets larger than one 4096-item block, a last block that is not full, and tile counts that need 9 .. 16 bits."""
+    rng = np.random.default_rng(7)
+    CH = 4096
+
+    def msd_sort(tiles, ids, tile_bits):
+        R = len(tiles)
+        low = (tile_bits + 1) // 2
+        high = tile_bits - low
+        nbuckets = 1 << high
+        # ---- pass A: stable partition by the high digit, one packed word per item
+        hd = tiles >> low
+        order_a = np.argsort(hd, kind="stable")
+        packed = ((tiles[order_a] & ((1 << low) - 1)).astype(np.uint64) << np.uint64(32 - low) | ids[order_a].astype(np.uint64)).astype(np.uint32)
+        totals = np.bincount(hd, minlength=nbuckets)
+        # ---- ts_locate_block: first block / first position of every bucket, then (start, count, bucket) of every block
+        nblk = (totals + CH - 1) // CH
+        fb = np.concatenate([[0], np.cumsum(nblk)])
+        st = np.concatenate([[0], np.cumsum(totals)])
+        nb_max = (R + CH - 1) // CH + nbuckets + 1
+        blocks = []
+        for b in range(nb_max):
+            if b >= fb[-1]:
+                blocks.append((0, 0, 0)); continue
+            h = 0
+            step = 128
+            fbp = np.concatenate([fb, np.full(257 - len(fb), fb[-1])])        # fb[nbuckets ..] = number of blocks
+            while step:
+                if h + step <= 255 and fbp[h + step] <= b:
+                    h += step
+                step >>= 1
+            within = (b - fb[h]) * CH
+            blocks.append((st[h] + within, min(CH, totals[h] - within), h))
+        assert sum(c for _, c, _ in blocks) == R
+        # ---- pass B: block histograms by the low digit, row scan over ALL blocks, bucket-relative offsets
+        nd = 1 << low
+        hist = np.zeros((nd, nb_max), np.int64)
+        for b, (s0, c, h) in enumerate(blocks):
+            hist[:, b] = np.bincount(packed[s0:s0 + c] >> np.uint32(32 - low), minlength=nd)
+        excl = np.concatenate([np.zeros((nd, 1), np.int64), np.cumsum(hist, axis=1)], axis=1)        # excl[d, b] = items of digit d in blocks < b
+        out = np.full(R, -1, np.int64)
+        ranges = np.zeros((1 << tile_bits, 2), np.int64)
+        for b, (s0, c, h) in enumerate(blocks):
+            if c == 0:
+                continue
+            pf, pn = excl[:, fb[h]], excl[:, fb[h + 1]]
+            cnt = pn - pf                                              # items of (bucket h, digit d)
+            start = st[h] + np.concatenate([[0], np.cumsum(cnt)[:-1]])
+            base = start + excl[:, b] - pf
+            w = packed[s0:s0 + c]
+            d = (w >> np.uint32(32 - low)).astype(np.int64)
+            rank = np.zeros(c, np.int64)                               # stable rank inside the block per digit
+            seen = np.zeros(nd, np.int64)
+            for i in range(c):
+                rank[i] = seen[d[i]]; seen[d[i]] += 1
+            out[base[d] + rank] = (w & np.uint32((1 << (32 - low)) - 1)).astype(np.int64)
+            if b == fb[h]:
+                nz = cnt > 0
+                ranges[(h << low) + np.nonzero(nz)[0]] = np.stack([start[nz], start[nz] + cnt[nz]], 1)
+        return out, ranges
+
+    for tile_bits, T, R in ((9, 300, 5000), (13, 5440, 30000), (14, 8704, 9000), (16, 33124, 12000), (12, 3000, 4096), (10, 600, 1)):
+        # skewed tile distribution: a few hot tiles (buckets larger than a block), many empty ones
+        hot = rng.integers(0, T, 5)
+        tiles = np.where(rng.random(R) < 0.6, rng.choice(hot, R), rng.integers(0, T, R)).astype(np.int64)
+        ids = rng.integers(0, 1 << 20, R).astype(np.int64)
+        got, ranges = msd_sort(tiles, ids, tile_bits)
+        ref = np.argsort(tiles, kind="stable")
+        assert np.array_equal(got, ids[ref]), (tile_bits, T, R)
+        sorted_tiles = tiles[ref]
+        for t in np.unique(tiles):
+            lo, hi = np.searchsorted(sorted_tiles, t, "left"), np.searchsorted(sorted_tiles, t, "right")
+            assert tuple(ranges[t]) == (lo, hi)
+        assert int((ranges[:, 1] - ranges[:, 0]).sum()) == R
