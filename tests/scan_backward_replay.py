@@ -1,19 +1,18 @@
-"""Developer prototype (numpy, float32) of the MFMA compositing backward's arithmetic -- NOT part of the product or the
-tests.  It replays, per 8x8 pixel quadrant, exactly what ex4d_composite.hip's composite_bwd_mfma_kernel computes:
+"""Numpy (float32) replay of the arithmetic of the scan compositing backward, ex4d_composite.hip: composite_bwd_scan_kernel -- used by
+tests/test_cpu_oracle_and_host.py as a CPU-side check of the reformulations against the oracle's double-precision sums (the -m gpu
+tests check the kernel itself).  Per 8x8 pixel quadrant it does what the kernel does:
 
   * batches of 16 list entries (descending from the quadrant's deepest contributor), lane = (entry n, pixel slot);
   * the per-pixel recurrences of CR/backward.cu:571-680 as 16-lane scans with a carry per pixel:
-        T_i   = T_carry * prod_{j<=i} 1/(1-alpha_j)                      (inclusive prefix product, Hillis-Steele 1,2,4,8)
-        E_i   = E_carry + sum_{j<i} alpha_j T_j (c_j . dL_dpixel)          (exclusive prefix sum) -- accum_rec in closed form:
-                (c_i - accum_rec_i) . dL_dpixel * T_i = (c_i . dL_dpixel) T_i - E_i / (1 - alpha_i)
+        T_i    = T_carry * prod_{j<=i} 1/(1-alpha_j)                      (inclusive prefix product, Hillis-Steele 1,2,4,8)
+        Q_i    = Q_carry - sum_{j<=i} alpha_j T_j (c_j . dL_dpixel)        (Q = bgT - E: the background term folded into the carry)
+        dL_dalpha (colour + background) = inv_i ((c_i . dL_dpixel) T_i + Q_i)
         gacc_i = gacc_carry * prod_{j<=i} T_j                              (dL_dacc compounding)
-  * the 13 per-Gaussian sums as three contractions over the 64 pixels (the f32 MFMAs of the kernel):
-        D1 = [gdepth, gp0..2, gflow0..2] . dcc      D2 = [1, x, y, xx, xy, yy] . sG      D3 = [1] . s6
-    with x, y relative to the quadrant origin, converted to Gaussian-centred moments per batch.
+  * the exponent with the forward's contraction power2 = fma(dx, fma(dx, a', b' dy), (c' dy) dy), pixel-row terms hoisted;
+  * the position moments accumulated per STEP PARITY (dx is constant over the even and over the odd steps of a batch):
+        S_e/o = sum sG,  Y_e/o = sum sG dy,  V = sum sG dy^2   ->   sum sG dx = dxe S_e + dxo S_o, etc.
 
-and compares the result with the oracle's double-precision sums under the tolerance model of tests/helpers.py.
-
-    python tools/dev/proto_bwd_scan.py [cfg] [P]
+    python tests/scan_backward_replay.py [cfg] [P]
 """
 import os
 import sys
@@ -21,7 +20,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import helpers as h          # noqa: E402
 from oracle import oracle               # noqa: E402
@@ -93,7 +92,7 @@ def run(cfg="cfg1", P=None, grad_acc_zero=False):
             xr, yr = fx - ox, fy - oy
             A1 = np.stack([gdepth, gp[0], gp[1], gp[2], gflow[0], gflow[1], gflow[2]], 0)                # [7,64]
             A2 = np.stack([np.ones(64, f32), xr, yr, xr * xr, xr * yr, yr * yr], 0).astype(f32)           # [6,64]
-            Tc = T_final.copy(); Ec = np.zeros(64, f32); gaccc = gacc0.copy()
+            Tc = T_final.copy(); Qc = bgT.copy(); gaccc = gacc0.copy()
             k_desc = np.arange(deepest - 1, -1, -1)
             for b0 in range(0, len(k_desc), 16):
                 ks = k_desc[b0:b0 + 16]
@@ -103,48 +102,55 @@ def run(cfg="cfg1", P=None, grad_acc_zero=False):
                 ap = (co[ids, 0] * f32(-0.5) * log2e).astype(f32); bp = (co[ids, 1] * -log2e).astype(f32); cp = (co[ids, 2] * f32(-0.5) * log2e).astype(f32)
                 w = co[ids, 3]
                 dx = (gxm[:, None] - fx[None]).astype(f32); dy = (gym[:, None] - fy[None]).astype(f32)
-                power2 = (dx * (ap[:, None] * dx + bp[:, None] * dy) + (cp[:, None] * dy) * dy).astype(f32)
+                fma = lambda a_, b_, c_: (a_.astype(np.float64) * b_.astype(np.float64) + c_.astype(np.float64)).astype(f32)   # one rounding
+                bdy = (bp[:, None] * dy).astype(f32); cdydy = ((cp[:, None] * dy).astype(f32) * dy).astype(f32)
+                power2 = fma(dx, fma(dx, np.broadcast_to(ap[:, None], dx.shape), bdy), cdydy)
                 G = np.exp2(power2).astype(f32)
                 alpha = np.minimum(f32(0.99), w[:, None] * G).astype(f32)
                 ok = (ks[:, None] < lastc[None]) & (power2 <= 0) & ~(alpha < f32(1.0 / 255.0))
                 alpha_m = np.where(ok, alpha, f32(0)); G_m = np.where(ok, G, f32(0))
                 inv = (f32(1) / (f32(1) - alpha_m)).astype(f32)
-                Tn = (scan_mul(np.concatenate([inv[:1] * Tc[None], inv[1:]], 0))).astype(f32)               # carry seeded into entry 0
+                Tn = (Tc[None] * scan_mul(inv)).astype(f32)                     # row-uniform carry times the identity-seeded scan
                 dcc = (alpha_m * Tn).astype(f32)
                 cgp = (colors[ids, 0][:, None] * gp[0][None] + colors[ids, 1][:, None] * gp[1][None] + colors[ids, 2][:, None] * gp[2][None]).astype(f32)
                 e = (dcc * cgp).astype(f32)
-                Einc = scan_add(np.concatenate([e[:1] + Ec[None], e[1:]], 0)).astype(f32)
-                Eexc = (Einc - e).astype(f32)
+                Q = (Qc[None] - scan_add(e)).astype(f32)                        # bgT - E (inclusive)
                 flag = (depths[ids] > min_depth).astype(f32)
-                u = ((fd[None] - depths[ids][:, None]) * (gdepth[None] * flag[:, None]) * Tn).astype(f32)
-                col = (cgp * Tn - Eexc * inv).astype(f32)
-                dLa = (u * Tn + col).astype(f32)
-                dLa = (dLa + bgT[None] * inv).astype(f32)
-                gaccn = scan_mul(np.concatenate([np.where(ok[:1], Tn[:1], f32(1)) * gaccc[None], np.where(ok[1:], Tn[1:], f32(1))], 0)).astype(f32)
-                sG = ((w[:, None] * G_m) * dLa).astype(f32)
-                s6 = (G_m * (dLa + gaccn)).astype(f32)
-                Tc, Ec, gaccc = Tn[-1].copy(), Einc[-1].copy(), gaccn[-1].copy()
-                D1 = (dcc @ A1.T).astype(f32)      # [n,7]
-                D2 = (sG @ A2.T).astype(f32)       # [n,6]: M0 Mx My Mxx Mxy Myy
-                D3 = s6.sum(1).astype(f32)
-                dx0 = (gxm - ox).astype(f32); dy0 = (gym - oy).astype(f32)
-                M0, Mx, My, Mxx, Mxy, Myy = (D2[:, i] for i in range(6))
+                depflag = (depths[ids] * flag).astype(f32)
+                dLa = ((cgp * Tn + Q) * inv).astype(f32)
+                gdT = (gdepth[None] * Tn).astype(f32)
+                dLa = (dLa + ((fd[None] * flag[:, None] - depflag[:, None]) * gdT) * Tn).astype(f32)
+                gaccn = (gaccc[None] * scan_mul(np.where(ok, Tn, f32(1)))).astype(f32)
+                s6 = (G_m * dLa).astype(f32)
+                sG = (w[:, None] * s6).astype(f32)
+                s6g = (G_m * gaccn).astype(f32)
+                Tc, Qc, gaccc = Tn[-1].copy(), Q[-1].copy(), gaccn[-1].copy()
+                # pixel p = 4 s + g: step parity = (p >> 2) & 1; dx is one value on the even steps and one on the odd steps (per pixel slot g)
+                par = ((np.arange(64) >> 2) & 1).astype(bool)
                 out = np.zeros((n, 13), f32)
-                out[:, 0] = dx0 * M0 - Mx
-                out[:, 1] = dy0 * M0 - My
-                out[:, 2] = D1[:, 0] * flag
-                out[:, 3] = (dx0 * dx0) * M0 - (f32(2) * dx0) * Mx + Mxx
-                out[:, 4] = (dx0 * dy0) * M0 - dx0 * My - dy0 * Mx + Mxy
-                out[:, 5] = (dy0 * dy0) * M0 - (f32(2) * dy0) * My + Myy
-                out[:, 6] = D3
-                out[:, 7:13] = D1[:, 1:7]
+                v0 = np.zeros(n, f32); v1 = np.zeros(n, f32); v3 = np.zeros(n, f32); v4 = np.zeros(n, f32)
+                for g_ in range(4):
+                    slot = (np.arange(64) & 3) == g_
+                    for odd in (False, True):
+                        m = slot & (par == odd)
+                        S = sG[:, m].sum(1, dtype=f32); Y = (sG[:, m] * dy[:, m]).sum(1, dtype=f32)
+                        dxc = dx[:, m][:, 0]                                     # constant over these 8 pixels
+                        v0 += dxc * S; v1 += Y; v3 += (dxc * dxc) * S; v4 += dxc * Y
+                V = (sG * (dy * dy).astype(f32)).sum(1, dtype=f32)
+                out[:, 0] = (f32(2) * ap) * v0 + bp * v1
+                out[:, 1] = (f32(2) * cp) * v1 + bp * v0
+                out[:, 2] = (alpha_m * gdT).sum(1, dtype=f32) * flag
+                out[:, 3] = v3; out[:, 4] = v4; out[:, 5] = V
+                out[:, 6] = (s6 + s6g).sum(1, dtype=f32)
+                out[:, 7:10] = (dcc @ gp.T).astype(f32)
+                out[:, 10:13] = (dcc @ gflow.T).astype(f32)
                 np.add.at(acc, ids, out)
-    # to reference units
-    A, B, Cc = co[:, 0].astype(np.float64), co[:, 1].astype(np.float64), co[:, 2].astype(np.float64)
+    # accumulator layout 0 -> reference units (factors the per-Gaussian backward kernel applies: ln2 W/2, ln2 H/2, -1/2)
     a64 = acc.astype(np.float64)
     ref = a64.copy()
-    ref[:, 0] = -(A * a64[:, 0] + B * a64[:, 1]) * (0.5 * W)
-    ref[:, 1] = -(Cc * a64[:, 1] + B * a64[:, 0]) * (0.5 * H)
+    ln2 = 0.6931471805599453
+    ref[:, 0] = a64[:, 0] * (ln2 * 0.5 * W)
+    ref[:, 1] = a64[:, 1] * (ln2 * 0.5 * H)
     ref[:, 3:6] = -0.5 * a64[:, 3:6]
     tol = 1e-5 + 64 * 2.0 ** -24 * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
     err = np.abs(ref - ob["sum13"])

@@ -657,3 +657,12 @@ def test_msd_tile_sort_index_arithmetic_against_a_stable_sort():
             lo, hi = np.searchsorted(sorted_tiles, t, "left"), np.searchsorted(sorted_tiles, t, "right")
             assert tuple(ranges[t]) == (lo, hi)
         assert int((ranges[:, 1] - ranges[:, 0]).sum()) == R
+
+
+def test_scan_backward_reformulations_against_the_oracle_sums():
+    """tests/scan_backward_replay.py replays the arithmetic of composite_bwd_scan_kernel in float32 numpy (16-lane scans with carries,
+    collapsed dL_dalpha, background term folded into the carry, hoisted exponent, per-parity moment sums) and must land inside the
+    accumulator tolerance against the oracle's double-precision sums -- with and without an upstream dL_dacc."""
+    from tests import scan_backward_replay as replay
+    assert replay.run("cfg1", 200) <= 1.0
+    assert replay.run("cfg1", 200, grad_acc_zero=True) <= 1.0
