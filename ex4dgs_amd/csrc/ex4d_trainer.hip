@@ -152,20 +152,27 @@ Ex4dTrainer *ex4d_trainer_create(const Ex4dTrainerConfig *cfg, float *const *par
     return t;
 }
 
-int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix, const float *projmatrix, const float *campos,
-                      const float *background, const float *gt_image, void *stream, int32_t *num_rendered)
+// The Python-number arithmetic of c_gaussian_model.py:184-186, :364 and interpolations.py:83-86 (double precision, then float32):
+// Python's `//` and `%` on floats (floor division; the remainder takes the sign of the divisor, and the quotient is the floor of the
+// exact division except where fmod says otherwise -- float_divmod of CPython), `**` = pow.
+void ex4d_trainer_time_scalars(const Ex4dTrainerConfig *cfg, double timestamp, Ex4dAttrParams *out)
 {
-    t_err[0] = 0;
-    if (!t || !viewmatrix || !projmatrix || !campos || !background || !gt_image) return tfail(EX4D_ERR_ARG, "null argument");
-    const Ex4dTrainerConfig &c = t->cfg;
-    // ---- the Python-number arithmetic of c_gaussian_model.py:184-186, :364 and interpolations.py:83-86 (double precision, then float32)
-    Ex4dAttrParams a;
+    const Ex4dTrainerConfig &c = *cfg;
+    Ex4dAttrParams &a = *out;
     const double tp = timestamp + c.time_shift;
-    const double kf = std::floor(tp / c.interval);
-    double d = std::fmod(tp, c.interval);
-    if (d != 0.0 && ((d < 0.0) != (c.interval < 0.0))) d += c.interval;      // Python's float modulo: sign of the divisor
-    d /= c.interval;
-    a.Ns = c.Ns; a.Nd = c.Nd; a.K = c.K; a.k = (int32_t)kf;
+    // CPython float_divmod: mod = fmod(vx, wx); div = (vx - mod) / wx; adjust when the signs differ; floordiv = floor(div) rounded
+    double mod = std::fmod(tp, c.interval);
+    double div = (tp - mod) / c.interval;
+    if (mod != 0.0) {
+        if ((c.interval < 0.0) != (mod < 0.0)) { mod += c.interval; div -= 1.0; }
+    } else {
+        mod = std::copysign(0.0, c.interval);
+    }
+    double floordiv;
+    if (div != 0.0) { floordiv = std::floor(div); if (div - floordiv > 0.5) floordiv += 1.0; }
+    else floordiv = std::copysign(0.0, tp / c.interval);
+    const double d = mod / c.interval;
+    a.Ns = c.Ns; a.Nd = c.Nd; a.K = c.K; a.k = (int32_t)floordiv;
     a.t = (float)timestamp; a.duration = (float)(c.duration > 1.0 ? c.duration : 1.0);
     a.delta = (float)d;
     a.h00 = (float)(2 * std::pow(d, 3) - 3 * std::pow(d, 2) + 1);
@@ -173,6 +180,16 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
     a.h01 = (float)(-2 * std::pow(d, 3) + 3 * std::pow(d, 2));
     a.h11 = (float)(std::pow(d, 3) - std::pow(d, 2));
     a.tau = (float)(tp / c.interval); a.var_min = (float)(c.var_pad / c.interval);
+}
+
+int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix, const float *projmatrix, const float *campos,
+                      const float *background, const float *gt_image, void *stream, int32_t *num_rendered)
+{
+    t_err[0] = 0;
+    if (!t || !viewmatrix || !projmatrix || !campos || !background || !gt_image) return tfail(EX4D_ERR_ARG, "null argument");
+    const Ex4dTrainerConfig &c = t->cfg;
+    Ex4dAttrParams a;
+    ex4d_trainer_time_scalars(&c, timestamp, &a);
     float *const *p = t->param;
     if (ex4d_attributes_forward(&a, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14],
                                 t->means3D, t->rotations, t->opacities, t->scales, nullptr, stream))

@@ -18,7 +18,7 @@ from .loss import _WINDOW
 from .trainer import DEFAULT_LRS
 
 EXPORTS = ("ex4d_trainer_last_error", "ex4d_trainer_create", "ex4d_trainer_destroy", "ex4d_trainer_step", "ex4d_trainer_output",
-           "ex4d_trainer_grad", "ex4d_trainer_read", "ex4d_trainer_bytes")
+           "ex4d_trainer_grad", "ex4d_trainer_read", "ex4d_trainer_bytes", "ex4d_trainer_time_scalars")
 
 
 class Ex4dTrainerConfig(C.Structure):
@@ -45,6 +45,8 @@ def _lib():
         lib.ex4d_trainer_grad.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         lib.ex4d_trainer_read.restype = C.c_int
         lib.ex4d_trainer_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.ex4d_trainer_time_scalars.restype = None
+        lib.ex4d_trainer_time_scalars.argtypes = [C.POINTER(Ex4dTrainerConfig), C.c_double, C.POINTER(attr.Ex4dAttrParams)]
         lib.ex4d_trainer_bytes.restype = C.c_size_t
         lib.ex4d_trainer_bytes.argtypes = [C.c_void_p]
         lib._trainer_ready = True

@@ -52,6 +52,11 @@ const char *ex4d_trainer_last_error(void);
 Ex4dTrainer *ex4d_trainer_create(const Ex4dTrainerConfig *cfg, float *const *params);
 void ex4d_trainer_destroy(Ex4dTrainer *t);
 
+/* The host-side scalars of one timestamp exactly as the Python reference computes them (float floor division / modulo / ** in double,
+ * then float32) -- what ex4d_trainer_step passes to ex4d_attributes_forward; exported so that the arithmetic can be pinned without a GPU. */
+struct Ex4dAttrParams;
+void ex4d_trainer_time_scalars(const Ex4dTrainerConfig *cfg, double timestamp, struct Ex4dAttrParams *out);
+
 /* One iteration at timestamp t for the camera (viewmatrix [16], projmatrix [16], campos [3]: device), background [3] (device) against
  * gt_image [3,H,W] (device).  Asynchronous on `stream` apart from the instance-count read-back.  Returns EX4D_OK or an error code of
  * ex4d_rasterizer.h.  *num_rendered (host, may be NULL) receives the instance count. */

@@ -666,3 +666,25 @@ def test_scan_backward_reformulations_against_the_oracle_sums():
     from tests import scan_backward_replay as replay
     assert replay.run("cfg1", 200) <= 1.0
     assert replay.run("cfg1", 200, grad_acc_zero=True) <= 1.0
+
+
+def test_compiled_trainer_time_scalars_match_the_python_arithmetic():
+    """ex4d_trainer_time_scalars (C++: CPython's float divmod restated, pow) against attributes.time_scalars (the Python numbers of
+    c_gaussian_model.py:184-186, :364 and interpolations.py:83-86): all 13 fields of Ex4dAttrParams bit-identical, for integer and
+    fractional timestamps, negative ones, several intervals."""
+    from ex4dgs_amd import attributes as attr
+    from ex4dgs_amd import native_trainer as nt
+    lib = nt._lib()
+    rng = np.random.default_rng(11)
+    stamps = list(range(0, 300, 7)) + [299, 0.5, 13.25, 299.999, -3, -0.75, 1e-9] + [float(x) for x in rng.uniform(-20, 320, 60)]
+    for interval, shift, duration, var_pad in ((10, 12, 300, 3), (7.5, 9.5, 120, 2), (3, 5, 0, 1), (10, 12.000000001, 300, 3)):
+        cfg = nt.Ex4dTrainerConfig()
+        cfg.Ns, cfg.Nd, cfg.K = 5, 7, 35
+        cfg.duration, cfg.interval, cfg.time_shift, cfg.var_pad = max(duration, 1), interval, shift, var_pad
+        for t in stamps:
+            got = attr.Ex4dAttrParams()
+            lib.ex4d_trainer_time_scalars(ctypes.byref(cfg), float(t), ctypes.byref(got))
+            ref = attr.time_scalars(t, 5, 7, 35, max(duration, 1), interval, shift, var_pad)
+            for name, _ in attr.Ex4dAttrParams._fields_:
+                a, b = getattr(got, name), getattr(ref, name)
+                assert a == b or (a != a and b != b), (interval, shift, t, name, a, b)
