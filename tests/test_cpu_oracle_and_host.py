@@ -688,3 +688,24 @@ def test_compiled_trainer_time_scalars_match_the_python_arithmetic():
             for name, _ in attr.Ex4dAttrParams._fields_:
                 a, b = getattr(got, name), getattr(ref, name)
                 assert a == b or (a != a and b != b), (interval, shift, t, name, a, b)
+
+
+def test_compiled_trainer_rejects_bad_configurations_without_touching_a_device():
+    """ex4d_trainer_create validates its configuration before the first HIP call: wrong sizes come back as NULL + message (host code)."""
+    from ex4dgs_amd import native_trainer as nt
+    lib = nt._lib()
+    ptrs = (ctypes.c_void_p * 15)()
+
+    def create(**kw):
+        cfg = nt.Ex4dTrainerConfig()
+        cfg.Ns, cfg.Nd, cfg.K, cfg.W, cfg.H, cfg.sh_degree, cfg.interval = 10, 4, 35, 64, 48, 3, 10.0
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = lib.ex4d_trainer_create(ctypes.byref(cfg), ptrs)
+        return h, lib.ex4d_trainer_last_error().decode()
+    for bad in (dict(Ns=0, Nd=0), dict(W=0), dict(K=3), dict(sh_degree=4), dict(interval=0.0), dict(Ns=-1)):
+        h, msg = create(**bad)
+        assert not h and "out of range" in msg, (bad, msg)
+    h, msg = create()                      # sizes fine, but the parameter pointers are NULL
+    assert not h and "NULL" in msg
+    assert lib.ex4d_trainer_bytes(None) == 0 and lib.ex4d_trainer_output(None, 0) is None
