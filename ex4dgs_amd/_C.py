@@ -26,7 +26,7 @@ class Ex4dParams(C.Structure):
 
 
 class GeomLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("records", "cov3D", "clamped", "tiles_touched", "depth_order", "sorted_offsets", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("records", "cov3D", "clamped", "tiles_touched", "depth_order", "sorted_offsets", "rects", "total")]
 
 
 class BinningLayout(C.Structure):
@@ -83,7 +83,7 @@ EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forw
            "ex4d_forward_split_sh", "ex4d_backward_split_sh",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
            "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset",
-           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option")
+           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option", "ex4d_debug_bwd_stats")
 
 
 def library_path():
@@ -363,7 +363,8 @@ def geom_views(geomBuffer, P):
     rec = v(lay.records, 16 * P, torch.float32).view(P, 16)
     return dict(records=rec, depths=rec[:, 8], means2D=rec[:, 0:2], conic_opacity=rec[:, [2, 3, 4, 15]], rgb=rec[:, 9:12], dir3D=rec[:, 12:15],
                 cov3D=v(lay.cov3D, 6 * P, torch.float32).view(P, 6), clamped=v(lay.clamped, P, torch.uint8),
-                tiles_touched=v(lay.tiles_touched, P, torch.int32), depth_order=v(lay.depth_order, P, torch.int32))
+                tiles_touched=v(lay.tiles_touched, P, torch.int32), depth_order=v(lay.depth_order, P, torch.int32),
+                rects=v(lay.rects, 2 * P, torch.int32).view(P, 2))
 
 
 def binning_views(binningBuffer, R, W, H):
@@ -391,6 +392,16 @@ def set_option(name, value):
 
 def get_option(name):
     return int(load().ex4d_get_option(name.encode()))
+
+
+def bwd_stats(reset=True):
+    """Developer counters of the compositing backward's variant 8 (ex4d_debug_bwd_stats): batches, valid Gaussians, steps run,
+    steps skipped, contributing (pixel, Gaussian) pairs, Gaussians with a contributing pair, 2 spare."""
+    buf = (C.c_ulonglong * 8)()
+    rc = load().ex4d_debug_bwd_stats(buf, int(bool(reset)))
+    if rc != 0:
+        raise RuntimeError("ex4d_debug_bwd_stats failed")
+    return [int(x) for x in buf]
 
 
 def profile_enable(on=True):

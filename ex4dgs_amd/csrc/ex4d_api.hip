@@ -14,7 +14,6 @@ namespace {
 
 std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
-static inline int acc_layout_of(int variant) { return variant == 2 ? 1 : 0; }
 std::atomic<int> g_bwd_variant{4};
 std::atomic<int> g_tile_ids{0};
 std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
@@ -129,7 +128,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     l.cov3D = c.off;          g.cov3D = c.take<float>(6 * (size_t)P);
     l.clamped = c.off;        g.clamped = c.take<uint8_t>(P);
     l.tiles_touched = c.off;  g.tiles_touched = c.take<uint32_t>(P);
-    g.rects = c.take<uint2>(P);
+    l.rects = c.off;          g.rects = c.take<uint2>(P);
     g.sorted_rects = c.take<uint2>(P);
     l.depth_order = c.off;    g.depth_order = c.take<uint32_t>(P);
     l.sorted_offsets = c.off; g.sorted_offsets = c.take<uint32_t>(P);
@@ -197,7 +196,7 @@ ImgState carve_img(void *buf, int W, int H, Ex4dImgLayout *lay, size_t *total)
 extern "C" {
 
 const char *ex4d_last_error(void) { return g_err; }
-int ex4d_abi_version(void) { return 1; }
+int ex4d_abi_version(void) { return 2; }
 const char *ex4d_target_arch(void) { return "gfx950"; }
 
 size_t ex4d_geom_bytes(int32_t P) { size_t t; carve_geom(nullptr, P, nullptr, &t); return t; }
@@ -373,7 +372,7 @@ static int backward_impl(
     // rasterizer_impl.cu:460 takes the forward's stored covariance when none was passed in; here the kernel recomputes it from
     // scale / rotation with the forward's own function (identical bits), so only a caller-provided covariance is read
     const float *cov3D_ptr = cov3D_precomp;
-    STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16, acc_layout_of(variant),
+    STAGE(ex4d_launch_preprocess_bwd(*prm, means3D, radii, shs, scales, rotations, cov3D_ptr, viewmatrix, projmatrix, campos, g, acc16,
                                      dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir,
                                      split, gsplit, stream), prm, stream);
     MARK(1, "preprocess_bwd");
@@ -466,7 +465,7 @@ int ex4d_backward_split_sh(
 
 int ex4d_set_option(const char *name, int value)
 {
-    if (name && !strcmp(name, "composite_bwd_variant") && (value == 0 || value == 2 || value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
@@ -477,7 +476,7 @@ int ex4d_debug_bwd_stats(unsigned long long *out8, int reset) { return ex4d_bwd_
 int ex4d_get_option(const char *name)
 {
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
-    if (name && !strcmp(name, "acc_layout")) return acc_layout_of(g_bwd_variant.load());
+    if (name && !strcmp(name, "acc_layout")) return 0;
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     return -1;

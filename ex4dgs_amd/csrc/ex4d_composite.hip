@@ -288,196 +288,6 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
-#define RED_VALUES 13
-
-// sum of this lane's 16 floats (a quarter row of s_red), then across the quad: all four lanes hold the row sum
-__device__ __forceinline__ float quad_row_sum(float4 c0, float4 c1, float4 c2, float4 c3)
-{
-    float r = (((c0.x + c0.y) + (c0.z + c0.w)) + ((c1.x + c1.y) + (c1.z + c1.w))) +
-              (((c2.x + c2.y) + (c2.z + c2.w)) + ((c3.x + c3.y) + (c3.z + c3.w)));
-    r += dpp_mov<0xB1>(r);       // quad_perm [1,0,3,2]
-    r += dpp_mov<0x4E>(r);       // quad_perm [2,3,0,1]
-    return r;
-}
-
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
-    int W, int H, int gx, int num_tiles,
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-    const float *__restrict__ subpixel_offset, const float *__restrict__ bg,
-    const float4 *__restrict__ records,
-    const float *__restrict__ depth_acc, const float *__restrict__ weight_acc, float min_depth,
-    const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dpixels, const float *__restrict__ dL_ddepths,
-    const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
-    float *__restrict__ acc16)
-{
-    __shared__ float4 s_q0[WPB][64];      // x, y, a' = -A/2 log2e, b' = -B log2e
-    __shared__ float4 s_q1[WPB][64];      // c' = -C/2 log2e, w
-    __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
-    __shared__ uint32_t s_id[WPB][64];
-    __shared__ uint32_t s_orig[WPB][64];
-    __shared__ float s_red[WPB][RED_VALUES * 64];     // per-Gaussian partials, transposed through LDS (see below)
-
-    int tile, quad;
-    tile_of_block<WPB>(num_tiles, tile, quad);
-    if (tile >= num_tiles) return;
-    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
-    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
-    const uint2 range = ranges[tile];
-    const size_t HW = (size_t)H * W;
-
-    // Wave-wide sums of the 13 per-pixel partials of one Gaussian.  A register butterfly (v_permlane32/16_swap + DPP)
-    // costs ~225 VALU issue cycles per Gaussian on gfx950 (swaps issue in ~9 cycles) -- 40 % of this VALU-bound loop.
-    // Instead the partials take a trip through the otherwise idle LDS pipe: every lane stores its 13 values
-    // (row q = value, 64 floats per row), then lane l sums the 16-pixel quarter g = l&3 of row q = l>>2 from four 16-byte
-    // reads and two quad DPP adds finish the row: ~75 VALU cycles.  16-byte chunk c of row q lives at chunk c ^ q, which
-    // spreads the simultaneous chunk reads of all (q, g) evenly over the banks; stores stay lane-contiguous per row.
-    float *red_w[RED_VALUES];
-#pragma unroll
-    for (int q = 0; q < RED_VALUES; q++) red_w[q] = &s_red[wave][q * 64 + (((lane >> 2) ^ q) << 2) + (lane & 3)];
-    const int red_q = min(lane >> 2, RED_VALUES - 1);
-    const float4 *red_r[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) red_r[k] = reinterpret_cast<const float4 *>(&s_red[wave][red_q * 64 + ((((lane & 3) * 4 + k) ^ red_q) << 2)]);
-
-    // CR/backward.cu:489-549
-    const float T_final = p.inside ? final_Ts[p.pix_id] : 0.f;
-    float T = T_final;
-    const uint32_t last_contributor = p.inside ? n_contrib[p.pix_id] : 0u;
-    const float acc = p.inside ? weight_acc[p.pix_id] : 0.f;
-    const float final_depth = p.inside ? depth_acc[p.pix_id] : 0.f;
-    float gdepth = 0.f, gflow0 = 0.f, gflow1 = 0.f, gflow2 = 0.f, gacc = 0.f, gp0 = 0.f, gp1 = 0.f, gp2 = 0.f;
-    if (p.inside) {
-        // a null upstream gradient = that output did not take part in the loss (autograd would otherwise materialise zeros)
-        if (dL_ddepths) gdepth = dL_ddepths[p.pix_id];
-        if (dL_dpixels) { gp0 = dL_dpixels[p.pix_id]; gp1 = dL_dpixels[HW + p.pix_id]; gp2 = dL_dpixels[2 * HW + p.pix_id]; }
-        if (acc > 0.0f) {
-            gdepth /= acc;
-            if (dL_dflows) { gflow0 = dL_dflows[p.pix_id] / acc; gflow1 = dL_dflows[HW + p.pix_id] / acc; gflow2 = dL_dflows[2 * HW + p.pix_id] / acc; }
-            if (dL_daccs) gacc = dL_daccs[p.pix_id];
-        }
-    }
-    const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
-    float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f;
-
-    const lanemask inside = LANES(p.inside);
-    const uint32_t deepest = wave_max_u32(last_contributor);     // nothing behind it touches this quadrant
-    if (deepest == 0) return;
-    const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const int which = lane >> 2;
-    const bool writer = ((lane & 3) == 0) && (which < RED_VALUES);
-    const uint32_t kNoPending = 0xffffffffu;
-    uint32_t pending_id = kNoPending;            // wave-uniform: Gaussian whose partials sit in s_red
-
-    for (int base = 0; base < (int)deepest; base += 64) {
-        const int k = (int)deepest - 1 - base - lane;            // descending list position
-        bool keep = false;
-        uint32_t id = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k >= 0) {
-            id = point_list[range.x + k];
-            const float4 *r = records + 4 * (size_t)id;
-            q0 = r[0];
-            q1 = r[1];
-            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
-        }
-        const uint64_t mask = __ballot(keep);
-        const int cnt = __popcll(mask);
-        if (keep) {
-            const int slot = __popcll(mask & lt);
-            s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
-            s_q1[wave][slot] = make_float4(q1.x * kHalfLog2e, records[4 * (size_t)id + 3].w, 0.f, 0.f);
-            s_q2[wave][slot] = records[4 * (size_t)id + 2];
-            s_id[wave][slot] = id;
-            s_orig[wave][slot] = (uint32_t)k;
-        }
-        wave_lds_sync();
-        for (int j = 0; j < cnt; j++) {
-            const float4 g0 = s_q0[wave][j];
-            const float4 g1 = s_q1[wave][j];
-            const uint32_t orig = s_orig[wave][j];
-            // CR/backward.cu:575-590, one flat predicate (same arithmetic as the forward kernel: identical decisions)
-            const float dx = g0.x - p.fx, dy = g0.y - p.fy;
-            const float adx = g0.z * dx, bdy = g0.w * dy, cdy = g1.x * dy;
-            const float power2 = power2_of(dx, dy, g0.z, g0.w, g1.x);
-            const float G = __builtin_amdgcn_exp2f(power2);                   // exp(power)
-            const float araw = g1.y * G;
-            const float alpha = fminf(0.99f, araw);
-            const lanemask ok = inside & LANES(orig < last_contributor) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
-            if (ok == 0) continue;
-
-            // the row sums of the PREVIOUS contributing Gaussian: its partials were stored at the end of its iteration, the
-            // reads are issued now and consumed after this Gaussian's arithmetic -- the LDS round trip hides behind ~60 VALU
-            // instructions (LDS serves one wave's requests in order, so the reads see those stores without a wait)
-            const float4 c0 = *red_r[0], c1 = *red_r[1], c2 = *red_r[2], c3 = *red_r[3];
-            wave_lds_sync();
-
-            // CR/backward.cu:592-679 for all 64 lanes at once, without a divergent branch: lanes that do not
-            // contribute run the same arithmetic with alpha = G = 0, which makes every partial exactly 0 and leaves
-            // T (x 1/(1-0)), the colour recurrence (R = 0*c + 1*R) and dL_dacc (x 1) unchanged.
-            const float alpha_m = select_f(ok, alpha, 0.f);
-            const float G_m = select_f(ok, G, 0.f);
-            const float4 g2 = s_q2[wave][j];
-            const float one_m = 1.f - alpha_m;
-            const float inv1ma = __builtin_amdgcn_rcpf(one_m);
-            T = T * inv1ma;
-            const float dcc = alpha_m * T;                          // dchannel_dcolor
-            float v[RED_VALUES];
-            const float gdep = select_f(LANES(g2.x > min_depth) & LANES(dcc > 0.0f), gdepth, 0.f);
-            v[2] = gdep * dcc;
-            float dL_dalpha = (final_depth - g2.x) * gdep * T;
-            // accum_rec of the reference == colour accumulated behind this Gaussian; R is advanced after use
-            const float df0 = g2.y - rec0, df1 = g2.z - rec1, df2 = g2.w - rec2;
-            dL_dalpha += df0 * gp0;
-            dL_dalpha += df1 * gp1;
-            dL_dalpha += df2 * gp2;
-            rec0 += alpha_m * df0;          // == alpha c + (1 - alpha) rec
-            rec1 += alpha_m * df1;
-            rec2 += alpha_m * df2;
-            v[7] = dcc * gp0; v[8] = dcc * gp1; v[9] = dcc * gp2;
-            v[10] = dcc * gflow0; v[11] = dcc * gflow1; v[12] = dcc * gflow2;
-            dL_dalpha *= T;
-            gacc *= select_f(ok, T, 1.f);
-            dL_dalpha += bgT * inv1ma;
-            // with s = dL_dG * G = w G dL_dalpha:  dL_dmean2D.x = s (-(A dx + B dy)) W/2 = s (2 a' dx + b' dy) (ln2 W/2),
-            // dL_dconic.x = -s dx^2 / 2, ...; the constant factors (ln2 W/2, ln2 H/2, -1/2) are applied once per
-            // Gaussian by the preprocess backward kernel instead of once per pair here
-            const float sG = (g1.y * G_m) * dL_dalpha;
-            v[0] = sG * (2.f * adx + bdy);
-            v[1] = sG * (2.f * cdy + g0.w * dx);
-            const float sdx = sG * dx;
-            v[3] = sdx * dx;
-            v[4] = sdx * dy;
-            v[5] = (sG * dy) * dy;
-            v[6] = G_m * (dL_dalpha + gacc);
-            const float row = quad_row_sum(c0, c1, c2, c3);        // all lanes: the DPP adds read the quad neighbours
-            if (pending_id != kNoPending && writer) unsafeAtomicAdd(&acc16[16 * (size_t)pending_id + which], row);
-            wave_lds_sync();
-#pragma unroll
-            for (int q = 0; q < RED_VALUES; q++) *red_w[q] = v[q];
-            pending_id = s_id[wave][j];
-        }
-        wave_lds_sync();
-    }
-    if (pending_id != kNoPending) {
-        wave_lds_sync();
-        const float4 c0 = *red_r[0], c1 = *red_r[1], c2 = *red_r[2], c3 = *red_r[3];
-        const float row = quad_row_sum(c0, c1, c2, c3);
-        if (writer) unsafeAtomicAdd(&acc16[16 * (size_t)pending_id + which], row);
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // Compositing backward, scan version (default) -- lanes = (Gaussian, pixel slot).
 //
 // The per-pixel version above spends a third of its VALU instructions forming the 13 per-Gaussian partials and summing them over
@@ -498,18 +308,13 @@ __global__ __launch_bounds__(64 * WPB) void composite_bwd_kernel(
 // this kernel 0.35 ms, 1.79e8 (86 % VALU-busy; 55 % of the lanes of a step hold a contributing pair, 96 % of the staged
 // Gaussians contribute somewhere in their quadrant).
 //
-// MODE 0 keeps the first formulation of the sums, as contractions over the pixels on the matrix cores:
-//     [gdepth gp0 gp1 gp2 gflow0 gflow1 gflow2] . (alpha T)       [1 x y xx xy yy] . (w G dL_dalpha)       [1] . G (dL_dalpha + dL_dacc)
-// (x, y relative to the quadrant origin; Gaussian-centred moments follow from dx = dx0 - x): lane (n, g) IS the B-operand layout of
-// v_mfma_f32_16x16x4_f32 (B[k = lane>>4][n = lane&15]), the A rows are per-pixel constants held in 32 registers, three MFMAs per
-// step, results land in the lane of their Gaussian.  Correct (same parity bounds) but SLOWER than 15 VALU FMAs per step: 0.40 ms.
-// The f32-input MFMA runs at the f32 VECTOR rate and does not overlap the VALU stream here (48 v_fma + 3 MFMA issue in 224 cycles
-// against 149 for the 48 v_fma alone, tools/dev/micro/mfma_dpp_probe.hip), and only 14 of its 3 x 16 result rows are used.
-// Accumulator row layouts (per-Gaussian backward kernel, ex4d_preprocess.hip): MODE 2 writes layout 0 like the per-pixel kernel;
-// MODE 0 writes layout 1:  0 sum sG dx   1 sum sG dy   2 dL_dmean2D.z   3..5 sum sG (dx^2, dx dy, dy^2)   6 dL_dopacity   7..9 dL_dcolor
-//     10..12 dL_ddir     (sG = dL_dG G; the mean2D.xy / conic gradients are linear in these with the conic as coefficients)
+// A formulation of the 13 sums as contractions on the matrix cores (three v_mfma_f32_16x16x4_f32 per step: lane (n, g) IS the B-operand
+// layout) was built and measured in round 2: correct, but slower than 15 VALU FMAs per step (0.40 vs 0.36 ms) -- the f32-input MFMA runs
+// at the f32 VECTOR rate and does not overlap the VALU stream on this part (tools/dev/micro/mfma_dpp_probe.hip).  Removed in round 3
+// together with round 1's per-pixel kernel (DESIGN.md section 4 keeps the measurements).
+// Accumulator row (per-Gaussian backward kernel, ex4d_preprocess.hip):  0,1 dL_dmean2D.xy without the factors ln2 W/2, ln2 H/2
+//     2 dL_dmean2D.z   3..5 dL_dconic.(x,y,w) without -1/2   6 dL_dopacity   7..9 dL_dcolor   10..12 dL_ddir
 // ------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
 // lanes whose DPP source lies outside their 16-lane row keep `old`
@@ -529,8 +334,8 @@ __device__ __forceinline__ float row_scan_mul(float x)
     return x;
 }
 // list entries staged per wave (<= 15 left over + 64 new): 96 slots (indices wrap by a conditional subtraction) keep the wave's LDS at
-// 9.75 KB = 16 waves per CU, what the registers allow as well; the matrix-core variant also uses the ring as transposition scratch
-__host__ __device__ constexpr int ring_of(int MODE) { return MODE == 0 ? 128 : 96; }
+// 9.75 KB = 16 waves per CU, what the registers allow as well
+#define BWD_RING 96
 template <int R> __device__ __forceinline__ int ring_wrap(int i) { return i >= R ? i - R : i; }       // 0 <= i < 2 R
 #define DUMP_FLOATS 320          // per-wave scratch: junk target of the non-carry lanes (64 lanes + 15 steps x 16 floats), epilogue staging
 
@@ -569,22 +374,19 @@ __device__ __forceinline__ float row_scan_add_asm(float x)
     return x;
 }
 
-// MODE: how the 13 sums over the pixels are formed
-//   0  three f32 MFMAs per step (dcc, sG, s6 against per-pixel constant rows held in registers)
-//   2  every lane accumulates the 13 Gaussian-centred partial sums of its 16 pixels in registers (15 VALU per step), the four
-//      pixel-slot lanes of a Gaussian are added in the epilogue                                            (default)
-//   4  = 2 plus the developer statistics of g_bwd_stats
+// Every lane accumulates the 13 Gaussian-centred partial sums of its 16 pixels in registers (15 VALU per step), the four pixel-slot
+// lanes of a Gaussian are added in the epilogue.  STATS = true additionally counts into g_bwd_stats (developer variant 8).
 // EXTRA = false: no pixel of the quadrant has an upstream depth or flow gradient (training on the image alone) -- the depth term of
 // dL_dalpha and four of the 13 sums drop out (compile-time, so the common all-gradients path carries no extra branches)
 // SEP = true: every pixel of the quadrant sits at its integer coordinates (no sub-pixel offsets), so dx / dy are not read per pixel
 // NOLAST = true: the batch is full and all of its entries lie in front of every pixel's last contributor (wave-uniform, decided
 // by the caller from the first = deepest entry): the per-pair test `list position < last contributor` is dropped
-template <int MODE, bool EXTRA, bool SEP, bool NOLAST>
-__device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
-                                          const float (&A1)[16], const float (&A2)[16], float *__restrict__ acc16)
+template <bool STATS, bool EXTRA, bool SEP, bool NOLAST>
+__device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
+                                          float *__restrict__ acc16)
 {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    constexpr int RING = ring_of(MODE);
+    constexpr int RING = BWD_RING;
     const int slot = ring_wrap<RING>(head + n);
     const float4 g0 = L.ring[0][slot], g1 = L.ring[1][slot], g2 = L.ring[2][slot];
     const bool valid = n < nvalid;
@@ -594,14 +396,13 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
     const uint32_t orig = (uint32_t)select_i(LANES(valid), (int)__float_as_uint(g2.w), -1);
     const float flagf = dep > min_depth ? 1.f : 0.f;       // CR/backward.cu:603
     const float depflag = dep * flagf;
-    f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f}, D3 = {0.f, 0.f, 0.f, 0.f};
     float v[13];
 #pragma unroll
     for (int q = 0; q < 13; q++) v[q] = 0.f;
     // carries of pixel 4s+g are written by lane n == 15 of row g; the other lanes write into the dump area (no exec masking)
     float2 *wTQ = (n == 15) ? reinterpret_cast<float2 *>(&L.pb[g].z) : reinterpret_cast<float2 *>(&L.dump[2 * (lane & 31)]);
     float *wG = (n == 15) ? (&L.pc[g].w) : (&L.dump[lane]);
-    const bool rd_pc = (EXTRA && MODE != 0) || use_gacc;       // wave-uniform
+    const bool rd_pc = EXTRA || use_gacc;       // wave-uniform
     // the per-pixel constants / carries of step s + 1 are requested before step s runs (its LDS latency hides behind the step;
     // the carries of pixels 4(s+1)+g are last written one batch earlier, so the early read sees the right values)
     float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = make_float4(0.f, 0.f, 0.f, 0.f), pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -610,7 +411,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
     unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
     const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
     float dyr = 0.f, bdy = 0.f, cdydy = 0.f, dy2 = 0.f;
-    constexpr bool MOMENTS = SEP && MODE != 0;     // see the accumulation below
+    constexpr bool MOMENTS = SEP;     // see the accumulation below
 #pragma unroll
     for (int s = 0; s < 16; s++) {
         const float4 pa = pa_n, pb = pb_n, pc = pc_n, pd = pd_n;
@@ -635,7 +436,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
         const float alpha = fminf(0.99f, w * G);
         const lanemask ok = NOLAST ? (LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)))
                                    : (LANES(orig < __float_as_uint(pb.y)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)));
-        if (MODE == 4) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
+        if (STATS) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         const float alpha_m = select_f(ok, alpha, 0.f);
         const float G_m = select_f(ok, G, 0.f);
@@ -661,14 +462,10 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
         if (use_gacc) {             // wave-uniform
             // dL_dacc *= T for every contributor (CR/backward.cu:650), then dL_dopacity += G (dL_dalpha + dL_dacc)
             const float ga = pc.w * row_scan_mul(select_f(ok, T, 1.f));
-            if (MODE == 0) s6 += G_m * ga; else v[6] += G_m * ga;
+            v[6] += G_m * ga;
             wG[16 * s] = ga;
         }
-        if (MODE == 0) {
-            D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[s], dcc, D1, 0, 0, 0);
-            D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], sG, D2, 0, 0, 0);
-            D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[s], s6, D3, 0, 0, 0);
-        } else {
+        {
             if (EXTRA) v[2] += alpha_m * gdT;
             v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
             if (EXTRA) { v[10] += dcc * pc.x; v[11] += dcc * pc.y; v[12] += dcc * pc.z; }
@@ -689,14 +486,14 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
     // The sums leave the wave like in the per-pixel kernel -- one atomic instruction covers whole 64-byte accumulator rows
     // (13 neighbouring floats per Gaussian, 4 Gaussians per instruction) -- after a 1 KB transposition through LDS; 13 separate
     // 16-lane atomics per batch would send 13x the requests to L2 (measured: 4.4x the kernel time).
-    if (MODE == 4 && lane == 0) {
+    if (STATS && lane == 0) {
         const unsigned long long any16 = (st_any | (st_any >> 16) | (st_any >> 32) | (st_any >> 48)) & 0xffffull;
         atomicAdd(&g_bwd_stats[0], 1ull); atomicAdd(&g_bwd_stats[1], (unsigned long long)nvalid); atomicAdd(&g_bwd_stats[2], st_run);
         atomicAdd(&g_bwd_stats[3], st_skip); atomicAdd(&g_bwd_stats[4], st_pairs); atomicAdd(&g_bwd_stats[5], (unsigned long long)__popcll(any16));
     }
     wave_lds_sync();
     float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
-    if (MODE == 2 || MODE == 4) {
+    {
         if (MOMENTS) {
             const float Se = v[0], Ye = v[1], So = v[3], Yo = v[4];
             v[0] = dxe * Se + dxo * So;
@@ -734,23 +531,6 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
             const int q = 4 * j + ((g & 1) << 1) + (g >> 1);    // rows 0 1 2 3 hold sums a c b d
             if (q < 13) out[q] = r;
         }
-    } else {
-        // lane (n, g) holds rows 4g..4g+3 of column n: sums of ITS Gaussian; moments about the quadrant origin -> Gaussian-centred
-        const float dxb = g0.x - ox, dyb = g0.y - oy;
-        if (g == 0) {               // A1 rows: gdepth gp0 gp1 gp2      A2 rows: 1 x xx 0
-            out[2] = D1[0] * flagf;
-            out[7] = D1[1]; out[8] = D1[2]; out[9] = D1[3];
-            out[0] = dxb * D2[0] - D2[1];
-            out[3] = (dxb * dxb) * D2[0] - (2.f * dxb) * D2[1] + D2[2];
-        } else if (g == 1) {        // A1 rows: gflow0 gflow1 gflow2 0   A2 rows: 1 y yy 0
-            out[10] = D1[0]; out[11] = D1[1]; out[12] = D1[2];
-            out[1] = dyb * D2[0] - D2[1];
-            out[5] = (dyb * dyb) * D2[0] - (2.f * dyb) * D2[1] + D2[2];
-        } else if (g == 2) {        // A2 rows: 1 x y xy
-            out[4] = (dxb * dyb) * D2[0] - dyb * D2[1] - dxb * D2[2] + D2[3];
-        } else {                    // A2 rows: 1 0 0 0
-            out[6] = D3[0];
-        }
     }
     wave_lds_sync();
 #pragma unroll
@@ -763,7 +543,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<ring_of(MODE)> &L, int head, i
     wave_lds_sync();
 }
 
-template <int WPB, int MODE>
+template <int WPB, bool STATS>
 __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -775,7 +555,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
     float *__restrict__ acc16, const unsigned long long *__restrict__ cull_masks)
 {
-    constexpr int RING = ring_of(MODE);
+    constexpr int RING = BWD_RING;
     __shared__ BwdLdsT<RING> lds[WPB];
     int tile, quad;
     tile_of_block<WPB>(num_tiles, tile, quad);
@@ -816,38 +596,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const bool sep = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
     const bool use_extra = LANES(gdepth != 0.0f || gflow0 != 0.0f || gflow1 != 0.0f || gflow2 != 0.0f) != 0;
 
-    // ---- A operands: row i = lane & 15 of the per-pixel constant matrices, k = pixel 4s + g  ->  one register per step.
-    // Transposed through the (not yet used) ring area: lane = pixel writes its column, lane = (i, g) reads its row entries.
-    float A1[16], A2[16];
-    if (MODE == 0) {
-        float *pt2 = reinterpret_cast<float *>(&L.ring[0][0]);      // [64][16]
-        float *pt1 = reinterpret_cast<float *>(&L.ring[2][0]);      // [64][8]
-        float4 *w2 = reinterpret_cast<float4 *>(pt2 + 16 * lane);
-        w2[0] = make_float4(1.f, xr, xr * xr, 0.f);
-        w2[1] = make_float4(1.f, yr, yr * yr, 0.f);
-        w2[2] = make_float4(1.f, xr, yr, xr * yr);
-        w2[3] = make_float4(1.f, 0.f, 0.f, 0.f);
-        float4 *w1 = reinterpret_cast<float4 *>(pt1 + 8 * lane);
-        w1[0] = make_float4(gdepth, gp0, gp1, gp2);
-        w1[1] = make_float4(gflow0, gflow1, gflow2, 0.f);
-        wave_lds_sync();
-        const int i = lane & 15, g = lane >> 4;
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            A2[s] = pt2[16 * (4 * s + g) + i];
-            A1[s] = pt1[8 * (4 * s + g) + (i & 7)];
-            A1[s] = i < 8 ? A1[s] : 0.f;
-        }
-        wave_lds_sync();
-    } else {
-        // no transposition scratch: the ring holds finite values from the start (stale entries are read by invalid lanes)
-        for (int i = lane; i < RING; i += 64) {
-            L.ring[0][i] = make_float4(0.f, 0.f, 0.f, 0.f); L.ring[1][i] = make_float4(0.f, 0.f, 0.f, 0.f); L.ring[2][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int s = 0; s < 16; s++) { A1[s] = 0.f; A2[s] = 0.f; }
-        wave_lds_sync();
+    // the ring holds finite values from the start (stale entries are read by invalid lanes)
+    for (int i = lane; i < RING; i += 64) {
+        L.ring[0][i] = make_float4(0.f, 0.f, 0.f, 0.f); L.ring[1][i] = make_float4(0.f, 0.f, 0.f, 0.f); L.ring[2][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    wave_lds_sync();
 
     int head = 0, tail = 0, count = 0;                            // wave-uniform ring indices in [0, RING) and the number of staged entries
     {
@@ -890,8 +643,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
                 // first entry of the batch = its deepest: wave-uniform read of its list position
                 const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(L.ring[2][head].w));
                 const bool nolast = nb == 16 && kfirst < min_last;
-#define BATCH(E, S, N) bwd_batch<MODE, E, S, N>(L, head, nb, ox, oy, min_depth, use_gacc, A1, A2, acc16)
-                if (MODE == 0 || !sep) BATCH(true, false, false);
+#define BATCH(E, S, N) bwd_batch<STATS, E, S, N>(L, head, nb, ox, oy, min_depth, use_gacc, acc16)
+                if (!sep) BATCH(true, false, false);
                 else if (use_extra) { if (nolast) BATCH(true, true, true); else BATCH(true, true, false); }
                 else { if (nolast) BATCH(false, true, true); else BATCH(false, true, false); }
 #undef BATCH
@@ -925,8 +678,8 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
     return hipGetLastError();
 }
 
-// variant: 0 = per-pixel lanes + LDS reduction; 2 = scan version with the sums on the matrix cores (accumulator layout 1);
-//          4 = scan version with register accumulation and the forward kernel's cull masks (default); 8 = 4 + developer statistics
+// variant: 4 = (Gaussian, pixel-slot) lanes with register accumulation and the forward kernel's cull masks (default);
+//          8 = 4 + developer statistics (g_bwd_stats)
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
@@ -937,10 +690,8 @@ hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges,
     const int Tpad = 8 * ((T + 7) / 8);
 #define BWD_ARGS prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, out_depth, out_acc, prm.min_depth, \
                  final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16
-    if (variant == 0) hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(Tpad), dim3(256), 0, stream, BWD_ARGS);
-    else if (variant == 2) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, 0>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
-    else if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, 4>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
-    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, 2>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
+    if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, true>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
+    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, false>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
 #undef BWD_ARGS
     return hipGetLastError();
 }

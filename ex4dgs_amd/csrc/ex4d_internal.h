@@ -77,7 +77,7 @@ hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *vi
 
 hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3D, const int32_t *radii,
     const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
-    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16, int acc_layout,
+    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
     float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
     float *dL_dscales, float *dL_drotations, float *dL_ddir, ShSplit split, ShSplitGrad gsplit, hipStream_t stream);
 

@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float scale_modifier, const float *__restrict__ cov3Ds, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos,
     int W, int H, float fx, float fy, float tanx, float tany, float kernel_size,
-    const float *__restrict__ acc16, int acc_layout, const float4 *__restrict__ records,
+    const float *__restrict__ acc16, const float4 *__restrict__ records,
     float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir, const ShSplit sp, const ShSplitGrad gsp)
@@ -776,13 +776,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         const float4 r0 = in_r0, r1 = in_r1, r2 = in_r2, r3 = in_r3;
         // factors the compositing backward defers to here (ex4d_composite.hip): ln2 W/2, ln2 H/2 (CR/backward.cu:548-549,
         // :669-670) and -1/2 (:673-675)
-        if (acc_layout == 0) {
-            g_mean2D[0] = r0.x * (0.6931471805599453f * (0.5f * W)); g_mean2D[1] = r0.y * (0.6931471805599453f * (0.5f * H));
-        } else {
-            const float4 c0 = records[4 * (size_t)idx], c1 = records[4 * (size_t)idx + 1];        // conic: A = c0.z, B = c0.w, C = c1.x
-            g_mean2D[0] = -(c0.z * r0.x + c0.w * r0.y) * (0.5f * W);
-            g_mean2D[1] = -(c1.x * r0.y + c0.w * r0.x) * (0.5f * H);
-        }
+        g_mean2D[0] = r0.x * (0.6931471805599453f * (0.5f * W)); g_mean2D[1] = r0.y * (0.6931471805599453f * (0.5f * H));
         g_mean2D[2] = r0.z;
         const float gA = -0.5f * r0.w, gB = -0.5f * r1.x, gC = -0.5f * r1.y;
         g_opacity = r1.z;
@@ -1008,7 +1002,7 @@ hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *vi
 
 hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3D, const int32_t *radii,
     const float *shs, const float *scales, const float *rotations, const float *cov3D_ptr,
-    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16, int acc_layout,
+    const float *viewmatrix, const float *projmatrix, const float *campos, GeomState g, const float *acc16,
     float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacity, float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
     float *dL_dscales, float *dL_drotations, float *dL_ddir, ShSplit split, ShSplitGrad gsplit, hipStream_t stream)
 {
@@ -1016,7 +1010,7 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
     const float fx = prm.W / (2.0f * prm.tanfovx);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
         prm.P, prm.D, prm.M, means3D, radii, shs, g.clamped, scales, rotations, prm.scale_modifier, cov3D_ptr,
-        viewmatrix, projmatrix, campos, prm.W, prm.H, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16, acc_layout, g.records,
+        viewmatrix, projmatrix, campos, prm.W, prm.H, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16, g.records,
         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir, split, gsplit);
     return hipGetLastError();
 }

@@ -174,6 +174,8 @@ typedef struct Ex4dGeomLayout {
     size_t tiles_touched;   /* uint32[P]           with option "geom_debug_arrays" = 1 only */
     size_t depth_order;     /* uint32[P]           Gaussian ids, stable-sorted by depth key (visible first) */
     size_t sorted_offsets;  /* uint32[P]           block-local inclusive scan of tiles_touched in depth order */
+    size_t rects;           /* uint2[P]            tile rect (getRect, auxiliary.h:46-56): .x = x0 | y0 << 16, .y = w | h << 16;
+                                                   w * h == tiles_touched; defined for visible Gaussians */
     size_t total;
 } Ex4dGeomLayout;
 typedef struct Ex4dBinningLayout {
@@ -192,16 +194,14 @@ void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out);
 void ex4d_binning_layout(int32_t num_rendered, int32_t W, int32_t H, Ex4dBinningLayout *out);
 void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
 /* offset of the packed per-Gaussian accumulator rows (float[P][16]) inside bwd_scratch -- for parity tests only.
- * Row contents depend on ex4d_get_option("acc_layout"):
- *   0: 0..2 dL_dmean2D.xyz (xy without the factors ln2 W/2, ln2 H/2), 3..5 dL_dconic.(x,y,w) (without -1/2), 6 dL_dopacity,
- *      7..9 dL_dcolor, 10..12 dL_ddir
- *   1: 0,1 = sum sG dx, sum sG dy; 2 dL_dmean2D.z; 3..5 = sum sG dx^2, sum sG dx dy, sum sG dy^2 (sG = dL_dG G, d = mean2D - pixel);
- *      6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir */
+ * Row: 0..2 dL_dmean2D.xyz (xy without the factors ln2 W/2, ln2 H/2), 3..5 dL_dconic.(x,y,w) (without -1/2), 6 dL_dopacity,
+ *      7..9 dL_dcolor, 10..12 dL_ddir   (ex4d_get_option("acc_layout") == 0; a second layout existed in round 2) */
 size_t ex4d_backward_scratch_acc_offset(int32_t P);
 
 /* Tuning knobs (process-wide; results are the same within float rounding whatever the setting):
- *   "composite_bwd_variant"  0 = per-pixel lanes + LDS reduction, 2 = (Gaussian, pixel-slot) lanes with the sums on the matrix
- *                            cores, 4 = the same lanes with register accumulation (default), 8 = 4 + developer statistics
+ *   "composite_bwd_variant"  4 = (Gaussian, pixel-slot) lanes with register accumulation (default), 8 = 4 + developer statistics
+ *                            (ex4d_debug_bwd_stats).  Round 1's per-pixel kernel (0) and the matrix-core formulation of the sums (2)
+ *                            were measured slower and are no longer part of the library.
  *   "binning_tile_ids"       1 = also write the sorted tile ids (Ex4dBinningLayout.tile_ids); 0 (default) = that region is scratch of
  *                            the tile sort -- nothing downstream reads the ids, the tile ranges carry the same information.  (Images with
  *                            <= 256 or > 65536 tiles, or more than 2^(32 - ceil(tile bits / 2)) Gaussians, take the key/value sort,
@@ -212,6 +212,9 @@ size_t ex4d_backward_scratch_acc_offset(int32_t P);
  * ex4d_get_option additionally answers "acc_layout" (see above).  Returns EX4D_OK / the value, or an error / -1. */
 int ex4d_set_option(const char *name, int value);
 int ex4d_get_option(const char *name);
+/* developer counters of "composite_bwd_variant" 8 since the last reset: [0] batches, [1] valid Gaussians, [2] steps run,
+ * [3] steps skipped, [4] contributing (pixel, Gaussian) pairs, [5] Gaussians with a contributing pair, [6..7] spare */
+int ex4d_debug_bwd_stats(unsigned long long *out8, int reset);
 
 /* Optional per-stage timing (hipEvents on the caller's stream, single host thread; used by bench.py).
  * ex4d_profile_read(which = 0 forward / 1 backward) waits for the last recorded call of that kind and

@@ -440,8 +440,14 @@ void ex4d_oracle_render_fwd(
     const float *bg_color, float min_depth, float max_depth,
     float *final_T, uint32_t *n_contrib,
     float *out_color /*[3,H,W]*/, float *out_depth, float *out_acc, float *out_flow /*[3,H,W]*/, int32_t *out_idx,
-    float *fragile /* may be NULL */, float *idx_margin /* may be NULL */)
+    float *fragile /* may be NULL */, float *idx_margin /* may be NULL */,
+    float frag_eps, float *flip_w /* may be NULL */)
 {
+    /* flip_w (optional, test instrumentation): per pixel, the summed blending weight of every decision that lies within
+     * frag_eps of its threshold -- what a flipped decision can move: a contributor that appears / disappears carries the
+     * weight alpha*T it would have had (alpha ~ 1/255 at the alpha threshold, <= min(0.99, opacity) at power ~ 0), a flipped
+     * termination test (CR/forward.cu:383-387) frees or drops everything behind it, which carries at most the transmittance T
+     * at that point.  |delta colour| <= flip_w * 2 max|c| (the flipped pair itself plus the rescaling of everything behind it). */
     /* idx_margin (optional, test instrumentation): per pixel, the smallest relative difference of any "alpha*T > max_vis"
      * comparison that decides the dominant index: an argmax over float weights swaps on 1-ulp differences when two weights tie */
     (void)min_depth;
@@ -460,7 +466,7 @@ void ex4d_oracle_render_fwd(
             float C[3] = { 0, 0, 0 };
             float Dm = 0.0f, acc = 0.0f, max_vis = 0.0f;
             float F[3] = { 0, 0, 0 };
-            float frag = 1.0f, imarg = 1.0f;
+            float frag = 1.0f, imarg = 1.0f, flipw = 0.0f;
             int done = 0;
             /* toDo is a signed int in the reference; r1 >= r0 always */
             for (uint32_t k = r0; k < r1 && !done; k++) {
@@ -471,15 +477,24 @@ void ex4d_oracle_render_fwd(
                 const float power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
                 if (fragile) {
                     float mag = 0.5f * (fabsf(con_o[0] * dx * dx) + fabsf(con_o[2] * dy * dy)) + fabsf(con_o[1] * dx * dy);
-                    if (mag > 0.0f && con_o[3] >= 1.0f / 255.0f) { float m = fabsf(power) / mag; if (m < frag) frag = m; }
+                    if (mag > 0.0f && con_o[3] >= 1.0f / 255.0f) {
+                        float m = fabsf(power) / mag; if (m < frag) frag = m;
+                        if (flip_w && m < frag_eps) flipw += fminf(0.99f, con_o[3]) * T;
+                    }
                 }
                 if (power > 0.0f) continue;
                 const float ex = expf(power);
                 float alpha = fminf(0.99f, con_o[3] * ex);
-                if (fragile) { float m = fabsf(con_o[3] * ex - 1.0f / 255.0f) * 255.0f; if (m < frag) frag = m; }
+                if (fragile) {
+                    float m = fabsf(con_o[3] * ex - 1.0f / 255.0f) * 255.0f; if (m < frag) frag = m;
+                    if (flip_w && m < frag_eps) flipw += fmaxf(alpha, 1.0f / 255.0f) * T;
+                }
                 if (alpha < 1.0f / 255.0f) continue;
                 float test_T = T * (1 - alpha);
-                if (fragile) { float m = fabsf(test_T - 0.0001f) / 0.0001f; if (m < frag) frag = m; }
+                if (fragile) {
+                    float m = fabsf(test_T - 0.0001f) / 0.0001f; if (m < frag) frag = m;
+                    if (flip_w && m < frag_eps) flipw += T;
+                }
                 if (test_T < 0.0001f) { done = 1; continue; }
                 for (int ch = 0; ch < 3; ch++) C[ch] += features[id * 3 + ch] * alpha * T;
                 float dep = depths[id];
@@ -506,6 +521,7 @@ void ex4d_oracle_render_fwd(
             for (int ch = 0; ch < 3; ch++) out_flow[(size_t)ch * H * W + pix_id] = F[ch];
             if (fragile) fragile[pix_id] = frag;
             if (idx_margin) idx_margin[pix_id] = imarg;
+            if (flip_w) flip_w[pix_id] = flipw;
         }
 }
 
@@ -527,8 +543,13 @@ void ex4d_oracle_render_bwd(
     const float *dL_dpixels /*[3,H,W]*/, const float *dL_ddepths, const float *dL_dflows /*[3,H,W]*/, const float *dL_daccs,
     float *dL_dmean2D /*[P,3]*/, float *dL_dconic2D /*[P,4]*/, float *dL_ddir /*[P,3]*/,
     float *dL_dopacity /*[P]*/, float *dL_dcolors /*[P,3]*/,
-    double *sum13, double *abs13)
+    double *sum13, double *abs13,
+    const uint32_t *pixel_order /* may be NULL: row-major */)
 {
+    /* pixel_order (optional, test instrumentation): a permutation of the pixel ids.  The reference's threads (one per pixel) add
+     * their terms with float atomicAdd (CR/backward.cu:613-679): the order in which the terms of different pixels reach one
+     * accumulator is arbitrary and differs from run to run.  Replaying the pixel loop in several random orders measures the
+     * reference's own float32 run-to-run spread (the noise floor the parity tolerances are anchored to). */
     (void)max_depth;
     const int gx = (W + BLOCK_X - 1) / BLOCK_X;
     const float ddelx_dx = (float)(0.5 * W);
@@ -539,9 +560,9 @@ void ex4d_oracle_render_bwd(
 #define ACCM(ptr, k, val, mag) do { float v_ = (val); *(ptr) += v_; \
         if (sum13) { sum13[13 * (size_t)global_id + (k)] += (double)v_; abs13[13 * (size_t)global_id + (k)] += (double)(mag) * cond; } } while (0)
 #define ACC(ptr, k, val) ACCM(ptr, k, val, fabs((double)v_))
-    for (int py = 0; py < H; py++)
-        for (int px = 0; px < W; px++) {
-            const uint32_t pix_id = (uint32_t)(W * py + px);
+    for (size_t pn = 0; pn < (size_t)W * (size_t)H; pn++) {
+            const uint32_t pix_id = pixel_order ? pixel_order[pn] : (uint32_t)pn;
+            const int py = (int)(pix_id / (uint32_t)W), px = (int)(pix_id % (uint32_t)W);
             float pixf_x = (float)px, pixf_y = (float)py;
             pixf_x += subpixel_offset[2 * pix_id];
             pixf_y += subpixel_offset[2 * pix_id + 1];

@@ -70,7 +70,7 @@ def mark_visible(means3D, viewmatrix, projmatrix, min_depth, max_depth):
 def forward(means3D, dir3D, opacities, *, shs=None, colors_precomp=None, scales=None, rotations=None,
             cov3D_precomp=None, bg, viewmatrix, projmatrix, campos, image_height, image_width,
             tanfovx, tanfovy, kernel_size, subpixel_offset=None, scale_modifier=1.0, sh_degree=0,
-            prefiltered=False, min_depth=0.2, max_depth=100.0, want_fragile=True):
+            prefiltered=False, min_depth=0.2, max_depth=100.0, want_fragile=True, frag_eps=1e-4):
     """Returns a dict with the six public outputs (color, radii, depth, flow, acc, idx), num_rendered,
     and every internal array (geometry / binning / image state)."""
     L = lib()
@@ -139,11 +139,13 @@ def forward(means3D, dir3D, opacities, *, shs=None, colors_precomp=None, scales=
     out["n_contrib"] = np.zeros((H, W), np.uint32)
     out["fragile"] = np.ones((H, W), np.float32) if want_fragile else None
     out["idx_margin"] = np.ones((H, W), np.float32) if want_fragile else None
+    # summed blending weight of the decisions within frag_eps of their threshold: bounds what a flipped decision moves (per pixel)
+    out["flip_w"] = np.zeros((H, W), np.float32) if want_fragile else None
     L.ex4d_oracle_render_fwd(
         C.c_int(W), C.c_int(H), _p(b["ranges"]), _p(b["point_list"]), _p(sub), _p(g["means2D"]), _p(features),
         _p(g["conic_opacity"]), _p(g["depths"]), _p(dir3D), _p(bg), C.c_float(min_depth), C.c_float(max_depth),
         _p(out["final_T"]), _p(out["n_contrib"]), _p(out["color"]), _p(out["depth"]), _p(out["acc"]), _p(out["flow"]),
-        _p(out["idx"]), _p(out["fragile"]), _p(out["idx_margin"]))
+        _p(out["idx"]), _p(out["fragile"]), _p(out["idx_margin"]), C.c_float(frag_eps), _p(out["flip_w"]))
     out["_inputs"] = dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                           cov3D_precomp=cov3D_precomp, bg=bg, vm=vm, pm=pm, cp=cp, sub=sub, tanfovx=float(tanfovx),
                           tanfovy=float(tanfovy), kernel_size=float(kernel_size), scale_modifier=float(scale_modifier),
@@ -151,9 +153,11 @@ def forward(means3D, dir3D, opacities, *, shs=None, colors_precomp=None, scales=
     return out
 
 
-def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True):
+def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True, pixel_order=None, stage=True):
     """fwd = dict returned by forward().  Returns the nine tensors of
-    RasterizeGaussiansBackwardCUDA (rasterize_points.cu:233) plus internals."""
+    RasterizeGaussiansBackwardCUDA (rasterize_points.cu:233) plus internals.
+    pixel_order: optional permutation of the H*W pixel ids -- the order in which the pixels' terms reach the float32 accumulators
+    (the reference's atomicAdd order is arbitrary; see backward_noise).  stage=False stops after the compositing backward."""
     L = lib()
     P, W, H, M, D = fwd["P"], fwd["W"], fwd["H"], fwd["M"], fwd["D"]
     res = dict(
@@ -178,9 +182,40 @@ def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True):
         _p(fwd["depth"]), _p(fwd["acc"]), C.c_float(i["min_depth"]), C.c_float(i["max_depth"]),
         _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(gc), _p(gd), _p(gf), _p(ga),
         _p(res["dL_dmeans2D"]), _p(res["dL_dconic"]), _p(res["dL_ddir"]), _p(res["dL_dopacity"]), _p(res["dL_dcolors"]),
-        _p(res["sum13"]), _p(res["abs13"]))
-    preprocess_backward(fwd, res)
+        _p(res["sum13"]), _p(res["abs13"]), _p(None if pixel_order is None else np.ascontiguousarray(pixel_order, dtype=np.uint32)))
+    if stage:
+        preprocess_backward(fwd, res)
     return res
+
+
+def acc13_of(res):
+    """The 13 accumulated quantities per Gaussian of a backward() result as one [P,13] float32 array (index convention of
+    ex4d_oracle_render_bwd: 0..2 dL_dmean2D, 3..5 dL_dconic.(x,y,w), 6 dL_dopacity, 7..9 dL_dcolor, 10..12 dL_ddir)."""
+    c = res["dL_dconic"]
+    return np.concatenate([res["dL_dmeans2D"], c[:, 0:2], c[:, 3:4], res["dL_dopacity"].reshape(-1, 1), res["dL_dcolors"], res["dL_ddir"]],
+                          axis=1).astype(np.float32)
+
+
+def backward_noise(fwd, grad_color, grad_depth, grad_flow, grad_acc, orders=8, seed=0, threads=None):
+    """The reference's own float32 noise floor: its compositing backward adds every pixel's terms with float atomicAdd
+    (CR/backward.cu:613-679), so the summation order -- and with it the float32 result -- changes from run to run.  Replays the
+    oracle's backward with the pixel loop in `orders` random orders (float32 accumulation, like the reference) and returns the
+    list of [P,13] float32 accumulator arrays, one per order.  The spread of these around the exact (double) sums is what two
+    runs of the reference itself differ by; the parity tolerances are stated in multiples of it (tests/helpers.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    HW = fwd["H"] * fwd["W"]
+    rng = np.random.default_rng(seed)
+    perms = [rng.permutation(HW).astype(np.uint32) for _ in range(orders)]
+
+    def run(perm):
+        r = backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=False, pixel_order=perm, stage=False)
+        return acc13_of(r)
+    if threads is None:
+        threads = min(orders, os.cpu_count() or 1)
+    if threads <= 1:
+        return [run(p) for p in perms]
+    with ThreadPoolExecutor(threads) as ex:           # ctypes releases the GIL inside the C call
+        return list(ex.map(run, perms))
 
 
 def preprocess_backward(fwd, res):

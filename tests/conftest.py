@@ -26,6 +26,18 @@ def hip_lib():
     return lib
 
 
+@pytest.fixture()
+def hip_lib_defaults(hip_lib):
+    """The library exactly as bench.py times it: no debug arrays, no materialised tile ids (lean geometry path, the backward
+    recomputing the covariance, the tile-id region used as sort scratch).  Restores the test options afterwards."""
+    from ex4dgs_amd import _C
+    _C.set_option("binning_tile_ids", 0)
+    _C.set_option("geom_debug_arrays", 0)
+    yield hip_lib
+    _C.set_option("binning_tile_ids", 1)
+    _C.set_option("geom_debug_arrays", 1)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Parity numbers of the run (achieved max-abs / relative errors per gradient tensor, fragile-pixel counts) -> gpurun_out/parity_report.json,
     so that "1e-5" is a number in a file and not only an assertion that passed."""

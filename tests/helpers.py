@@ -93,29 +93,14 @@ def gpu_backward_raw(ins, fwd, grads, device="cuda"):
     return res
 
 
-def acc_layout():
-    """Layout of the compositing backward's accumulator rows (include/ex4d_rasterizer.h: ex4d_get_option("acc_layout"))."""
-    from ex4dgs_amd import _C
-    return _C.get_option("acc_layout")
-
-
 def acc16_in_reference_units(acc16, W, H, conic=None, layout=None):
     """Accumulator rows of the compositing backward -> the reference's dL_dmean2D.xyz / dL_dconic.(x,y,w) / ... (float32,
-    the same operations in the same order as the per-Gaussian backward kernel, so the result is bit-identical to what it uses).
-    layout 0: xy and conic sums lack their constant factors (ln2*W/2, ln2*H/2, -1/2).
-    layout 1: rows hold the moments sum sG d, sum sG d d^T; the mean2D gradient is -(A Sx + B Sy) W/2, -(C Sy + B Sx) H/2."""
-    layout = acc_layout() if layout is None else layout
+    the same operations in the same order as the per-Gaussian backward kernel, so the result is bit-identical to what it uses):
+    the xy and conic sums lack their constant factors (ln2*W/2, ln2*H/2, -1/2)."""
     a = np.array(to_np(acc16), dtype=np.float32, copy=True)
-    if layout == 0:
-        ln2 = np.float32(0.6931471805599453)
-        a[:, 0] = a[:, 0] * (ln2 * (np.float32(0.5) * np.float32(W)))
-        a[:, 1] = a[:, 1] * (ln2 * (np.float32(0.5) * np.float32(H)))
-    else:
-        c = np.asarray(to_np(conic), dtype=np.float32)
-        A, B, C = c[:, 0], c[:, 1], c[:, 2]
-        sx, sy = a[:, 0].copy(), a[:, 1].copy()
-        a[:, 0] = -(A * sx + B * sy) * (np.float32(0.5) * np.float32(W))
-        a[:, 1] = -(C * sy + B * sx) * (np.float32(0.5) * np.float32(H))
+    ln2 = np.float32(0.6931471805599453)
+    a[:, 0] = a[:, 0] * (ln2 * (np.float32(0.5) * np.float32(W)))
+    a[:, 1] = a[:, 1] * (ln2 * (np.float32(0.5) * np.float32(H)))
     a[:, 3:6] = np.float32(-0.5) * a[:, 3:6]
     return a
 
@@ -132,9 +117,17 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4, tag="
     P = o["P"]
     if P:
         vis = o["radii"] > 0
+        from ex4dgs_amd import _C
+        # cov3D[P,6] / tiles_touched[P] and the sorted tile ids are only materialised with the debug options (tests/conftest.py);
+        # the library's defaults -- the configuration bench.py times -- are compared on everything that exists there
+        geom_debug, tile_ids_on = bool(_C.get_option("geom_debug_arrays")), bool(_C.get_option("binning_tile_ids"))
+        rep["options"] = dict(geom_debug_arrays=int(geom_debug), binning_tile_ids=int(tile_ids_on))
         assert np.array_equal(o["radii"], to_np(g["radii"])), "radii differ"
-        assert np.array_equal(o["tiles_touched"].astype(np.int64), to_np(g["tiles_touched"]).astype(np.int64) & 0xFFFFFFFF), "tiles_touched differ"
-        keys = ("depths", "means2D", "conic_opacity") + (("cov3D",) if o["_inputs"]["cov3D_precomp"] is None else ())
+        if geom_debug:
+            assert np.array_equal(o["tiles_touched"].astype(np.int64), to_np(g["tiles_touched"]).astype(np.int64) & 0xFFFFFFFF), "tiles_touched differ"
+        rects = to_np(g["rects"]).astype(np.int64)         # the tile rect is always there: its area is tiles_touched
+        assert np.array_equal(o["tiles_touched"].astype(np.int64)[vis], ((rects[:, 1] & 0xFFFF) * (rects[:, 1] >> 16))[vis]), "tile rect area differs from tiles_touched"
+        keys = ("depths", "means2D", "conic_opacity") + (("cov3D",) if (o["_inputs"]["cov3D_precomp"] is None and geom_debug) else ())
         for k in keys:
             a, b = o[k][vis], to_np(g[k])[vis]
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{k} not bit-exact (max abs {np.abs(a - b).max()})"
@@ -145,7 +138,8 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4, tag="
             assert np.array_equal(o["clamped"][vis], np.stack([(cl >> c) & 1 for c in range(3)], -1)), "clamped differ"
         assert o["num_rendered"] == g["num_rendered"], (o["num_rendered"], g["num_rendered"])
         assert np.array_equal(o["point_list"].astype(np.int64), to_np(g["point_list"]).astype(np.int64)), "point_list (sort order) differs"
-        assert np.array_equal((o["keys_sorted"] >> np.uint64(32)).astype(np.int64), to_np(g["tile_ids"]).astype(np.int64)), "sorted tile ids differ"
+        if tile_ids_on:
+            assert np.array_equal((o["keys_sorted"] >> np.uint64(32)).astype(np.int64), to_np(g["tile_ids"]).astype(np.int64)), "sorted tile ids differ"
         assert np.array_equal(o["ranges"].astype(np.int64), to_np(g["ranges"]).astype(np.int64)), "tile ranges differ"
     H, W = o["H"], o["W"]
     frag = o["fragile"] if o.get("fragile") is not None else np.ones((H, W), np.float32)
@@ -160,9 +154,18 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4, tag="
         rep[k] = float(e)
         worst = max(worst, e)
         assert e <= atol, f"{k}: max err {e} > {atol} on non-fragile pixels ({rep})"
-        # fragile pixels: a flipped 1/255 contribution is bounded by ~alpha_min * |value| -- loose sanity bound
+        # fragile pixels: what a flipped decision can move is bounded PER PIXEL by the oracle's own list of near-threshold decisions
+        # (oracle: flip_w = summed blending weight alpha*T of the decisions within frag_eps of their threshold; a flipped
+        # contributor changes the pixel by its own term plus the rescaling of everything behind it: <= 2 flip_w max|value|)
         if (~solid).any():
-            assert err[:, ~solid].max() < 0.05 * max(1.0, np.abs(a).max()), f"{k}: fragile pixel error too large"
+            if k in ("color", "acc") and o.get("flip_w") is not None:
+                vmax = 1.0 if k == "acc" else max(1.0, float(np.abs(o["_features_max"])) if "_features_max" in o else _feature_max(o))
+                bound = atol + 2.0 * o["flip_w"][~solid].astype(np.float64) * vmax
+                worst_flip = float((np.abs(a - b)[:, ~solid] / bound[None]).max())
+                rep[k + "_fragile_err_over_flip_bound"] = worst_flip
+                assert worst_flip <= 1.0, f"{k}: a fragile pixel moved by {worst_flip:.2f}x what its near-threshold decisions can move"
+            else:
+                assert err[:, ~solid].max() < 0.05 * max(1.0, np.abs(a).max()), f"{k}: fragile pixel error too large"
     if P:
         # the dominant index is an argmax over float weights alpha*T: two Gaussians whose weights agree to a few ulp swap places
         # with a 1-ulp exp() difference.  The oracle reports the smallest relative margin of the deciding comparisons per pixel;
@@ -183,6 +186,11 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4, tag="
         rep["idx_undecided_pixels"] = int(solid.sum() - decided.sum())
     REPORT.append(dict(kind="forward", tag=tag, P=int(P), R=int(o["num_rendered"]), W=int(W), H=int(H), **rep))
     return rep
+
+
+def _feature_max(o):
+    f = o["_inputs"]["colors_precomp"] if o["_inputs"]["colors_precomp"] is not None else o["rgb"]
+    return max(1.0, float(np.abs(f).max()), float(np.abs(o["_inputs"]["bg"]).max()))
 
 
 REPORT = []          # one dict per compared case; conftest.py writes it to gpurun_out/parity_report.json at session end
@@ -262,7 +270,70 @@ def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=6):
     return out
 
 
-def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=None, tag=""):
+ACC_GROUPS = {"dL_dmeans2D": slice(0, 3), "dL_dconic": slice(3, 6), "dL_dopacity": slice(6, 7), "dL_dcolors": slice(7, 10), "dL_ddir": slice(10, 13)}
+NOISE_C = 4.0            # HIP error <= NOISE_C x the reference's own run-to-run spread (VERDICT r02 item 1a asks for c <= 4)
+NOISE_FLOOR_EPS = 8.0    # ... or NOISE_FLOOR_EPS half-ulps of sum|terms| x cond where the replayed spread is below that (rows with 1-3 terms:
+                         # a sum of two terms has NO order noise, yet two float evaluations of its terms -- expf vs v_exp_f32, fused
+                         # vs unfused multiply-adds, which nvcc applies to the reference as well -- differ by ulps of the terms)
+
+
+def noise_floor(fwd_o, noise_accs, sum13, abs13=None):
+    """The reference's own float32 noise, from `noise_accs` = the oracle's compositing backward replayed with the pixels in several
+    random orders (oracle.backward_noise: float32 accumulation like the reference's atomicAdd, whose order changes from run to run).
+    Returns per tensor the per-entry deviation max_k |result_k - exact| ([P, n] float64) for the five accumulated quantities and
+    for the five tensors derived from them by the per-Gaussian stage (each replay pushed through the oracle's stage)."""
+    exact = np.asarray(sum13, dtype=np.float64)
+    ref_stage = _stage(fwd_o, exact)
+    dev = {k: 0.0 for k in list(ACC_GROUPS) + list(DERIVED)}
+    for a in noise_accs:
+        d = np.abs(a.astype(np.float64) - exact)
+        for k, sl in ACC_GROUPS.items():
+            dev[k] = np.maximum(dev[k], d[:, sl])
+        r = _stage(fwd_o, a)
+        for k in DERIVED:
+            dev[k] = np.maximum(dev[k], np.abs(r[k].astype(np.float64) - ref_stage[k].astype(np.float64)).reshape(exact.shape[0], -1))
+    return dev
+
+
+def compare_with_noise(rep, ref, gb, dev, P, floor_acc=None, floor_derived=None, assert_rows=True):
+    """HIP error against the reference's own noise floor, per tensor and per row (Gaussian).
+      tensor: max|hip - ref| <= NOISE_C * max(dev)                      (the worst entry of two reference runs vs the worst HIP entry)
+      row:    max_row|hip - ref| <= NOISE_C * max(max_row(dev), floor)  (floor: NOISE_FLOOR_EPS half-ulps of the row's sum|terms| x cond)"""
+    out = {}
+    for k, d in dev.items():
+        if k == "dL_dconic":
+            continue                                   # internal ([P,2,2] in the reference); covered through cov3D / scales / rotations
+        a = np.asarray(ref[k], dtype=np.float64).reshape(P, -1)
+        b = to_np(gb[k]).astype(np.float64).reshape(P, -1)
+        if a.size == 0:
+            continue
+        err = np.abs(a - b)
+        d = np.asarray(d, dtype=np.float64).reshape(P, -1)
+        noise_t, err_t = float(d.max()), float(err.max())
+        row_noise, row_err = d.max(1), err.max(1)
+        floor = 0.0
+        if k in ACC_GROUPS and floor_acc is not None:
+            floor = np.asarray(floor_acc)[:, ACC_GROUPS[k]].max(1)
+        elif k not in ACC_GROUPS and floor_derived is not None:
+            floor = np.asarray(floor_derived[k]).reshape(P, -1).max(1)
+        eff = np.maximum(row_noise, floor) + 1e-300
+        ratio = row_err / eff
+        live = row_err > 0
+        out[k] = dict(err_max=err_t, ref_noise_max=noise_t, err_over_ref_noise=(err_t / noise_t if noise_t > 0 else 0.0),
+                      row_ratio_max=float(ratio.max()), row_ratio_p999=float(np.quantile(ratio[live], 0.999)) if live.any() else 0.0,
+                      rows_above_c=int((ratio > NOISE_C).sum()), rows=int(live.sum()),
+                      row_ratio_noise_only_p999=float(np.quantile((row_err / (row_noise + 1e-300))[live & (row_noise > 0)], 0.999)) if (live & (row_noise > 0)).any() else 0.0)
+    rep["noise_floor"] = out
+    for k, r in out.items():
+        if r["ref_noise_max"] > 0:
+            assert r["err_max"] <= NOISE_C * r["ref_noise_max"] + 1e-30, (f"{k}: max error {r['err_max']:.3e} is {r['err_over_ref_noise']:.2f}x the reference's own "
+                                                                       f"run-to-run spread {r['ref_noise_max']:.3e} (> {NOISE_C})")
+        if assert_rows:
+            assert r["rows_above_c"] == 0, f"{k}: {r['rows_above_c']} rows exceed {NOISE_C}x max(reference spread, float floor); worst x{r['row_ratio_max']:.2f}"
+    return out
+
+
+def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=None, tag="", noise=None, frac_above_bar=1e-6):
     """Accumulated quantities: |gpu - oracle_double_sum| <= tol13 = atol + k_eps * 2^-24 * sum|terms| + 3e-6 |sum| per entry
     (the reference itself sums ~1e2..1e5 float terms per Gaussian with atomics in arbitrary order; a flat 1e-5 is below one ulp
     of the sums, which reach 1e3..1e5).  The nine RETURNED gradients are asserted per entry against the same bound pushed through
@@ -288,6 +359,13 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
     ref["dL_dmeans2D"], ref["dL_dcolors"] = ob["sum13"][:, 0:3], ob["sum13"][:, 7:10]
     ref["dL_dopacity"], ref["dL_ddir"] = ob["sum13"][:, 6:7], ob["sum13"][:, 10:13]
     rep["grads"] = gradient_errors(ref, gb, P)
+    if noise is not None:
+        # first check: the reference's own atomics-order noise floor (the hand-built bound below stays as the second check)
+        dev = noise_floor(fwd_o, noise, ob["sum13"])
+        floor13 = NOISE_FLOOR_EPS * eps * ob["abs13"]
+        fl = propagated_tolerance(fwd_o, floor13)
+        compare_with_noise(rep, ref, gb, dev, P, floor_acc=floor13, floor_derived={k: fl[k] for k in DERIVED},
+                           assert_rows=os.environ.get("EX4D_NOISE_ROWS_ASSERT", "1") != "0")
     bound = propagated_tolerance(fwd_o, tol + 4 * eps * np.abs(ob["sum13"]), acc13=ob["sum13"])
     for k in GRAD_NAMES:
         a, b = np.asarray(ref[k], dtype=np.float64).reshape(P, -1), to_np(gb[k]).astype(np.float64).reshape(P, -1)
@@ -300,6 +378,8 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
         rep["grads"][k]["stage_noise_max"] = bound.get("_stage_noise_max", {}).get(k, 0.0)
     REPORT.append(dict(kind="backward", tag=tag, P=int(P), R=int(fwd_o["num_rendered"]), W=int(fwd_o["W"]), H=int(fwd_o["H"]), **rep))
     for k, r in rep["grads"].items():
+        # the FRACTION of entries above north_star's 1e-5 x tensor magnitude is bounded, not only the maximum
+        assert r["frac_above_1e5"] <= frac_above_bar, f"{k}: {r['frac_above_1e5']:.2e} of the entries exceed 1e-5 x the tensor magnitude"
         assert r["worst_err_over_bound"] <= 1.0, (f"{k}: error exceeds the propagated accumulator bound by x{r['worst_err_over_bound']:.2f} "
                                                   f"(max-abs {r['max_abs']:.3e}, tensor max {r['ref_max']:.3e})")
         bar = rel_tol * max(1.0, r["ref_max"]) + 8.0 * r.get("stage_noise_max", 0.0)

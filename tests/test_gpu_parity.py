@@ -15,13 +15,24 @@ from tests import helpers as h
 pytestmark = pytest.mark.gpu
 
 
-def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, subpixel=None, seed=3, max_fragile_frac=2e-3, **fwd_over):
+_ORACLE_FWD = {}       # (cfg, P, t, degree) -> oracle forward of the unmodified scene: the full-size cases run once with the test
+                       # options and once with the library's defaults (the timed configuration) against the same oracle result
+
+
+def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, subpixel=None, seed=3, max_fragile_frac=2e-3, noise_orders=8, **fwd_over):
     from oracle import oracle
     ins, st = h.scene_inputs(cfg, P=P, t=t, sh_degree=sh_degree)
     st.update(fwd_over)
     if mutate:
         mutate(ins, st)
-    o = h.oracle_forward(ins, st, subpixel_offset=subpixel)
+    key = (cfg, P, t, sh_degree) if (isinstance(cfg, str) and mutate is None and subpixel is None and not fwd_over) else None
+    if key is not None and key in _ORACLE_FWD:
+        o = _ORACLE_FWD[key]
+    else:
+        o = h.oracle_forward(ins, st, subpixel_offset=subpixel)
+        if key is not None and (o["P"] >= 50_000):
+            _ORACLE_FWD.clear()                        # one large scene at a time (a 1.0 M forward holds ~1 GB)
+            _ORACLE_FWD[key] = o
     g = h.gpu_forward_raw(ins, st, subpixel_offset=subpixel)
     rep = h.compare_forward(o, g, max_fragile_frac=max_fragile_frac, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t}")
     H, W = st["image_height"], st["image_width"]
@@ -36,8 +47,11 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     ob_state.update(depth=h.to_np(g["depth"]), acc=h.to_np(g["acc"]), final_T=np.ascontiguousarray(h.to_np(g["final_T"])),
                     n_contrib=np.ascontiguousarray(h.to_np(g["n_contrib"]).astype(np.uint32)))
     ob = oracle.backward(ob_state, *grads)
+    # the reference's own noise floor: the same backward replayed in float32 with the pixels in `noise_orders` random orders
+    # (its atomicAdd order changes from run to run, CR/backward.cu:613-679); the HIP error is asserted in multiples of that spread
+    noise = oracle.backward_noise(ob_state, *grads, orders=noise_orders) if noise_orders else None
     gb = h.gpu_backward_raw(ins, g, grads)
-    rep.update(h.compare_backward(ob, gb, o, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} (oracle backward on the GPU forward's state)"))
+    rep.update(h.compare_backward(ob, gb, o, noise=noise, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} (oracle backward on the GPU forward's state)"))
     # end to end: oracle(forward -> backward) against GPU(forward -> backward), nothing shared but the inputs.  The oracle's own
     # forward state differs from the GPU's by forward rounding (<= 1e-5, checked above), which dL_dalpha amplifies through
     # (final_depth - depth) dL_ddepth / acc: bound 3e-5 instead of 1e-5

@@ -28,6 +28,16 @@ def test_cfg2_full_size_100k(hip_lib):
     _fragile_budget(rep, o["W"] * o["H"], 3e-3)
 
 
+def test_cfg2_full_size_100k_library_defaults(hip_lib_defaults):
+    """The same comparison on the library's DEFAULT options -- the configuration bench.py times: cov3D / tiles_touched not stored
+    (the backward recomputes the covariance), the sorted tile ids not materialised."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("geom_debug_arrays") == 0 and _C.get_option("binning_tile_ids") == 0 and _C.get_option("composite_bwd_variant") == 4
+    o, g, ob, gb, rep = _fwd_bwd("cfg2", max_fragile_frac=3e-3)
+    assert rep["options"] == dict(geom_debug_arrays=0, binning_tile_ids=0)
+    _fragile_budget(rep, o["W"] * o["H"], 3e-3)
+
+
 def test_cfg5_deep_overlap_100k(hip_lib):
     """BASELINE config 5's generator at 100 k Gaussians, 2048x1088, off-centre projection: tile lists several hundred entries deep."""
     o, g, ob, gb, rep = _fwd_bwd("cfg5", P=100_000, max_fragile_frac=1e-2)
@@ -48,6 +58,41 @@ def test_cfg3_full_size_1M_against_the_oracle(hip_lib):
     o, g, ob, gb, rep = _fwd_bwd("cfg3", t=137, max_fragile_frac=1e-2)
     assert o["P"] == 1_000_000 and o["num_rendered"] > 6_000_000
     _fragile_budget(rep, o["W"] * o["H"], 1e-2)
+
+
+def test_cfg3_full_size_1M_library_defaults(hip_lib_defaults):
+    """BASELINE config 3 at full size on the library's DEFAULT options = exactly what bench.py times, against
+    the same oracle forward (cached from the test above when both run)."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("geom_debug_arrays") == 0 and _C.get_option("binning_tile_ids") == 0 and _C.get_option("composite_bwd_variant") == 4
+    o, g, ob, gb, rep = _fwd_bwd("cfg3", t=137, max_fragile_frac=1e-2)
+    assert o["P"] == 1_000_000 and rep["options"] == dict(geom_debug_arrays=0, binning_tile_ids=0)
+    _fragile_budget(rep, o["W"] * o["H"], 1e-2)
+
+
+def test_stats_variant_of_the_compositing_backward(hip_lib):
+    """The one other selectable compositing-backward variant (8 = default + developer counters) returns the default's gradients up to
+    the order of the float atomics, and its counters are consistent."""
+    from ex4dgs_amd import _C
+    ins, st = h.scene_inputs("cfg2", P=30_000)
+    g = h.gpu_forward_raw(ins, st)
+    H, W = st["image_height"], st["image_width"]
+    grads = [x.cuda() for x in h.upstream_grads(g["acc"].cpu(), H, W, seed=5)]
+    d = {k: v.cuda() for k, v in ins.items()}
+    a4 = h.gpu_backward_raw(d, g, grads)["acc16"].clone()
+    stats = _C.bwd_stats(reset=True)
+    _C.set_option("composite_bwd_variant", 8)
+    try:
+        a8 = h.gpu_backward_raw(d, g, grads)["acc16"].clone()
+        torch.cuda.synchronize()
+        stats = _C.bwd_stats(reset=True)
+    finally:
+        _C.set_option("composite_bwd_variant", 4)
+    scale = a4.abs().max(0)[0].clamp_min(1.0)
+    assert float(((a8 - a4).abs() / scale).max()) < 1e-5
+    batches, gaussians, steps_run, steps_skipped, pairs, touched = [int(x) for x in stats[:6]]
+    assert batches > 0 and steps_run + steps_skipped == 16 * batches and gaussians <= 16 * batches and touched <= gaussians
+    assert 0 < pairs <= 64 * steps_run
 
 
 def test_cfg4_full_size_properties_2M(hip_lib):
