@@ -40,7 +40,7 @@ def eval_sh_rgb(deg, sh, dirs):
 
 def rasterize(means3D, dir3D, opacities, shs, scales, rotations, *, bg, viewmatrix, projmatrix, campos,
               image_height, image_width, tanfovx, tanfovy, kernel_size, sh_degree, subpixel_offset=None,
-              scale_modifier=1.0, min_depth=0.2, max_depth=100.0, colors_precomp=None, cut_cov_mean_path=True):
+              scale_modifier=1.0, min_depth=0.2, max_depth=100.0, colors_precomp=None, cut_cov_mean_path=True, return_dense=False):
     """Returns dict(color[3,H,W], radii[P], depth[1,H,W], flow[3,H,W], acc[1,H,W], idx[1,H,W], n_contrib, final_T,
     num_rendered, plus differentiable intermediates means2D_pix / conic / w / rgb with retained grads)."""
     H, W = int(image_height), int(image_width)
@@ -162,7 +162,12 @@ def rasterize(means3D, dir3D, opacities, shs, scales, rotations, *, bg, viewmatr
     # n_contrib: position (1-based) in the tile's list of the last used contributor
     pos_in_list = torch.cumsum(member.int(), 1)
     n_contrib = torch.where(use, pos_in_list, torch.zeros_like(pos_in_list)).max(1)[0]
-    return dict(color=color.t().reshape(3, H, W), radii=radii, depth=depth_out.reshape(1, H, W),
+    dense = None
+    if return_dense:
+        # the pixels x (visible Gaussians in depth order) tensors, for closed-form checks (tests: quirk terms of the backward)
+        dense = dict(order=o, use=use, alpha=a_eff.detach(), G=G.detach(), dx=dx.detach(), dy=dy.detach(), T_before=T_excl.detach(),
+                     conic=cn.detach(), w=w[o].detach(), rgb=rgb[o].detach(), depth=depth[o].detach())
+    return dict(dense=dense, color=color.t().reshape(3, H, W), radii=radii, depth=depth_out.reshape(1, H, W),
                 flow=flow_out.t().reshape(3, H, W), acc=acc.reshape(1, H, W), idx=idx.reshape(1, H, W),
                 n_contrib=n_contrib.reshape(H, W), final_T=T_final.reshape(H, W), num_rendered=int(tiles[vis].sum()),
                 means2D_pix=pix, conic=conic, w=w, rgb=rgb, tiles_touched=torch.where(vis, tiles, torch.zeros_like(tiles)),

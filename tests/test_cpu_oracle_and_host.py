@@ -88,6 +88,55 @@ def test_oracle_backward_matches_autograd_on_true_gradient_subset():
     close("dL_ddir", b2["dL_ddir"], leaf["dir3D"].grad)
 
 
+def test_oracle_backward_quirk_terms_match_independent_closed_form():
+    """The NON-derivative terms of the reference backward (depth term + `dep > min_depth` gate CR/backward.cu:603-622, dL_dacc
+    compounding :649-650,:679, alpha-clamp pass-through :588, flow channel :640-647, pre-scaling by acc :505-535) have no autograd
+    counterpart.  oracle/quirk_closed_form.py states them as dense float64 algebra from SURVEY Appendix A.4 -- independently of
+    oracle/ex4d_oracle.c's sequential replay -- and all 13 accumulators of the C oracle must agree with it, with every upstream
+    gradient non-zero, with a Gaussian clamped at alpha = 0.99 and with Gaussians on both sides of the min_depth gate."""
+    from oracle import oracle, oracle_torch, quirk_closed_form
+    ins, st = _small_scene()
+    # a large, opaque, near Gaussian in the image centre: alpha reaches the 0.99 clamp on many pixels
+    ins["means3D"][3] = torch.tensor([0.0, 0.0, 5.0])
+    ins["scales"][3] = torch.tensor([0.6, 0.6, 0.6])
+    ins["opacities"][3] = 1.6          # (the API takes any value; sigmoid outputs stay below 1, where opacity * coef only grazes the clamp)
+    o = h.oracle_forward(ins, st)
+    H, W = st["image_height"], st["image_width"]
+    kw = {k: st[k] for k in ("bg", "viewmatrix", "projmatrix", "campos", "image_height", "image_width", "tanfovx", "tanfovy",
+                             "kernel_size", "sh_degree", "min_depth", "max_depth")}
+    g = oracle_torch.rasterize(ins["means3D"], ins["dir3D"], ins["opacities"], ins["shs"], ins["scales"], ins["rotations"], return_dense=True, **kw)
+    d = g["dense"]
+    assert int(((d["alpha"] == 0.99) & d["use"]).sum()) > 50, "the scene must exercise the alpha clamp"
+    solid = torch.from_numpy(o["fragile"] > 1e-4)
+    assert bool((torch.from_numpy(o["n_contrib"].astype(np.int64))[solid] == g["n_contrib"][solid]).all())
+    g0 = torch.Generator().manual_seed(17)
+    gc = torch.randn(3, H, W, generator=g0) * solid[None]
+    gd = 0.3 * torch.randn(1, H, W, generator=g0) * solid[None]
+    gf = torch.randn(3, H, W, generator=g0) * solid[None]
+    ga = torch.randn(1, H, W, generator=g0) * solid[None]
+    depths_vis = np.sort(o["depths"][o["radii"] > 0])
+    for gate_depth in (st["min_depth"], float(depths_vis[len(depths_vis) // 2])):     # the second run closes the gate for half the Gaussians
+        fwd = dict(o)
+        fwd["_inputs"] = dict(o["_inputs"], min_depth=gate_depth)
+        b = oracle.backward(fwd, gc, gd, gf, ga)
+        ref = quirk_closed_form.accumulators(d, final_T=o["final_T"], acc=o["acc"], final_depth=o["depth"], bg=st["bg"].numpy(), grad_color=gc.numpy(),
+                                             grad_depth=gd.numpy(), grad_flow=gf.numpy(), grad_acc=ga.numpy(), W=W, H=H, min_depth=gate_depth,
+                                             n_visible_total=o["P"])
+        names = ["dmean2D.x", "dmean2D.y", "dmean2D.z", "dconic.x", "dconic.y", "dconic.w", "dopacity", "dcolor.r", "dcolor.g", "dcolor.b", "ddir.x", "ddir.y", "ddir.z"]
+        for k, name in enumerate(names):
+            a, r = b["sum13"][:, k], ref[:, k]
+            scale = max(1.0, np.abs(r).max())
+            assert np.abs(a - r).max() <= 2e-4 * scale, (name, gate_depth, np.abs(a - r).max(), scale)
+            assert np.abs(r).max() > 0, name
+        if gate_depth != st["min_depth"]:
+            closed = (o["depths"] <= gate_depth) & (o["radii"] > 0)
+            assert closed.sum() > 10 and np.all(b["sum13"][closed, 2] == 0.0) and np.abs(b["sum13"][~closed, 2]).max() > 0
+    # each quirk on its own is visible: dropping grad_acc / grad_depth changes dL_dopacity
+    b_no_acc = oracle.backward(o, gc, gd, gf, torch.zeros(1, H, W))
+    b_all = oracle.backward(o, gc, gd, gf, ga)
+    assert np.abs(b_all["sum13"][:, 6] - b_no_acc["sum13"][:, 6]).max() > 1e-3
+
+
 def test_oracle_sh_matches_reference_eval_sh_golden():
     """SH->RGB of the oracle (CR/forward.cu:20-71 restated) vs outputs of the reference's utils/sh_utils.eval_sh."""
     from oracle import oracle
