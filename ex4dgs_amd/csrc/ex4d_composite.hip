@@ -586,7 +586,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     }
     const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
     const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
-    const float xr = p.fx - ox, yr = p.fy - oy;
     L.pa[lane] = make_float4(gp0, gp1, gp2, gdepth);
     L.pb[lane] = make_float4(final_depth, __uint_as_float(last_contributor), T_final, bgT);     // w: bgT - E, E = 0 behind the deepest contributor
     L.pc[lane] = make_float4(gflow0, gflow1, gflow2, gacc);

@@ -27,12 +27,17 @@ struct RadamSlot {
     float eps;
     int rectified;     // rho_t > 5
     unsigned first_chunk;   // index of this tensor's first chunk in the launch
+    int sanitize;      // gradient read through nan_to_num (train.py:244-247)
 };
 
 struct RadamArgs { RadamSlot slot[EX4D_RADAM_MAX_TENSORS]; int count; };
 
-__device__ __forceinline__ void radam_update(float &p, const float g, float &m, float &v, const RadamSlot &s)
+// torch.nan_to_num with its defaults: NaN -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX
+__device__ __forceinline__ float nan_to_num(float g) { return g != g ? 0.f : fminf(fmaxf(g, -3.402823466e+38f), 3.402823466e+38f); }
+
+__device__ __forceinline__ void radam_update(float &p, float g, float &m, float &v, const RadamSlot &s)
 {
+    if (s.sanitize) g = nan_to_num(g);
     m = m + s.w1 * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
     v = v * s.beta2;                              // exp_avg_sq.mul_(beta2)
     v = v + (s.w2 * g) * g;                       //           .addcmul_(grad, grad, value=1 - beta2)
@@ -82,16 +87,17 @@ struct SlicedSlot {
     int K, C, nw;
     int first[EX4D_RADAM_MAX_WINDOWS], count[EX4D_RADAM_MAX_WINDOWS];
     const float *grad[EX4D_RADAM_MAX_WINDOWS];
+    const int *first_dev;    // optional: window positions in device memory (uniform loads)
     unsigned first_block;
 };
 struct SlicedArgs { SlicedSlot slot[EX4D_RADAM_MAX_SLICED]; int count; };
 
 // gradient of flat element e = (row, kk, c) of a [rows, K, C] tensor from the windows (zero outside them); windows add in index order
-__device__ __forceinline__ float sliced_grad(const SlicedSlot &t, long long row, int kk, int c)
+__device__ __forceinline__ float sliced_grad(const SlicedSlot &t, const int (&first)[EX4D_RADAM_MAX_WINDOWS], long long row, int kk, int c)
 {
     float g = 0.f;
     for (int w = 0; w < t.nw; w++) {
-        const unsigned rel = (unsigned)(kk - t.first[w]);
+        const unsigned rel = (unsigned)(kk - first[w]);
         if (rel < (unsigned)t.count[w]) g += t.grad[w][((size_t)row * t.count[w] + rel) * t.C + c];
     }
     return g;
@@ -109,6 +115,9 @@ __global__ __launch_bounds__(256) void radam_sliced_kernel(const SlicedArgs a)
     const long long n = s.s.numel - base < RADAM_CHUNK ? s.s.numel - base : RADAM_CHUNK;
     float *p = s.s.p + base, *m = s.s.m + base, *v = s.s.v + base;
     const bool vec = n == RADAM_CHUNK && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    int first[EX4D_RADAM_MAX_WINDOWS];
+#pragma unroll
+    for (int w = 0; w < EX4D_RADAM_MAX_WINDOWS; w++) first[w] = (s.first_dev && w < s.nw) ? s.first_dev[w] : s.first[w];
     if (vec) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void radam_sliced_kernel(const SlicedArgs a)
             float g[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                g[j] = sliced_grad(s, row, kk, c);
+                g[j] = sliced_grad(s, first, row, kk, c);
                 if (++c == s.C) { c = 0; if (++kk == s.K) { kk = 0; row++; } }
             }
             float4 pp = ((float4 *)p)[i], mm = ((float4 *)m)[i], vv = ((float4 *)v)[i];
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) void radam_sliced_kernel(const SlicedArgs a)
             const long long e = base + i;
             const long long sl = e / s.C, row = sl / s.K;
             float pp = p[i], mm = m[i], vv = v[i];
-            radam_update(pp, sliced_grad(s, row, (int)(sl - row * s.K), (int)(e - sl * s.C)), mm, vv, s.s);
+            radam_update(pp, sliced_grad(s, first, row, (int)(sl - row * s.K), (int)(e - sl * s.C)), mm, vv, s.s);
             p[i] = pp; m[i] = mm; v[i] = vv;
         }
     }
@@ -180,7 +189,7 @@ int ex4d_radam_step(const Ex4dRadamTensor *tensors, int32_t count, double beta1,
             return EX4D_ERR_ARG;
         }
         RadamSlot &s = a.slot[a.count++];
-        s.p = t.param; s.g = t.grad; s.m = t.exp_avg; s.v = t.exp_avg_sq; s.numel = t.numel;
+        s.p = t.param; s.g = t.grad; s.m = t.exp_avg; s.v = t.exp_avg_sq; s.numel = t.numel; s.sanitize = t.nan_to_num != 0;
         fill_coefficients(s, t.lr, t.step, beta1, beta2, eps);
         s.first_chunk = chunks;
         const long long c = (t.numel + RADAM_CHUNK - 1) / RADAM_CHUNK;
@@ -213,12 +222,13 @@ int ex4d_radam_step_sliced(const Ex4dRadamSlicedTensor *tensors, int32_t count, 
             return EX4D_ERR_ARG;
         }
         SlicedSlot &s = a.slot[a.count++];
-        s.s.p = t.param; s.s.g = nullptr; s.s.m = t.exp_avg; s.s.v = t.exp_avg_sq; s.s.numel = t.rows * t.K * t.C; s.s.first_chunk = 0;
+        s.s.p = t.param; s.s.g = nullptr; s.s.m = t.exp_avg; s.s.v = t.exp_avg_sq; s.s.numel = t.rows * t.K * t.C; s.s.first_chunk = 0; s.s.sanitize = 0;
+        s.first_dev = t.first_dev;
         fill_coefficients(s.s, t.lr, t.step, beta1, beta2, eps);
         s.slices = t.rows * t.K; s.K = t.K; s.C = t.C; s.nw = t.n_windows;
         for (int w = 0; w < EX4D_RADAM_MAX_WINDOWS; w++) {
             const bool live = w < t.n_windows;
-            if (live && (t.first[w] < 0 || t.count[w] < 1 || t.first[w] + t.count[w] > t.K || !t.grad[w])) {
+            if (live && (((t.first[w] < 0 || t.first[w] + t.count[w] > t.K) && !t.first_dev) || t.count[w] < 1 || t.count[w] > t.K || !t.grad[w])) {
                 snprintf(g_optim_err, sizeof(g_optim_err), "sliced tensor %d: window %d outside [0, K) or null", i, w);
                 return EX4D_ERR_ARG;
             }

@@ -243,12 +243,33 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
                 s.first[0] = t->slices[i == 7 ? 0 : 2]; s.count[0] = t->slices[i == 7 ? 1 : 3]; s.grad[0] = g[i];
             } else {
                 Ex4dRadamTensor &q = dense[nd++];
+                memset(&q, 0, sizeof(q));
+                q.nan_to_num = i == 11;            // train.py:244-247: _opacity_duration_var.grad.nan_to_num() before optimizer.step()
                 q.param = p[i]; q.grad = g[i]; q.exp_avg = t->m[i]; q.exp_avg_sq = t->v[i]; q.numel = t->numel[i]; q.lr = c.lr[i]; q.step = t->step;
             }
         }
         if (nd && ex4d_radam_step(dense, nd, c.beta1, c.beta2, c.eps, stream)) return tfail(EX4D_ERR_HIP, "RAdam: %s", ex4d_optim_last_error());
         if (ns && ex4d_radam_step_sliced(sl, ns, c.beta1, c.beta2, c.eps, stream)) return tfail(EX4D_ERR_HIP, "RAdam (sliced): %s", ex4d_optim_last_error());
     }
+    return EX4D_OK;
+}
+
+int ex4d_trainer_set_lr(Ex4dTrainer *t, const double *lr15)
+{
+    t_err[0] = 0;
+    if (!t || !lr15) return tfail(EX4D_ERR_ARG, "null argument");
+    for (int i = 0; i < EX4D_TRAINER_PARAMS; i++) {
+        if (!(lr15[i] >= 0.0)) return tfail(EX4D_ERR_ARG, "learning rate %d is negative or NaN", i);
+        t->cfg.lr[i] = lr15[i];
+    }
+    return EX4D_OK;
+}
+
+int ex4d_trainer_set_sh_degree(Ex4dTrainer *t, int32_t degree)
+{
+    t_err[0] = 0;
+    if (!t || degree < 0 || degree > 3) return tfail(EX4D_ERR_ARG, "SH degree outside [0, 3]");
+    t->cfg.sh_degree = degree;
     return EX4D_OK;
 }
 

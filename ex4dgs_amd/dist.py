@@ -224,10 +224,12 @@ class SliceGather:
     sum as the dense all-reduce.  (The union of W random timestamps covers most of the K keyframes, so a dense "union" tensor would
     save little; W small windows do.)"""
 
-    def __init__(self, shape, device, group=None):
+    def __init__(self, shape, device, group=None, local_only=False):
+        """local_only: a single local window, no collective (exchange mode "none": nothing is summed over ranks)."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local_only = bool(local_only)
+        self.world = dist.get_world_size(group) if (dist.is_initialized() and not local_only) else 1
+        self.rank = dist.get_rank(group) if (dist.is_initialized() and not local_only) else 0
         self.all = torch.zeros((self.world,) + tuple(shape), dtype=torch.float32, device=device)
         self.first = torch.zeros(self.world, dtype=torch.int32, device=device)
         self.pending = []
@@ -253,9 +255,14 @@ class SliceGather:
         self.pending = []
 
     def windows(self, count):
-        """[(first keyframe, count, device pointer of the [Nd, count, C] block)] for all ranks (call after wait())."""
-        firsts = self.first.tolist() if self.world > 1 else [self._first_host]      # one rank: no device round trip
-        return [(int(firsts[r]), int(count), self.all[r].data_ptr()) for r in range(self.world)]
+        """[(first keyframe, count, device pointer of the [Nd, count, C] block)] for all ranks (call after wait()).  With more than
+        one rank the positions of the other ranks' windows exist on the DEVICE only (first_device_ptr(): the optimizer kernel reads
+        them there -- no device -> host round trip in the step); the host values returned for them are placeholders."""
+        return [(self._first_host if r == self.rank else 0, int(count), self.all[r].data_ptr()) for r in range(self.world)]
+
+    def first_device_ptr(self):
+        """Device int32[world] of the windows' first keyframes (None for one rank: the host value is exact)."""
+        return self.first.data_ptr() if self.world > 1 else None
 
     def bytes_on_wire(self):
         return 4 * self.all[0].numel()

@@ -15,10 +15,11 @@ import torch
 from . import _C
 from . import attributes as attr
 from .loss import _WINDOW
-from .trainer import DEFAULT_LRS
+from .trainer import reference_lrs
 
 EXPORTS = ("ex4d_trainer_last_error", "ex4d_trainer_create", "ex4d_trainer_destroy", "ex4d_trainer_step", "ex4d_trainer_output",
-           "ex4d_trainer_grad", "ex4d_trainer_read", "ex4d_trainer_bytes", "ex4d_trainer_time_scalars")
+           "ex4d_trainer_grad", "ex4d_trainer_read", "ex4d_trainer_bytes", "ex4d_trainer_time_scalars", "ex4d_trainer_set_lr",
+           "ex4d_trainer_set_sh_degree")
 
 
 class Ex4dTrainerConfig(C.Structure):
@@ -47,6 +48,10 @@ def _lib():
         lib.ex4d_trainer_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.ex4d_trainer_time_scalars.restype = None
         lib.ex4d_trainer_time_scalars.argtypes = [C.POINTER(Ex4dTrainerConfig), C.c_double, C.POINTER(attr.Ex4dAttrParams)]
+        lib.ex4d_trainer_set_lr.restype = C.c_int
+        lib.ex4d_trainer_set_lr.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.ex4d_trainer_set_sh_degree.restype = C.c_int
+        lib.ex4d_trainer_set_sh_degree.argtypes = [C.c_void_p, C.c_int32]
         lib.ex4d_trainer_bytes.restype = C.c_size_t
         lib.ex4d_trainer_bytes.argtypes = [C.c_void_p]
         lib._trainer_ready = True
@@ -57,7 +62,11 @@ class NativeTrainer:
     """model: scene.DynamicGaussians on a ROCm device (its 15 parameter tensors are updated in place).  cam: the image size and field
     of view are fixed at construction; step() takes any camera of that size."""
 
-    def __init__(self, model, cam, optimizer=True, lrs=None, lambda_dssim=0.2, near=4.0, far=300.0, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, cam, optimizer=True, lrs=None, lambda_dssim=0.2, near=0.2, far=300.0, betas=(0.9, 0.999), eps=1e-8,
+                 spatial_lr_scale=1.0):
+        """lrs: per-parameter learning rates overriding the reference table (trainer.reference_lrs(spatial_lr_scale));
+        near / far default to the reference's dataset.near / dataset.far (arguments/__init__.py:74-75).  This is the render +
+        L1/SSIM + RAdam core of the iteration (include/ex4d_trainer.h: SCOPE): no regularisers, no l1_accum hook, no densification."""
         self.model = model
         self.names = list(attr.PARAM_ORDER)
         self.params = [getattr(model, n) for n in self.names]
@@ -78,7 +87,7 @@ class NativeTrainer:
         cfg.duration, cfg.interval, cfg.time_shift, cfg.var_pad = model.duration, model.interval, model.time_shift, model.var_pad
         cfg.lambda_dssim = lambda_dssim
         cfg.window = (C.c_float * 11)(*[float(x) for x in _WINDOW])
-        lrs = dict(DEFAULT_LRS, **(lrs or {}))
+        lrs = dict(reference_lrs(spatial_lr_scale), **(lrs or {}))
         cfg.lr = (C.c_double * 15)(*[float(lrs[n]) for n in self.names])
         cfg.beta1, cfg.beta2, cfg.eps, cfg.optimizer = betas[0], betas[1], eps, int(bool(optimizer))
         self.cfg = cfg
@@ -107,6 +116,22 @@ class NativeTrainer:
         self.num_rendered = R.value
         if self.cfg.optimizer:
             torch.autograd.graph.increment_version(self.params)
+
+    def set_lrs(self, lrs):
+        """Learning rates from the next step on (dict name -> value; unnamed groups keep theirs): the reference's update_learning_rate."""
+        cur = {n: self.cfg.lr[i] for i, n in enumerate(self.names)}
+        cur.update(lrs)
+        arr = (C.c_double * 15)(*[float(cur[n]) for n in self.names])
+        if _lib().ex4d_trainer_set_lr(self.handle, arr):
+            raise RuntimeError(_lib().ex4d_trainer_last_error().decode())
+        self.cfg.lr = arr
+
+    def set_sh_degree(self, degree):
+        """Active SH degree from the next step on (oneupSHdegree, train.py:113-114)."""
+        if _lib().ex4d_trainer_set_sh_degree(self.handle, int(degree)):
+            raise RuntimeError(_lib().ex4d_trainer_last_error().decode())
+        self.cfg.sh_degree = int(degree)
+        self.model.active_sh_degree = int(degree)
 
     def output(self, what):
         """Copies of the trainer's outputs of the last step: 'loss', 'render', 'radii', 'viewspace_grad', 'depth', 'acc'."""

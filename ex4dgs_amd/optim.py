@@ -21,13 +21,13 @@ MAX_TENSORS = 32
 
 class Ex4dRadamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("numel", C.c_int64), ("lr", C.c_double), ("step", C.c_int64)]
+                ("numel", C.c_int64), ("lr", C.c_double), ("step", C.c_int64), ("nan_to_num", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Ex4dRadamSlicedTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("rows", C.c_int64), ("K", C.c_int32), ("C", C.c_int32),
                 ("lr", C.c_double), ("step", C.c_int64), ("n_windows", C.c_int32), ("first", C.c_int32 * 8), ("count", C.c_int32 * 8),
-                ("grad", C.c_void_p * 8)]
+                ("grad", C.c_void_p * 8), ("first_dev", C.c_void_p)]
 
 
 def _lib():
@@ -44,10 +44,12 @@ def _lib():
 
 def radam_step_raw(items, betas, eps, device):
     """One fused launch (per <= 32 tensors) over raw element ranges.  items: iterable of
-    (param_ptr, grad_ptr, exp_avg_ptr, exp_avg_sq_ptr, numel, lr, step) -- plain device pointers, so a range may be a whole tensor or
-    a rank's shard of one (RAdam is element-wise: updating ranges separately gives bit-identical results)."""
+    (param_ptr, grad_ptr, exp_avg_ptr, exp_avg_sq_ptr, numel, lr, step[, nan_to_num]) -- plain device pointers, so a range may be a
+    whole tensor or a rank's shard of one (RAdam is element-wise: updating ranges separately gives bit-identical results).
+    nan_to_num = 1 reads the gradient through torch.nan_to_num (train.py:244-247 does that to _opacity_duration_var.grad)."""
     lib = _lib()
-    descs = [Ex4dRadamTensor(int(p), int(g), int(m), int(v), int(n), float(lr), int(step)) for (p, g, m, v, n, lr, step) in items if n > 0]
+    descs = [Ex4dRadamTensor(int(it[0]), int(it[1]), int(it[2]), int(it[3]), int(it[4]), float(it[5]), int(it[6]), int(it[7]) if len(it) > 7 else 0, 0)
+             for it in items if it[4] > 0]
     with torch.cuda.device(device):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for i in range(0, len(descs), MAX_TENSORS):
@@ -59,11 +61,14 @@ def radam_step_raw(items, betas, eps, device):
 
 def radam_step_sliced_raw(items, betas, eps, device):
     """ex4d_radam_step_sliced over keyframe tensors [rows, K, C] with windowed gradients.  items: iterable of
-    (param_ptr, exp_avg_ptr, exp_avg_sq_ptr, rows, K, C, lr, step, windows) with windows = [(first, count, grad_ptr), ...] (<= 8),
-    grad_ptr -> [rows, count, C] floats.  Bit-identical to radam_step_raw on the dense gradient the windows add up to."""
+    (param_ptr, exp_avg_ptr, exp_avg_sq_ptr, rows, K, C, lr, step, windows[, first_dev_ptr]) with windows = [(first, count, grad_ptr), ...]
+    (<= 8), grad_ptr -> [rows, count, C] floats; first_dev_ptr (optional): device int32 array of the windows' first keyframes, read by
+    the kernel instead of the host values (no device -> host round trip when the positions were gathered from other ranks).
+    Bit-identical to radam_step_raw on the dense gradient the windows add up to."""
     lib = _lib()
     descs = []
-    for (p, m, v, rows, K, Cc, lr, step, windows) in items:
+    for it in items:
+        (p, m, v, rows, K, Cc, lr, step, windows), first_dev = it[:9], (it[9] if len(it) > 9 else None)
         if rows <= 0:
             continue
         if len(windows) > MAX_WINDOWS:
@@ -71,7 +76,8 @@ def radam_step_sliced_raw(items, betas, eps, device):
         first = (C.c_int32 * 8)(*([w[0] for w in windows] + [0] * (8 - len(windows))))
         count = (C.c_int32 * 8)(*([w[1] for w in windows] + [0] * (8 - len(windows))))
         grad = (C.c_void_p * 8)(*([int(w[2]) for w in windows] + [None] * (8 - len(windows))))
-        descs.append(Ex4dRadamSlicedTensor(int(p), int(m), int(v), int(rows), int(K), int(Cc), float(lr), int(step), len(windows), first, count, grad))
+        descs.append(Ex4dRadamSlicedTensor(int(p), int(m), int(v), int(rows), int(K), int(Cc), float(lr), int(step), len(windows), first, count, grad,
+                                           int(first_dev) if first_dev else None))
     with torch.cuda.device(device):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for i in range(0, len(descs), MAX_SLICED):
@@ -123,7 +129,7 @@ class FusedRAdam(torch.optim.Optimizer):
                 if not (m.is_contiguous() and v.is_contiguous()):
                     raise RuntimeError("FusedRAdam: optimizer state must be contiguous")
                 batches.setdefault((p.device,) + key_tail, []).append(
-                    (Ex4dRadamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step_t.item())), g))
+                    (Ex4dRadamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step_t.item()), 0, 0), g))
                 touched += (p, m, v)
         for (dev, betas, eps), items in batches.items():
             with torch.cuda.device(dev):

@@ -21,19 +21,35 @@ from . import dist as xdist
 from ._C import SplitSH
 from .diff_gaussian_rasterization_df import GaussianRasterizationSettings, rasterize_gaussians
 
-# reference learning rates of the 15 groups (arguments/__init__.py of the reference; position groups use the initial value of their schedule)
-DEFAULT_LRS = {"_xyz": 1.6e-4, "_xyz_disp": 1.6e-4, "_rotation": 1e-3, "_opacity": 5e-2, "_scaling": 5e-3, "_features_dc": 2.5e-3,
-               "_features_rest": 2.5e-3 / 20, "_xyz_motion": 1.6e-4, "_rotation_motion": 1e-3, "_opacity_motion": 5e-2,
-               "_opacity_duration_center": 1e-3, "_opacity_duration_var": 1e-3, "_scaling_motion": 5e-3, "_features_dc_motion": 2.5e-3,
-               "_features_rest_motion": 2.5e-3 / 20}
+def reference_lrs(spatial_lr_scale=1.0):
+    """The 15 optimizer groups of CGaussianModel.training_setup (scene/c_gaussian_model.py:430-447) with the default OptimizationParams
+    (arguments/__init__.py:93-110); the two position groups carry the initial value of their exponential schedule times
+    spatial_lr_scale.  Pinned by tests/golden/training_args.json (captured from the imported reference)."""
+    return {"_xyz": 0.00016 * spatial_lr_scale, "_features_dc": 0.0025, "_features_rest": 0.0025 / 20.0, "_opacity": 0.05, "_scaling": 0.005,
+            "_rotation": 0.00001, "_xyz_disp": 0.0001,
+            "_xyz_motion": 0.00016 * spatial_lr_scale, "_features_dc_motion": 0.0025, "_features_rest_motion": 0.0025 / 20.0,
+            "_scaling_motion": 0.005, "_opacity_motion": 0.05, "_opacity_duration_center": 0.001, "_opacity_duration_var": 0.0005,
+            "_rotation_motion": 0.001}
+
+
+# reference group name (c_gaussian_model.py:430-447) -> parameter attribute
+REFERENCE_GROUP_NAMES = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+                         "rotation": "_rotation", "xyz_disp": "_xyz_disp", "motion_xyz": "_xyz_motion", "motion_f_dc": "_features_dc_motion",
+                         "motion_f_rest": "_features_rest_motion", "motion_scaling": "_scaling_motion", "motion_opacity": "_opacity_motion",
+                         "motion_opacity_center": "_opacity_duration_center", "motion_opacity_var": "_opacity_duration_var",
+                         "motion_rotation": "_rotation_motion"}
+DEFAULT_LRS = reference_lrs(1.0)
+# parameters whose gradient the reference passes through nan_to_num before optimizer.step() (train.py:244-247)
+NAN_TO_NUM = ("_opacity_duration_var",)
 
 
 class FrameTrainer:
     """model: scene.DynamicGaussians on a ROCm device.  exchange: "none" | "allreduce" | "sharded" (reduce-scatter + sharded RAdam +
     all-gather; implies optimizer).  optimizer: False | True (replicated fused RAdam when exchange != "sharded")."""
 
-    def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None):
-        """sliced (default: on whenever a replicated optimizer runs): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from the
+    def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None, spatial_lr_scale=1.0):
+        """lrs: overrides of the reference table reference_lrs(spatial_lr_scale).
+        sliced (default: on whenever a replicated optimizer runs): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from the
         attribute backward through the exchange (all-gather of the ranks' windows) into ex4d_radam_step_sliced -- no 196 MB zero fill,
         no dense read, 16 MB per rank on the wire instead of 196."""
         assert exchange in ("none", "allreduce", "sharded")
@@ -51,27 +67,38 @@ class FrameTrainer:
         # persistent gradient buffers of the 11 non-feature parameters (written once per step by the attribute backward);
         # the four feature gradients come out of the rasterizer's SplitSH path as fresh tensors every step
         self.pgrad = [None if i in self.feature_idx else torch.zeros_like(p) for i, p in enumerate(self.params)]
-        lrs = dict(DEFAULT_LRS, **(lrs or {}))
+        lrs = dict(reference_lrs(spatial_lr_scale), **(lrs or {}))
         self.lrs = [lrs[n] for n in self.names]
         self.opt = None
         self.exchange = None
-        self.sliced = bool(optimizer) and self.mode != "sharded" and model.num_dynamic > 0 if sliced is None else bool(sliced)
+        # one gradient window per rank reaches ex4d_radam_step_sliced: more ranks than it takes windows -> dense keyframe gradients
+        from .optim import MAX_WINDOWS
+        gather_world = self.world if self.mode == "allreduce" else 1      # exchange "none": nothing is summed over ranks, keyframes included
+        fits = gather_world <= MAX_WINDOWS
+        self.sliced = (bool(optimizer) and self.mode != "sharded" and model.num_dynamic > 0 and fits) if sliced is None else bool(sliced)
         if self.sliced and (self.mode == "sharded" or not optimizer):
             raise ValueError("sliced keyframe gradients need the replicated optimizer (the sharded one and plain gradient output are dense)")
+        if self.sliced and not fits:
+            raise ValueError(f"sliced keyframe gradients take one window per rank, at most {MAX_WINDOWS}")
         self.kf_idx = [self.names.index(n) for n in attr.SLICED_SHAPES] if self.sliced else []
         self.kf_gather = []
         if self.sliced:
             for i in self.kf_idx:
                 shape = (self.params[i].shape[0],) + attr.SLICED_SHAPES[self.names[i]]
                 self.pgrad[i] = torch.zeros(shape, dtype=torch.float32, device=self.device)
-                self.kf_gather.append(xdist.SliceGather(shape, self.device, group=group))
-        shapes = [p.shape for i, p in enumerate(self.params) if i not in self.kf_idx]
+                self.kf_gather.append(xdist.SliceGather(shape, self.device, group=group, local_only=(self.mode != "allreduce")))
+        # two exchanges: the four feature gradients (3/4 of the bytes) leave the rasterizer backward and are on the wire while the
+        # attribute backward still runs; the other parameters follow it
+        self.feat_pos = [i for i in self.feature_idx]
+        self.rest_pos = [i for i in range(len(self.params)) if i not in self.kf_idx and i not in self.feature_idx]
+        self.exchange_feat = None
         if self.mode == "sharded":
             self.opt = xdist.ShardedRAdam(self.params, self.lrs, group=group)
             self.exchange = self.opt.exchange
         else:
             if self.mode == "allreduce":
-                self.exchange = xdist.ParamGradExchange(shapes, self.device, mode="allreduce", group=group)
+                self.exchange_feat = xdist.ParamGradExchange([self.params[i].shape for i in self.feat_pos], self.device, mode="allreduce", group=group)
+                self.exchange = xdist.ParamGradExchange([self.params[i].shape for i in self.rest_pos], self.device, mode="allreduce", group=group)
             if optimizer:
                 self.m = [torch.zeros_like(p) for p in self.params]
                 self.v = [torch.zeros_like(p) for p in self.params]
@@ -97,6 +124,8 @@ class FrameTrainer:
     def finish_exchange(self):
         """Block the current stream on the pending gradient exchange (its results are needed by the optimizer / the caller)."""
         def wait_all():
+            if self.exchange_feat is not None:
+                self.exchange_feat.wait()
             if self.exchange is not None:
                 self.exchange.wait()
             for gth in self.kf_gather:
@@ -109,7 +138,17 @@ class FrameTrainer:
             else:
                 wait_all()
 
-    def step(self, cam, bg, t, upstream, near=4.0, far=300.0):
+    def exchange_bytes_on_wire(self):
+        """Payload bytes one rank contributes to one step's gradient exchange (all collectives of the step)."""
+        n = 0
+        for ex in (self.exchange_feat, self.exchange):
+            if ex is not None:
+                n += ex.bytes_on_wire()
+        if self.world > 1:
+            n += sum(g.bytes_on_wire() for g in self.kf_gather if not g.local_only)
+        return n
+
+    def step(self, cam, bg, t, upstream, near=0.2, far=300.0):
         """upstream: callable(render dict) -> (list of outputs, list of their gradients), e.g. a loss evaluated with the fused
         L1+SSIM op, or fixed synthetic gradients.  Returns the render dict (tensors of this frame, detached)."""
         m = self.model
@@ -144,6 +183,9 @@ class FrameTrainer:
         else:
             ctx = torch.cuda.stream(main)
         with ctx:
+            if self.exchange_feat is not None:
+                self.exchange_feat.wait()
+                self.exchange_feat.launch(fgrads)            # on the wire before the attribute backward runs
             if self.exchange is not None:
                 self.exchange.wait()                       # previous frame's collectives own the persistent buffers until here
             for gth in self.kf_gather:
@@ -157,7 +199,10 @@ class FrameTrainer:
             grads = [fgrads[self.feature_idx.index(i)] if i in self.feature_idx else gout[i] for i in range(len(self.params))]
             self._grads = grads
             if self.exchange is not None:
-                self.exchange.launch([g for i, g in enumerate(grads) if i not in self.kf_idx])
+                if self.exchange_feat is not None:
+                    self.exchange.launch([grads[i] for i in self.rest_pos])
+                else:                                      # sharded: one reduce-scatter over all 15 tensors
+                    self.exchange.launch([g for i, g in enumerate(grads) if i not in self.kf_idx])
         self.last = {"radii": radii}
         return out
 
@@ -171,7 +216,7 @@ class FrameTrainer:
         else:
             from .optim import radam_step_raw, radam_step_sliced_raw
             self.steps += 1
-            items = [(p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), lr, self.steps)
+            items = [(p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel(), lr, self.steps, int(self.names[i] in NAN_TO_NUM))
                      for i, (p, g, mm, vv, lr) in enumerate(zip(self.params, self._grads, self.m, self.v, self.lrs)) if i not in self.kf_idx]
             radam_step_raw(items, (0.9, 0.999), 1e-8, self.device)
             if self.sliced:
@@ -179,7 +224,8 @@ class FrameTrainer:
                 for gth, i in zip(self.kf_gather, self.kf_idx):
                     p = self.params[i]
                     count, Cc = attr.SLICED_SHAPES[self.names[i]]
-                    sl.append((p.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.shape[0], p.shape[1], Cc, self.lrs[i], self.steps, gth.windows(count)))
+                    sl.append((p.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.shape[0], p.shape[1], Cc, self.lrs[i], self.steps,
+                               gth.windows(count), gth.first_device_ptr()))
                 radam_step_sliced_raw(sl, (0.9, 0.999), 1e-8, self.device)
             torch.autograd.graph.increment_version(self.params)
         self._grads = None

@@ -32,6 +32,9 @@ typedef struct Ex4dRadamTensor {
     int64_t numel;
     double lr;               /* the group's learning rate for this step */
     int64_t step;            /* t: the tensor's step count AFTER this step's increment (>= 1) */
+    int32_t nan_to_num;      /* != 0: the gradient is read through torch.nan_to_num (NaN -> 0, +-inf -> +-FLT_MAX) -- what train.py:244-247
+                                applies to _opacity_duration_var.grad before optimizer.step(); 0 for every other tensor */
+    int32_t reserved;
 } Ex4dRadamTensor;
 
 const char *ex4d_optim_last_error(void);
@@ -58,6 +61,10 @@ typedef struct Ex4dRadamSlicedTensor {
     int32_t n_windows;       /* 0 .. EX4D_RADAM_MAX_WINDOWS */
     int32_t first[EX4D_RADAM_MAX_WINDOWS], count[EX4D_RADAM_MAX_WINDOWS];
     const float *grad[EX4D_RADAM_MAX_WINDOWS];      /* device [rows, count[w], C] */
+    const int32_t *first_dev;                       /* optional DEVICE array of n_windows first-keyframe indices: when non-NULL the kernel
+                                                       reads the window positions from it and first[] is ignored (windows gathered from
+                                                       other ranks: no device -> host round trip before the launch; a position outside
+                                                       [0, K - count] simply matches no element) */
 } Ex4dRadamSlicedTensor;
 
 int ex4d_radam_step_sliced(const Ex4dRadamSlicedTensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream);

@@ -13,6 +13,14 @@
  * a frame needs more), so the only host <-> device synchronisation of an iteration is the instance-count read-back the reference has
  * too (rasterizer_impl.cu:298-299), which overlaps the depth sort.
  *
+ * SCOPE: this is the render + L1/SSIM + RAdam core of the iteration, not the reference's whole loop.  Not included (they live in the
+ * reference's Python policy layer, out of SURVEY.md 8's scope): the regularisers static_reg / motion_reg / rot_reg (train.py:156-168;
+ * motion_reg and rot_reg make the keyframe gradients dense over all K, which the sliced optimizer path here does not take), the
+ * l1_accum error-map hook on the flow output (train.py:149-152: dL_dout_flow is NULL here, so viewspace_l1points stays zero),
+ * densification / pruning and their statistics.  What the loop changes over time is settable: ex4d_trainer_set_lr (the position
+ * learning-rate schedule, update_learning_rate) and ex4d_trainer_set_sh_degree (oneupSHdegree every 1000 iterations).
+ * _opacity_duration_var's gradient is read through nan_to_num like train.py:244-247 does before optimizer.step().
+ *
  * The 15 parameter tensors stay the caller's (device pointers, CGaussianModel order, float32 contiguous); they are updated in place.
  * Optimizer state (exp_avg, exp_avg_sq, step counts) and every intermediate belong to the trainer.
  */
@@ -62,6 +70,11 @@ void ex4d_trainer_time_scalars(const Ex4dTrainerConfig *cfg, double timestamp, s
  * ex4d_rasterizer.h.  *num_rendered (host, may be NULL) receives the instance count. */
 int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix, const float *projmatrix, const float *campos,
                       const float *background, const float *gt_image, void *stream, int32_t *num_rendered);
+
+/* The per-group learning rates (15, PARAM order) / the active SH degree used from the next step on: update_learning_rate
+ * (c_gaussian_model.py:451-470) and oneupSHdegree (train.py:113-114) of the reference change them during training. */
+int ex4d_trainer_set_lr(Ex4dTrainer *t, const double *lr15);
+int ex4d_trainer_set_sh_degree(Ex4dTrainer *t, int32_t degree);
 
 /* Device pointers into the trainer's workspace, valid until the next step / destroy:
  * what = 0 loss [1], 1 render [3,H,W], 2 radii int32 [P], 3 dL_dmeans2D [P,3] (viewspace gradient, densification statistics),

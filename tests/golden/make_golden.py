@@ -3,6 +3,9 @@ in the build container.  The reference never travels to the GPU box; only these 
 
 What is captured:
   model_getters.npz  CGaussianModel per-frame getters (scene/c_gaussian_model.py:170-215,330-375) + autograd grads
+  model_getters_1k.npz  the same for the seeded 1k static / 1k dynamic case (parameters regenerated from tests/golden/param_gen.py)
+  training_args.json the 15 optimizer groups / learning rates CGaussianModel.training_setup builds from the default OptimizationParams,
+                     near / far defaults (arguments/__init__.py)
   sh_eval.npz        utils/sh_utils.eval_sh outputs (independent check of the SH->RGB restatement)
   cameras.npz        getWorld2View2 / getProjectionMatrix / getProjectionMatrixCV / Cameravideo matrix block
   loss_l1_ssim.npz   utils/loss_utils.l1_loss + ssim (train.py:144-151 combination) outputs + autograd grads
@@ -80,6 +83,74 @@ def golden_model_getters():
                 out[f"{tag}/t{t}/grad/{k}"] = (torch.zeros_like(getattr(pc, k)) if gr is None else gr).numpy()
     np.savez_compressed(os.path.join(OUT, "model_getters.npz"), **out)
     return len(out)
+
+
+def golden_model_getters_1k():
+    """The 1k static / 1k dynamic case of SURVEY 8(a): parameters regenerated from a seed (tests/golden/param_gen.py), so the fixture
+    holds the reference's OUTPUTS and gradients only; keyframe gradients are stored as their non-zero time slices."""
+    from scene.c_gaussian_model import CGaussianModel
+    sys.path.insert(0, OUT)
+    from param_gen import seeded_params, checksum
+    Ns = Nd = 1000
+    pc = CGaussianModel(3, 300, 10, 2, interp_type="cube", rot_interp_type="slerp")
+    K = math.ceil((300 + pc.time_shift + 2 * pc.time_pad + 1) / pc.interval) + 3
+    P, Wt = seeded_params(Ns, Nd, K, seed=4321)
+    out = {"checksum": np.array(checksum(P)), "K": K, "seed": 4321}
+    for k, v in P.items():
+        setattr(pc, k, v.clone().requires_grad_(True))
+    pc.active_sh_degree = 3
+    for t in (0, 137, 299):
+        vals = dict(xyz=pc.get_xyz_at_t(t), rot=pc.get_rotation_at_t(t), opa=pc.get_opacity_at_t(t), scl=pc.get_scaling())
+        loss = sum((vals[k] * Wt[k]).sum() for k in vals)
+        names = [k for k in P if "features" not in k]
+        grads = torch.autograd.grad(loss, [getattr(pc, k) for k in names], allow_unused=True)
+        for k, v in vals.items():
+            out[f"t{t}/{k}"] = v.detach().numpy()
+        for k, gr in zip(names, grads):
+            gr = torch.zeros_like(getattr(pc, k)) if gr is None else gr
+            if k in ("_xyz_motion", "_rotation_motion"):
+                nz = (gr.abs().sum(dim=(0, 2)) > 0).nonzero().flatten()
+                out[f"t{t}/grad_slices/{k}"] = nz.numpy()
+                out[f"t{t}/grad/{k}"] = gr[:, nz].numpy()
+            else:
+                out[f"t{t}/grad/{k}"] = gr.numpy()
+    fea = pc.get_features()
+    assert torch.equal(fea, torch.cat([torch.cat([P["_features_dc"], P["_features_rest"]], 1), torch.cat([P["_features_dc_motion"], P["_features_rest_motion"]], 1)], 0))
+    np.savez_compressed(os.path.join(OUT, "model_getters_1k.npz"), **out)
+    return len(out)
+
+
+def golden_training_args():
+    """The 15 optimizer groups exactly as CGaussianModel.training_setup builds them (c_gaussian_model.py:430-447) from the reference's
+    default OptimizationParams (arguments/__init__.py:93-110), for two values of spatial_lr_scale; near / far defaults of ModelParams."""
+    import argparse
+    from arguments import OptimizationParams, ModelParams
+    from scene.c_gaussian_model import CGaussianModel
+    parser = argparse.ArgumentParser()
+    mp, op = ModelParams(parser), OptimizationParams(parser)
+    real = {n: getattr(torch, n) for n in ("zeros", "ones")}
+    strip = lambda f: (lambda *a, **k: f(*a, **{kk: vv for kk, vv in k.items() if kk != "device"}))
+    info = {"near": mp.near, "far": mp.far, "lambda_dssim": op.lambda_dssim, "groups": {}}
+    try:
+        torch.zeros, torch.ones = strip(real["zeros"]), strip(real["ones"])
+        for scale in (1.0, 3.7):
+            pc = CGaussianModel(3, 300, 10, 2, interp_type="cube", rot_interp_type="slerp")
+            sys.path.insert(0, OUT)
+            from param_gen import seeded_params
+            P, _ = seeded_params(3, 2, 35, seed=1)
+            for k, v in P.items():
+                setattr(pc, k, torch.nn.Parameter(v))
+            pc.spatial_lr_scale = scale
+            pc.training_setup(op)
+            info["groups"][str(scale)] = {g["name"]: g["lr"] for g in pc.optimizer.param_groups}
+            info["optimizer"] = type(pc.optimizer).__name__
+            d = pc.optimizer.defaults
+            info["optimizer_defaults"] = {"betas": list(d["betas"]), "eps": d["eps"], "weight_decay": d["weight_decay"]}
+    finally:
+        torch.zeros, torch.ones = real["zeros"], real["ones"]
+    with open(os.path.join(OUT, "training_args.json"), "w") as f:
+        json.dump(info, f, indent=1)
+    return len(info["groups"]["1.0"])
 
 
 def golden_sh():
@@ -253,6 +324,8 @@ if __name__ == "__main__":
     _stub_modules()
     torch.set_default_dtype(torch.float32)
     print("model_getters:", golden_model_getters())
+    print("model_getters_1k:", golden_model_getters_1k())
+    print("training_args:", golden_training_args())
     print("sh_eval:", golden_sh())
     print("cameras:", golden_cameras())
     print("loss:", golden_loss())

@@ -200,6 +200,60 @@ def test_model_getters_match_reference_golden():
                 assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (tag, t, n)
 
 
+def test_model_getters_match_reference_golden_1k_static_1k_dynamic():
+    """The 1k / 1k case of SURVEY 8(a): parameters regenerated from the seed the golden was made with (tests/golden/param_gen.py),
+    outputs and autograd gradients of the imported CGaussianModel at t in {0, 137, 299}; keyframe gradients are stored as their
+    non-zero time slices (4 position / 2 rotation keyframes) and must be exactly zero elsewhere."""
+    from ex4dgs_amd.scene import DynamicGaussians
+    sys.path.insert(0, GOLD)
+    from param_gen import seeded_params, checksum
+    z = np.load(os.path.join(GOLD, "model_getters_1k.npz"))
+    P, Wt = seeded_params(1000, 1000, int(z["K"]), seed=int(z["seed"]))
+    assert np.allclose(checksum(P), z["checksum"], rtol=1e-12), "torch's CPU generator no longer reproduces the stored parameter set"
+    params = {n: P[n].clone().requires_grad_(True) for n in DynamicGaussians.PARAM_NAMES}
+    m = DynamicGaussians(params, duration=300, interval=10, time_pad=2)
+    for t in (0, 137, 299):
+        vals = dict(xyz=m.get_xyz_at_t(t), rot=m.get_rotation_at_t(t), opa=m.get_opacity_at_t(t), scl=m.get_scaling())
+        for k, v in vals.items():
+            ref = z[f"t{t}/{k}"]
+            assert v.shape == ref.shape and np.abs(v.detach().numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (t, k)
+        names = [n for n in DynamicGaussians.PARAM_NAMES if "features" not in n]
+        grads = torch.autograd.grad(sum((vals[k] * Wt[k]).sum() for k in vals), [params[n] for n in names], allow_unused=True)
+        for n, gr in zip(names, grads):
+            ref = z[f"t{t}/grad/{n}"]
+            got = torch.zeros_like(params[n]) if gr is None else gr
+            if n in ("_xyz_motion", "_rotation_motion"):
+                sl = torch.from_numpy(z[f"t{t}/grad_slices/{n}"])
+                assert len(sl) == (4 if n == "_xyz_motion" else 2)
+                mask = torch.ones(got.shape[1], dtype=torch.bool); mask[sl] = False
+                assert float(got[:, mask].abs().max()) == 0.0, (t, n)
+                got = got[:, sl]
+            assert np.abs(got.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (t, n)
+    assert torch.equal(m.get_features(), torch.cat([torch.cat([P["_features_dc"], P["_features_rest"]], 1),
+                                                    torch.cat([P["_features_dc_motion"], P["_features_rest_motion"]], 1)], 0))
+
+
+def test_trainer_learning_rates_and_depth_range_match_reference_golden():
+    """The optimizer groups the trainers build by default == what the imported CGaussianModel.training_setup built from the reference's
+    default OptimizationParams (tests/golden/training_args.json), for two spatial_lr_scale values; near / far defaults == dataset.near /
+    dataset.far; the gradient the reference sanitises with nan_to_num is flagged."""
+    import inspect
+    from ex4dgs_amd import trainer, native_trainer
+    gold = json.load(open(os.path.join(GOLD, "training_args.json")))
+    assert gold["optimizer"] == "RAdam" and gold["optimizer_defaults"] == {"betas": [0.9, 0.999], "eps": 1e-08, "weight_decay": 0}
+    for scale, groups in gold["groups"].items():
+        ours = trainer.reference_lrs(float(scale))
+        assert set(trainer.REFERENCE_GROUP_NAMES) == set(groups) and len(groups) == 15
+        for gname, lr in groups.items():
+            assert ours[trainer.REFERENCE_GROUP_NAMES[gname]] == pytest.approx(lr, rel=1e-12), (scale, gname)
+    assert trainer.DEFAULT_LRS == trainer.reference_lrs(1.0)
+    for fn in (trainer.FrameTrainer.step, native_trainer.NativeTrainer.__init__):
+        sig = inspect.signature(fn)
+        assert sig.parameters["near"].default == gold["near"] and sig.parameters["far"].default == gold["far"]
+    assert inspect.signature(native_trainer.NativeTrainer.__init__).parameters["lambda_dssim"].default == gold["lambda_dssim"]
+    assert trainer.NAN_TO_NUM == ("_opacity_duration_var",)
+
+
 def test_cameras_match_reference_golden():
     from ex4dgs_amd.scene import make_camera
     z = np.load(os.path.join(GOLD, "cameras.npz"))
@@ -516,7 +570,7 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     hdr4 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_optim.h")).read(), flags=re.S)
     declared4 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr4))
     assert declared4 == set(optim_mod.EXPORTS), declared4 ^ set(optim_mod.EXPORTS)
-    assert ctypes.sizeof(optim_mod.Ex4dRadamTensor) == 56
+    assert ctypes.sizeof(optim_mod.Ex4dRadamTensor) == 64
     from ex4dgs_amd.simple_knn import _C as knn_mod
     hdr5 = re.sub(r"/\*.*?\*/", "", open(os.path.join(h.ROOT, "include", "ex4d_knn.h")).read(), flags=re.S)
     declared5 = set(re.findall(r"\b(ex4d_[a-z0-9_]+)\s*\(", hdr5))

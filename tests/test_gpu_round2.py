@@ -350,3 +350,82 @@ def test_lean_geometry_path_and_optional_gradient_outputs(hip_lib):
         if n in ("dL_dcolors", "dL_dcov3D"):
             continue
         assert float((o - ga[n]).abs().max()) <= 1e-5 * max(1.0, float(ga[n].abs().max())), n
+
+
+def test_radam_nan_to_num_flag_and_device_side_window_positions(hip_lib):
+    """(1) Ex4dRadamTensor.nan_to_num: the gradient is read through torch.nan_to_num (train.py:244-247 does that to
+    _opacity_duration_var.grad before optimizer.step()) -- an injected NaN / inf neither reaches the parameter nor the optimizer state, and
+    the result equals torch.optim.RAdam stepped on the sanitised gradient.  (2) Ex4dRadamSlicedTensor.first_dev: window positions read
+    from device memory (no host round trip) give the step of the host-side positions bit for bit."""
+    from ex4dgs_amd.optim import radam_step_raw, radam_step_sliced_raw
+    g0 = torch.Generator().manual_seed(4)
+    p = torch.randn(5000, generator=g0).cuda()
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.RAdam([ref], lr=1e-2)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 9):
+        g = torch.randn(5000, generator=g0).cuda()
+        g[17] = float("nan"); g[99] = float("inf"); g[100] = float("-inf")
+        ref.grad = torch.nan_to_num(g)
+        opt.step()
+        radam_step_raw([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1e-2, step, 1)], (0.9, 0.999), 1e-8, p.device)
+    torch.cuda.synchronize()
+    assert torch.isfinite(p).all() and torch.isfinite(m).all() and torch.isfinite(v[:99]).all()
+    assert float((p - ref.detach()).abs().max()) <= 2e-6 * float(ref.detach().abs().max())
+    # without the flag the NaN goes through (the caller asked for the plain step)
+    p2, m2, v2 = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    radam_step_raw([(p2.data_ptr(), g.data_ptr(), m2.data_ptr(), v2.data_ptr(), p2.numel(), 1e-2, 1)], (0.9, 0.999), 1e-8, p.device)
+    assert bool(torch.isnan(m2[17]))
+    # (2) sliced step: positions on the host vs in device memory
+    rows, K, Cc = 300, 35, 3
+    q0 = torch.randn(rows, K, Cc, generator=g0).cuda()
+    wins = [torch.randn(rows, 4, Cc, generator=g0).cuda() for _ in range(3)]
+    firsts = [2, 17, 16]
+    res = []
+    for dev_side in (False, True):
+        q, mq, vq = q0.clone(), torch.zeros_like(q0), torch.zeros_like(q0)
+        fd = torch.tensor(firsts, dtype=torch.int32).cuda()
+        for step in range(1, 8):
+            w = [((0 if dev_side else f), 4, x.data_ptr()) for f, x in zip(firsts, wins)]
+            item = (q.data_ptr(), mq.data_ptr(), vq.data_ptr(), rows, K, Cc, 1e-3, step, w) + ((fd.data_ptr(),) if dev_side else ())
+            radam_step_sliced_raw([item], (0.9, 0.999), 1e-8, q.device)
+        torch.cuda.synchronize()
+        res.append((q, mq, vq))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][0], q0)
+
+
+def test_compiled_host_path_learning_rate_and_sh_degree_setters(hip_lib):
+    """ex4d_trainer_set_lr / ex4d_trainer_set_sh_degree (the reference changes both during training: update_learning_rate,
+    oneupSHdegree): a trainer whose rates are set to zero stops moving its parameters; lowering the SH degree changes the render to
+    that of a trainer created at the lower degree."""
+    from ex4dgs_amd.native_trainer import NativeTrainer
+    from ex4dgs_amd.scene import make_scene
+    model, cam, bg = make_scene("cfg3", P=6000, device="cuda", fused=True)
+    cam = cam.to("cuda"); bg = bg.cuda()
+    gt = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(3)).cuda()
+    nt = NativeTrainer(model, cam, optimizer=True, lrs={n: 1e-3 for n in model.PARAM_NAMES})
+    for t in range(7):
+        nt.step(cam, bg, t, gt)
+    before = {n: getattr(model, n).clone() for n in model.PARAM_NAMES}
+    nt.set_lrs({n: 0.0 for n in model.PARAM_NAMES})
+    nt.step(cam, bg, 7, gt)
+    torch.cuda.synchronize()
+    for n in model.PARAM_NAMES:
+        assert torch.equal(getattr(model, n), before[n]), n
+    with pytest.raises(RuntimeError):
+        nt.set_lrs({"_xyz": -1.0})
+    r3 = nt.output("render")
+    nt.set_sh_degree(1)
+    nt.step(cam, bg, 7, gt)
+    r1 = nt.output("render")
+    nt.close()
+    assert float((r1 - r3).abs().max()) > 1e-3
+    model.active_sh_degree = 1
+    fresh = NativeTrainer(model, cam, optimizer=False)
+    fresh.step(cam, bg, 7, gt)
+    assert float((fresh.output("render") - r1).abs().max()) <= 1e-6
+    fresh.close()
+    with pytest.raises(RuntimeError):
+        NativeTrainer(model, cam, optimizer=False).set_sh_degree(4)
