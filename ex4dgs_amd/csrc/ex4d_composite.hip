@@ -151,34 +151,53 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compositing forward.
 // FLOW = false: no Gaussian of the frame carries a non-zero dir3D (the training loop passes the all-zero gradient-trap tensor,
-// gaussian_renderer/__init__.py:66-70): the flow image is zero, its three accumulations per pair and the staging of dir3D are skipped
-template <int WPB, bool FLOW>
+// gaussian_renderer/__init__.py:66-70): the flow image is zero, its three accumulations per pair and the staging of dir3D are skipped.
+// SEP = true (wave-uniform, decided per quadrant): every pixel sits at its integer coordinates (callers always pass a zero
+// subpixel_offset, gaussian_renderer/__init__.py:50).  Then dy takes one value per quadrant ROW, so b'dy and (c'dy)dy -- 5 of the 13
+// VALU instructions every (pixel, staged Gaussian) pair costs before its alpha is known -- are evaluated once per (Gaussian, row) by
+// the staging lane and read back from LDS by the lanes of that row (round 3; the LDS pipe has slack, the VALU has none).
+//
+// Per staged Gaussian and pixel (SEP), before alpha is known:  dx, 2 fma, exp2, w G, min, alpha T, T - alpha T, 3 compares = 11 VALU;
+// for a wave with a contributing pixel 10 more: the masked weight, 4 fma (colour, depth), acc, T -= weight, the last-contributor select
+// and the dominant-index update as ONE integer max of  (weight bits & ~63) | (63 - j):  the 6 low mantissa bits (7.6e-6 relative) give
+// way to the list position, larger for earlier entries -- equal weights keep the first one like the reference's strict `>`, and two
+// weights closer than that are a near-tie the parity contract excludes anyway (oracle: idx_margin < 1e-4).
+// (round 2: 15 + 14 VALU per pair; measured on MI355X, 1.0 M Gaussians: 0.146 ms -> see DESIGN.md section 4.)
+// FLOW frames take the per-pixel evaluation (SEP = false) and keep dir3D in the unused part of the row table: one LDS footprint
+// (7.5 KB per wave) for every variant of the one kernel.
+struct FwdLds {                 // per wave: the survivors of one 64-entry chunk of the tile list
+    float4 q[64];               // SEP: mean.x, a', w, -            otherwise: mean.x, mean.y, a', b'
+    float2 rows[64][8];         // SEP: b' dy, (c' dy) dy of the 8 quadrant rows     otherwise rows[j][0] = (c', w), rows[j][2..3] = dir3D
+    float4 c[64];               // depth, r, g, b
+    uint32_t id[64], orig[64];
+};
+
+template <int WPB, bool FLOW, bool SEP>
 __device__ __forceinline__ void composite_fwd_body(
-    int W, int H, int gx, int num_tiles,
+    int W, int H, int gx, int tile, int quad, const PixelGeom p,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-    const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
+    const float4 *__restrict__ records,
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
-    float4 (*s_q0)[64], float2 (*s_q1)[64], float4 (*s_q2)[64], float4 (*s_q3)[64], uint32_t (*s_id)[64], uint32_t (*s_orig)[64])
+    FwdLds &L)
 {
-
-    int tile, quad;
-    tile_of_block<WPB>(num_tiles, tile, quad);
-    if (tile >= num_tiles) return;
-    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
-    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
+    static_assert(!(FLOW && SEP), "frames with dir3D use the per-pixel evaluation");
+    const int lane = threadIdx.x & 63, row = lane >> 3;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
+    const float oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);       // SEP: p.fy == oy + row, exactly
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
     uint32_t last_contributor = 0;
     int32_t best = -1;
+    const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the list position)
 
     for (int base = 0; base < n; base += 64) {
         if (live == 0) break;
@@ -203,44 +222,80 @@ __device__ __forceinline__ void composite_fwd_body(
             const float4 *r = records + 4 * (size_t)id;
             const float4 q3 = r[3];
             // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
-            s_q0[wave][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
-            s_q1[wave][slot] = make_float2(q1.x * kHalfLog2e, q3.w);
-            s_q2[wave][slot] = r[2];
-            if (FLOW) s_q3[wave][slot] = q3;
-            s_id[wave][slot] = id;
-            s_orig[wave][slot] = (uint32_t)k;
+            const float ap = q0.z * kHalfLog2e, bp = q0.w * kNegLog2e, cp = q1.x * kHalfLog2e;
+            if (SEP) {
+                L.q[slot] = make_float4(q0.x, ap, q3.w, 0.f);
+                // the expressions of power2_of, per quadrant row (identical bits to the per-pixel evaluation and to the backward's)
+                float4 *rw = reinterpret_cast<float4 *>(&L.rows[slot][0]);
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    const float dy0 = q0.y - (oy + (float)(2 * r2)), dy1 = q0.y - (oy + (float)(2 * r2 + 1));
+                    rw[r2] = make_float4(bp * dy0, (cp * dy0) * dy0, bp * dy1, (cp * dy1) * dy1);
+                }
+            } else {
+                L.q[slot] = make_float4(q0.x, q0.y, ap, bp);
+                L.rows[slot][0] = make_float2(cp, q3.w);
+            }
+            L.c[slot] = r[2];
+            if (FLOW) *reinterpret_cast<float4 *>(&L.rows[slot][2]) = q3;
+            L.id[slot] = id;
+            L.orig[slot] = (uint32_t)k;
         }
         wave_lds_sync();
-        int last_j = -1, best_j = -1;
-        for (int j = 0; j < cnt; j++) {
-            if (live == 0) break;
-            const float4 g0 = s_q0[wave][j];
-            const float2 g1 = s_q1[wave][j];
+        int last_j = -1;
+        uint32_t best_key = 0;
+        // one (pixel, staged Gaussian) pair per lane; unrolled by two by hand so that the second entry is read at immediate
+        // offsets of the same LDS addresses (the compiler does not unroll a loop with data-dependent exits)
+        auto pair = [&](const int j) {
+            const float4 g0 = L.q[j];
             // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
-            const float dx = g0.x - p.fx, dy = g0.y - p.fy;
-            const float power2 = power2_of(dx, dy, g0.z, g0.w, g1.x);
-            const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(power2));
-            const float test_T = T * (1.f - alpha);
+            float power2, w;
+            if (SEP) {
+                const float2 rw = L.rows[j][row];
+                power2 = power2_rows(g0.x - p.fx, g0.y, rw.x, rw.y);
+                w = g0.z;
+            } else {
+                const float2 g1 = L.rows[j][0];
+                power2 = power2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
+                w = g1.y;
+            }
+            const float alpha = fminf(0.99f, w * __builtin_amdgcn_exp2f(power2));
+            const float wgt_all = alpha * T;
+            const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
             const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
             const lanemask stop = ok & LANES(test_T < 0.0001f);
             live &= ~stop;
             const lanemask add = ok & ~stop;
-            if (add == 0) continue;
+            if (add == 0) return;
             // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
-            const float4 g2 = s_q2[wave][j];
-            const float wgt = select_f(add, alpha * T, 0.f);
+            const float4 g2 = L.c[j];
+            const float wgt = select_f(add, wgt_all, 0.f);
             C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
             Dm += g2.x * wgt;
             acc += wgt;
-            if (FLOW) { const float4 g3 = s_q3[wave][j]; F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
-            const lanemask brighter = LANES(wgt > max_vis);
-            best_j = select_i(brighter, j, best_j);
-            max_vis = select_f(brighter, wgt, max_vis);
-            T = select_f(add, test_T, T);
+            if (FLOW) { const float4 g3 = *reinterpret_cast<const float4 *>(&L.rows[j][2]); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
+            // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
+            uint32_t key;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
+            best_key = best_key > key ? best_key : key;
+            T -= wgt;                                          // the contributing lanes' new transmittance
             last_j = select_i(add, j, last_j);
+        };
+        {
+            int j = 0;
+            for (; j + 1 < cnt; j += 2) {
+                if (live == 0) break;
+                pair(j);
+                if (live == 0) break;
+                pair(j + 1);
+            }
+            if (j < cnt && live != 0) pair(j);          // odd count: the last entry (a break above leaves live == 0)
         }
-        if (last_j >= 0) last_contributor = s_orig[wave][last_j] + 1;
-        if (best_j >= 0) best = (int32_t)s_id[wave][best_j];
+        if (last_j >= 0) last_contributor = L.orig[last_j] + 1;
+        if (best_key > 63u) {
+            const float wq = __uint_as_float(best_key & keep_hi);
+            if (wq > max_vis) { max_vis = wq; best = (int32_t)L.id[63 - (int)(best_key & 63u)]; }
+        }
         wave_lds_sync();
     }
     if (p.inside) {
@@ -272,19 +327,21 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
     const uint32_t *__restrict__ frame_flags)
 {
-    __shared__ float4 s_q0[WPB][64];      // x, y, A, B
-    __shared__ float2 s_q1[WPB][64];      // C, w
-    __shared__ float4 s_q2[WPB][64];      // depth, r, g, b
-    __shared__ float4 s_q3[WPB][64];      // dir xyz
-    __shared__ uint32_t s_id[WPB][64];
-    __shared__ uint32_t s_orig[WPB][64];
+    __shared__ FwdLds lds[WPB];
+    int tile, quad;
+    tile_of_block<WPB>(num_tiles, tile, quad);
+    if (tile >= num_tiles) return;
+    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
+    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
+    const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
+    const bool sep = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
+#define FWD_ARGS W, H, gx, tile, quad, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
+                 cull_masks, lds[wave]
     // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
-    if (frame_flags[2] != 0u)
-        composite_fwd_body<WPB, true>(W, H, gx, num_tiles, ranges, point_list, subpixel_offset, records, bg, max_depth, final_T, n_contrib,
-                                      out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, s_q0, s_q1, s_q2, s_q3, s_id, s_orig);
-    else
-        composite_fwd_body<WPB, false>(W, H, gx, num_tiles, ranges, point_list, subpixel_offset, records, bg, max_depth, final_T, n_contrib,
-                                       out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, s_q0, s_q1, s_q2, s_q3, s_id, s_orig);
+    if (frame_flags[2] != 0u) composite_fwd_body<WPB, true, false>(FWD_ARGS);
+    else if (sep) composite_fwd_body<WPB, false, true>(FWD_ARGS);
+    else composite_fwd_body<WPB, false, false>(FWD_ARGS);
+#undef FWD_ARGS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 3, GPU call 1: full GPU suite (row-level noise assertion recorded, not asserted), default bench, kernel stats
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p $out
+cd $root
+export EX4D_NOISE_ROWS_ASSERT=0
+timeout 1100 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=900 > $out/r3c1_pytest.txt 2>&1
+echo "pytest rc=$?" >> $out/r3c1_pytest.txt
+cp $out/parity_report.json $out/r3c1_parity_report.json 2>/dev/null
+timeout 300 python bench.py > $out/r3c1_bench.json 2> $out/r3c1_bench.err
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_b
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-model-step > $out/r3c1_prof.log 2>&1
+python $root/tools/rocpd_summary.py $(find /tmp/prof_b -name "*.db" | head -1) $out/r3c1_kernel_stats.txt
+cd $root
+tail -5 $out/r3c1_pytest.txt
+cut -c1-400 $out/r3c1_bench.json
+head -24 $out/r3c1_kernel_stats.txt | cut -c1-140
