@@ -351,6 +351,7 @@ static int backward_impl(
     const int P = prm->P, W = prm->W, H = prm->H;
     if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
     if (!geom_buffer || !binning_buffer || !img_buffer || !bwd_scratch) return fail(EX4D_ERR_ARG, "null state buffer");
+    if ((size_t)P * 64 > 0xFFFFFFFFull) return fail(EX4D_ERR_ARG, "more than 2^26 Gaussians: the accumulator rows are addressed with 32-bit byte offsets");
     // any of the four upstream gradients may be NULL (= zeros: that output is not part of the loss)
     if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
         return fail(EX4D_ERR_ARG, "null gradient output");

@@ -151,152 +151,243 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 }
 
 // ------------------------------------------------------------------------------------------------
-// Compositing forward.
+// Compositing forward (round 3: tile-cooperative list compaction + dense staging).
+//
+// Measured on the round-2 kernel (4 independent quadrant waves, each gathering and culling every 64-entry chunk of the tile list
+// itself): only ~6 % of the (entry, quadrant) pairs survive the quadrant cull and a quadrant almost never finishes before the end
+// of the list, so more than half of the kernel's VALU instructions were the per-chunk work -- id load, record gather, exact
+// ellipse-vs-quadrant test, compaction and the staging of a handful of survivors with 60 idle lanes -- done four times per chunk.
+// Now the four waves of a tile share it:
+//   * every wave takes 64 of the next 256 list entries: ONE id load and ONE 32-byte record gather per entry and tile, the exact
+//     cull against all four quadrants (their boxes sit in SGPRs), four ballots -> the four survivor masks of its chunk, which are
+//     also what the backward kernel compacts from (BinState::cull_masks: same layout as before);
+//   * survivors are appended as (id, list position) to the four per-quadrant queues in LDS -- order preserved: per-wave counts,
+//     one barrier, prefix over the waves, ballot rank inside a wave;
+//   * wave q drains queue q in batches of 32: 64 lanes stage 32 Gaussians (lower half of the wave: mean / conic / weight and
+//     rows 0-3, upper half: colour / depth and rows 4-7), then the 64 pixels walk the batch.
+// Two workgroup barriers per 256 entries.  Finished quadrants keep culling for the others and stop draining; the loop ends when
+// all four are done.
+//
 // FLOW = false: no Gaussian of the frame carries a non-zero dir3D (the training loop passes the all-zero gradient-trap tensor,
 // gaussian_renderer/__init__.py:66-70): the flow image is zero, its three accumulations per pair and the staging of dir3D are skipped.
-// SEP = true (wave-uniform, decided per quadrant): every pixel sits at its integer coordinates (callers always pass a zero
-// subpixel_offset, gaussian_renderer/__init__.py:50).  Then dy takes one value per quadrant ROW, so b'dy and (c'dy)dy -- 5 of the 13
-// VALU instructions every (pixel, staged Gaussian) pair costs before its alpha is known -- are evaluated once per (Gaussian, row) by
-// the staging lane and read back from LDS by the lanes of that row (round 3; the LDS pipe has slack, the VALU has none).
+// SEP = true (uniform over the tile): every pixel sits at its integer coordinates (callers always pass a zero subpixel_offset,
+// gaussian_renderer/__init__.py:50).  Then dy takes one value per quadrant ROW, so b'dy and (c'dy)dy -- 5 of the 13 VALU instructions
+// every (pixel, staged Gaussian) pair costs before its alpha is known -- are evaluated once per (Gaussian, row) by the staging lane
+// and read back from LDS by the lanes of that row (the LDS pipe has slack, the VALU has none).
 //
-// Per staged Gaussian and pixel (SEP), before alpha is known:  dx, 2 fma, exp2, w G, min, alpha T, T - alpha T, 3 compares = 11 VALU;
-// for a wave with a contributing pixel 10 more: the masked weight, 4 fma (colour, depth), acc, T -= weight, the last-contributor select
-// and the dominant-index update as ONE integer max of  (weight bits & ~63) | (63 - j):  the 6 low mantissa bits (7.6e-6 relative) give
-// way to the list position, larger for earlier entries -- equal weights keep the first one like the reference's strict `>`, and two
-// weights closer than that are a near-tie the parity contract excludes anyway (oracle: idx_margin < 1e-4).
-// (round 2: 15 + 14 VALU per pair; measured on MI355X, 1.0 M Gaussians: 0.146 ms -> see DESIGN.md section 4.)
-// FLOW frames take the per-pixel evaluation (SEP = false) and keep dir3D in the unused part of the row table: one LDS footprint
-// (7.5 KB per wave) for every variant of the one kernel.
-struct FwdLds {                 // per wave: the survivors of one 64-entry chunk of the tile list
-    float4 q[64];               // SEP: mean.x, a', w, -            otherwise: mean.x, mean.y, a', b'
-    float2 rows[64][8];         // SEP: b' dy, (c' dy) dy of the 8 quadrant rows     otherwise rows[j][0] = (c', w), rows[j][2..3] = dir3D
-    float4 c[64];               // depth, r, g, b
-    uint32_t id[64], orig[64];
+// Per staged Gaussian and pixel (SEP), before alpha is known:  dx, 2 fma, exp2, w G, min, T (1 - alpha) as one fma, 3 compares = 10
+// VALU; for a wave with a contributing pixel 12 more: alpha T, the masked weight, 4 fma (colour, depth), acc, T -= weight, the
+// last-contributor select and the dominant-index update as ONE integer max of  (weight bits & ~63) | (63 - j):  the 6 low mantissa
+// bits (7.6e-6 relative) give way to the batch position, larger for earlier entries -- equal weights keep the first one like the
+// reference's strict `>`, and two weights closer than that are a near-tie the parity contract excludes anyway (oracle: idx_margin
+// < 1e-4).  FLOW frames take the per-pixel evaluation (SEP = false) and keep dir3D in the unused part of the row table.
+#define FWD_BATCH 32
+#define FWD_SUPER 256                       // list entries per cooperative round (64 per wave)
+#define FWD_QCAP (FWD_SUPER + FWD_BATCH)    // a queue holds < FWD_BATCH left-overs + one round
+struct FwdStage {                // per wave: one batch
+    float4 q[FWD_BATCH];         // SEP: mean.x, a', w, -            otherwise: mean.x, mean.y, a', b'
+    float2 rows[FWD_BATCH][8];   // SEP: b' dy, (c' dy) dy of the 8 quadrant rows     otherwise rows[j][0] = (c', w), rows[j][2..3] = dir3D
+    float4 c[FWD_BATCH];         // depth, r, g, b
+};
+struct FwdShared {
+    uint2 queue[4][FWD_QCAP];    // per quadrant: (Gaussian id, position in the tile list) of the survivors, in list order
+    FwdStage stage[4];
+    uint32_t cnt[4][4];          // [wave][quadrant] survivors of the current round
+    float4 box[4];               // quadrant sample boxes: x0, x1, y0, y1
+    uint32_t done[4];
+    uint32_t nosep[4];
 };
 
-template <int WPB, bool FLOW, bool SEP>
+template <bool FLOW, bool SEP>
 __device__ __forceinline__ void composite_fwd_body(
-    int W, int H, int gx, int tile, int quad, const PixelGeom p,
+    int W, int H, int gx, int tile, const PixelGeom p,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ records,
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
-    FwdLds &L)
+    FwdShared &S)
 {
     static_assert(!(FLOW && SEP), "frames with dir3D use the per-pixel evaluation");
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));          // = quadrant; told to the compiler as wave-uniform
     const int lane = threadIdx.x & 63, row = lane >> 3;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
-    const float oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);       // SEP: p.fy == oy + row, exactly
+    const float oy = (float)((tile / gx) * EX4D_TILE + (wave >> 1) * 8);               // SEP: p.fy == oy + row, exactly
+    FwdStage &L = S.stage[wave];
+    uint2 *const myq = S.queue[wave];
+
+    // the four quadrant boxes (wave-uniform: SGPRs)
+    float bx0[4], bx1[4], by0[4], by1[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 b = S.box[q];
+        bx0[q] = __builtin_amdgcn_readfirstlane(b.x); bx1[q] = __builtin_amdgcn_readfirstlane(b.y);
+        by0[q] = __builtin_amdgcn_readfirstlane(b.z); by1[q] = __builtin_amdgcn_readfirstlane(b.w);
+    }
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
     uint32_t last_contributor = 0;
     int32_t best = -1;
-    const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the list position)
+    const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the batch position)
+    int tail[4] = { 0, 0, 0, 0 };             // entries waiting in the four queues: every wave tracks all four identically
+    bool alive[4] = { true, true, true, true };
+    if (live == 0 && lane == 0) S.done[wave] = 1u;       // a quadrant wholly outside the image
 
-    for (int base = 0; base < n; base += 64) {
-        if (live == 0) break;
-        const int k = base + lane;
-        bool keep = false;
+    for (int base = 0; base < n; base += FWD_SUPER) {
+        // ---- (A) cull: this wave's 64 entries of the round against the four quadrants
+        const int k = base + 64 * wave + lane;
         uint32_t id = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < n) {
-            id = point_list[range.x + k];
-            const float4 *r = records + 4 * (size_t)id;
-            q0 = r[0];
-            q1 = r[1];
-            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
-        }
-        const uint64_t mask = __ballot(keep);
-        const int cnt = __popcll(mask);
-        // the survivors of this chunk, for the backward pass (ex4d_internal.h: BinState::cull_masks)
-        if (lane == 0) cull_masks[4 * ((size_t)((range.x + (uint32_t)base) >> 6) + (size_t)tile) + quad] = mask;
-        if (keep) {
-            const int slot = __popcll(mask & lt);
-            const float4 *r = records + 4 * (size_t)id;
-            const float4 q3 = r[3];
-            // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
-            const float ap = q0.z * kHalfLog2e, bp = q0.w * kNegLog2e, cp = q1.x * kHalfLog2e;
-            if (SEP) {
-                L.q[slot] = make_float4(q0.x, ap, q3.w, 0.f);
-                // the expressions of power2_of, per quadrant row (identical bits to the per-pixel evaluation and to the backward's)
-                float4 *rw = reinterpret_cast<float4 *>(&L.rows[slot][0]);
-#pragma unroll
-                for (int r2 = 0; r2 < 4; r2++) {
-                    const float dy0 = q0.y - (oy + (float)(2 * r2)), dy1 = q0.y - (oy + (float)(2 * r2 + 1));
-                    rw[r2] = make_float4(bp * dy0, (cp * dy0) * dy0, bp * dy1, (cp * dy1) * dy1);
-                }
-            } else {
-                L.q[slot] = make_float4(q0.x, q0.y, ap, bp);
-                L.rows[slot][0] = make_float2(cp, q3.w);
-            }
-            L.c[slot] = r[2];
-            if (FLOW) *reinterpret_cast<float4 *>(&L.rows[slot][2]) = q3;
-            L.id[slot] = id;
-            L.orig[slot] = (uint32_t)k;
-        }
-        wave_lds_sync();
-        int last_j = -1;
-        uint32_t best_key = 0;
-        // one (pixel, staged Gaussian) pair per lane; unrolled by two by hand so that the second entry is read at immediate
-        // offsets of the same LDS addresses (the compiler does not unroll a loop with data-dependent exits)
-        auto pair = [&](const int j) {
-            const float4 g0 = L.q[j];
-            // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
-            float power2, w;
-            if (SEP) {
-                const float2 rw = L.rows[j][row];
-                power2 = power2_rows(g0.x - p.fx, g0.y, rw.x, rw.y);
-                w = g0.z;
-            } else {
-                const float2 g1 = L.rows[j][0];
-                power2 = power2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
-                w = g1.y;
-            }
-            const float alpha = fminf(0.99f, w * __builtin_amdgcn_exp2f(power2));
-            const float wgt_all = alpha * T;
-            const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
-            const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
-            const lanemask stop = ok & LANES(test_T < 0.0001f);
-            live &= ~stop;
-            const lanemask add = ok & ~stop;
-            if (add == 0) return;
-            // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
-            const float4 g2 = L.c[j];
-            const float wgt = select_f(add, wgt_all, 0.f);
-            C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
-            Dm += g2.x * wgt;
-            acc += wgt;
-            if (FLOW) { const float4 g3 = *reinterpret_cast<const float4 *>(&L.rows[j][2]); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
-            // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
-            uint32_t key;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
-            best_key = best_key > key ? best_key : key;
-            T -= wgt;                                          // the contributing lanes' new transmittance
-            last_j = select_i(add, j, last_j);
-        };
+        uint64_t m[4] = { 0ull, 0ull, 0ull, 0ull };
         {
-            int j = 0;
-            for (; j + 1 < cnt; j += 2) {
-                if (live == 0) break;
-                pair(j);
-                if (live == 0) break;
-                pair(j + 1);
+            bool keep[4] = { false, false, false, false };
+            if (k < n) {
+                id = point_list[range.x + k];
+                const float4 *r = records + 4 * (size_t)id;
+                const float4 q0 = r[0], q1 = r[1];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    keep[q] = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0[q], bx1[q], by0[q], by1[q]);
             }
-            if (j < cnt && live != 0) pair(j);          // odd count: the last entry (a break above leaves live == 0)
+#pragma unroll
+            for (int q = 0; q < 4; q++) m[q] = __ballot(keep[q]);
         }
-        if (last_j >= 0) last_contributor = L.orig[last_j] + 1;
-        if (best_key > 63u) {
-            const float wq = __uint_as_float(best_key & keep_hi);
-            if (wq > max_vis) { max_vis = wq; best = (int32_t)L.id[63 - (int)(best_key & 63u)]; }
+        if (base + 64 * wave < n) {
+            // the survivors of this chunk, for the backward pass (ex4d_internal.h: BinState::cull_masks): 4 words = 32 contiguous bytes
+            const unsigned long long mine = lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3]));
+            if (lane < 4) cull_masks[4 * ((size_t)((range.x + (uint32_t)(base + 64 * wave)) >> 6) + (size_t)tile) + lane] = mine;
         }
-        wave_lds_sync();
+        if (lane < 4) S.cnt[wave][lane] = (uint32_t)__popcll(lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3])));
+        __syncthreads();                       // B1: counts visible; everybody has finished draining the previous round
+        // ---- (B) which quadrants still composite (flags were written before B1), where this wave's survivors go
+        bool any_alive = false;
+        int add_total[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            alive[q] = __builtin_amdgcn_readfirstlane((int)S.done[q]) == 0;
+            any_alive = any_alive || alive[q];
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int c = __builtin_amdgcn_readfirstlane((int)S.cnt[w][q]);
+                if (w < wave) before += c;
+                total += c;
+            }
+            add_total[q] = total;
+            if (alive[q] && ((m[q] >> lane) & 1ull))
+                S.queue[q][tail[q] + before + __popcll(m[q] & lt)] = make_uint2(id, (uint32_t)k);
+        }
+        if (!any_alive) break;                 // uniform over the workgroup: same flags, same barrier count
+        __syncthreads();                       // B2: the queues are complete
+#pragma unroll
+        for (int q = 0; q < 4; q++) tail[q] = alive[q] ? tail[q] + add_total[q] : 0;
+        const bool last_round = base + FWD_SUPER >= n;
+        // ---- (C) drain this quadrant's queue in batches of FWD_BATCH
+        int mytail = wave == 0 ? tail[0] : (wave == 1 ? tail[1] : (wave == 2 ? tail[2] : tail[3]));
+        int head = 0;
+        if (live != 0) {
+            while (mytail - head >= FWD_BATCH || (last_round && mytail > head)) {
+                const int nb = (mytail - head) < FWD_BATCH ? (mytail - head) : FWD_BATCH;
+                // stage: lanes 0-31 mean / conic / weight + rows 0-3, lanes 32-63 colour / depth + rows 4-7 of Gaussian (lane & 31)
+                const int l = lane & 31, hi = lane >> 5;
+                if (l < nb) {
+                    const uint32_t gid = myq[head + l].x;
+                    const float4 *r = records + 4 * (size_t)gid;
+                    const float4 q0 = r[0], q1 = r[1];
+                    const float4 q23 = r[3 - hi];                  // lower half: dir3D + w, upper half: depth + colour
+                    // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
+                    const float ap = q0.z * kHalfLog2e, bp = q0.w * kNegLog2e, cp = q1.x * kHalfLog2e;
+                    if (SEP) {
+                        // the expressions of power2_of, per quadrant row (identical bits to the per-pixel evaluation and to the backward's)
+                        float4 *rw = reinterpret_cast<float4 *>(&L.rows[l][4 * hi]);
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; r2++) {
+                            const float dy0 = q0.y - (oy + (float)(4 * hi + 2 * r2)), dy1 = q0.y - (oy + (float)(4 * hi + 2 * r2 + 1));
+                            rw[r2] = make_float4(bp * dy0, (cp * dy0) * dy0, bp * dy1, (cp * dy1) * dy1);
+                        }
+                        if (hi == 0) L.q[l] = make_float4(q0.x, ap, q23.w, 0.f);
+                        else L.c[l] = q23;
+                    } else {
+                        if (hi == 0) {
+                            L.q[l] = make_float4(q0.x, q0.y, ap, bp);
+                            L.rows[l][0] = make_float2(cp, q23.w);
+                            if (FLOW) *reinterpret_cast<float4 *>(&L.rows[l][2]) = q23;
+                        } else L.c[l] = q23;
+                    }
+                }
+                wave_lds_sync();
+                int last_j = -1;
+                uint32_t best_key = 0;
+                // one (pixel, staged Gaussian) pair per lane; unrolled by two by hand so that the second entry is read at immediate
+                // offsets of the same LDS addresses (the compiler does not unroll a loop with data-dependent exits)
+                auto pair = [&](const int j) {
+                    const float4 g0 = L.q[j];
+                    // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
+                    float power2, w;
+                    if (SEP) {
+                        const float2 rw = L.rows[j][row];
+                        power2 = power2_rows(g0.x - p.fx, g0.y, rw.x, rw.y);
+                        w = g0.z;
+                    } else {
+                        const float2 g1 = L.rows[j][0];
+                        power2 = power2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
+                        w = g1.y;
+                    }
+                    const float alpha = fminf(0.99f, w * __builtin_amdgcn_exp2f(power2));
+                    const float wgt_all = alpha * T;
+                    const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
+                    const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
+                    const lanemask stop = ok & LANES(test_T < 0.0001f);
+                    live &= ~stop;
+                    const lanemask add = ok & ~stop;
+                    if (add == 0) return;
+                    // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
+                    const float4 g2 = L.c[j];
+                    const float wgt = select_f(add, wgt_all, 0.f);
+                    C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
+                    Dm += g2.x * wgt;
+                    acc += wgt;
+                    if (FLOW) { const float4 g3 = *reinterpret_cast<const float4 *>(&L.rows[j][2]); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
+                    // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
+                    uint32_t key;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
+                    best_key = best_key > key ? best_key : key;
+                    T -= wgt;                                          // the contributing lanes' new transmittance
+                    last_j = select_i(add, j, last_j);
+                };
+                {
+                    int j = 0;
+                    for (; j + 1 < nb; j += 2) {
+                        if (live == 0) break;
+                        pair(j);
+                        if (live == 0) break;
+                        pair(j + 1);
+                    }
+                    if (j < nb && live != 0) pair(j);          // odd count: the last entry (a break above leaves live == 0)
+                }
+                if (last_j >= 0) last_contributor = myq[head + last_j].y + 1;
+                if (best_key > 63u) {
+                    const float wq = __uint_as_float(best_key & keep_hi);
+                    if (wq > max_vis) { max_vis = wq; best = (int32_t)myq[head + 63 - (int)(best_key & 63u)].x; }
+                }
+                wave_lds_sync();
+                head += nb;
+                if (live == 0) break;
+            }
+            if (live == 0) { if (lane == 0) S.done[wave] = 1u; }
+            else if (head > 0 && head < mytail) {
+                // left-overs (< FWD_BATCH) move to the front of the queue
+                const uint2 keep_it = lane < mytail - head ? myq[head + lane] : make_uint2(0u, 0u);
+                wave_lds_sync();
+                if (lane < mytail - head) myq[lane] = keep_it;
+            }
+        }
+        // every wave tracks the four queue lengths: what a live quadrant leaves behind is a function of its length alone
+#pragma unroll
+        for (int q = 0; q < 4; q++) tail[q] = (alive[q] && !last_round) ? tail[q] % FWD_BATCH : 0;
     }
     if (p.inside) {
         // CR/forward.cu:426-460
@@ -316,8 +407,7 @@ __device__ __forceinline__ void composite_fwd_body(
     }
 }
 
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
@@ -327,20 +417,25 @@ __global__ __launch_bounds__(64 * WPB) void composite_fwd_kernel(
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
     const uint32_t *__restrict__ frame_flags)
 {
-    __shared__ FwdLds lds[WPB];
+    __shared__ FwdShared S;
     int tile, quad;
-    tile_of_block<WPB>(num_tiles, tile, quad);
-    if (tile >= num_tiles) return;
-    const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
+    tile_of_block<4>(num_tiles, tile, quad);
+    if (tile >= num_tiles) return;             // the whole workgroup
+    quad = __builtin_amdgcn_readfirstlane(quad);
+    const int lane = threadIdx.x & 63;
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
     const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
-    const bool sep = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
-#define FWD_ARGS W, H, gx, tile, quad, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
-                 cull_masks, lds[wave]
+    const bool sep_q = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
+    const float x0 = wave_min(p.fx), x1 = wave_max(p.fx), y0 = wave_min(p.fy), y1 = wave_max(p.fy);
+    if (lane == 0) { S.box[quad] = make_float4(x0, x1, y0, y1); S.done[quad] = 0u; S.nosep[quad] = sep_q ? 0u : 1u; }
+    __syncthreads();
+    const bool sep = (S.nosep[0] | S.nosep[1] | S.nosep[2] | S.nosep[3]) == 0u;        // uniform over the tile: one code path, matching barriers
+#define FWD_ARGS W, H, gx, tile, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
+                 cull_masks, S
     // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
-    if (frame_flags[2] != 0u) composite_fwd_body<WPB, true, false>(FWD_ARGS);
-    else if (sep) composite_fwd_body<WPB, false, true>(FWD_ARGS);
-    else composite_fwd_body<WPB, false, false>(FWD_ARGS);
+    if (frame_flags[2] != 0u) composite_fwd_body<true, false>(FWD_ARGS);
+    else if (sep) composite_fwd_body<false, true>(FWD_ARGS);
+    else composite_fwd_body<false, false>(FWD_ARGS);
 #undef FWD_ARGS
 }
 
@@ -589,13 +684,26 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
             if (q < 13) out[q] = r;
         }
     }
+    // byte offset of this lane's Gaussian's accumulator row (all four pixel-slot lanes write the same value); slots 304..319 of the
+    // dump area lie behind everything the steps and the transposition touch
+    reinterpret_cast<uint32_t *>(L.dump)[304 + n] = 64u * __float_as_uint(g1.w);
     wave_lds_sync();
+    // round r: lane (n, g) adds slot n of Gaussian 4r + g -- one atomic instruction covers whole 64-byte rows of four Gaussians.  The
+    // row offsets and the sums sit at immediate offsets of two per-lane LDS addresses; the global address is the (scalar) base of
+    // the accumulator array + a 32-bit lane offset: 1 VALU instruction per round besides the two LDS reads and the atomic
+    // (round 2 recomputed the ring slot, the LDS addresses and a 64-bit address per round: 12 VALU, one of them the ~24-cycle
+    // VOP2 v_cndmask of the ring wrap)
+    {
+        const float *pv = L.dump + 17 * g + n;
+        const uint32_t *po = reinterpret_cast<const uint32_t *>(L.dump) + 304 + g;
+        const uint32_t n4 = 4u * (uint32_t)n;
+        char *base = reinterpret_cast<char *>(acc16);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int gn = 4 * r + g;                  // Gaussian of this lane in round r; accumulator slot = n
-        const float val = L.dump[17 * gn + n];
-        const uint32_t gid = __float_as_uint(L.ring[1][ring_wrap<RING>(head + gn)].w);
-        if (gn < nvalid && n < 13) unsafeAtomicAdd(acc16 + 16 * (size_t)gid + n, val);
+        for (int r = 0; r < 4; r++) {
+            const float val = pv[68 * r];
+            const uint32_t off = po[4 * r] | n4;               // 64 id + 4 n: the row offset has its low six bits clear
+            if (n < 13 && (NOLAST || 4 * r + g < nvalid)) unsafeAtomicAdd(reinterpret_cast<float *>(base + off), val);
+        }
     }
     wave_lds_sync();
 }
@@ -728,7 +836,7 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
         prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
         prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, frame_flags);
     return hipGetLastError();

@@ -272,6 +272,7 @@ def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=6):
 
 ACC_GROUPS = {"dL_dmeans2D": slice(0, 3), "dL_dconic": slice(3, 6), "dL_dopacity": slice(6, 7), "dL_dcolors": slice(7, 10), "dL_ddir": slice(10, 13)}
 NOISE_C = 4.0            # HIP error <= NOISE_C x the reference's own run-to-run spread (VERDICT r02 item 1a asks for c <= 4)
+NOISE_ABS = 1e-5         # north_star's absolute bar: a row whose error is below it passes whatever its noise estimate
 NOISE_FLOOR_EPS = 8.0    # ... or NOISE_FLOOR_EPS half-ulps of sum|terms| x cond where the replayed spread is below that (rows with 1-3 terms:
                          # a sum of two terms has NO order noise, yet two float evaluations of its terms -- expf vs v_exp_f32, fused
                          # vs unfused multiply-adds, which nvcc applies to the reference as well -- differ by ulps of the terms)
@@ -298,7 +299,8 @@ def noise_floor(fwd_o, noise_accs, sum13, abs13=None):
 def compare_with_noise(rep, ref, gb, dev, P, floor_acc=None, floor_derived=None, assert_rows=True):
     """HIP error against the reference's own noise floor, per tensor and per row (Gaussian).
       tensor: max|hip - ref| <= NOISE_C * max(dev)                      (the worst entry of two reference runs vs the worst HIP entry)
-      row:    max_row|hip - ref| <= NOISE_C * max(max_row(dev), floor)  (floor: NOISE_FLOOR_EPS half-ulps of the row's sum|terms| x cond)"""
+      row:    max_row|hip - ref| <= max(NOISE_C * max(max_row(dev), floor), NOISE_ABS)
+              (floor: NOISE_FLOOR_EPS half-ulps of the row's sum|terms| x cond; NOISE_ABS: north_star's absolute 1e-5)"""
     out = {}
     for k, d in dev.items():
         if k == "dL_dconic":
@@ -318,10 +320,16 @@ def compare_with_noise(rep, ref, gb, dev, P, floor_acc=None, floor_derived=None,
             floor = np.asarray(floor_derived[k]).reshape(P, -1).max(1)
         eff = np.maximum(row_noise, floor) + 1e-300
         ratio = row_err / eff
+        # rows whose error is below north_star's absolute 1e-5 are inside the contract whatever their noise estimate says (K = 8 replays
+        # under-estimate the spread of a row with a handful of terms)
+        ratio = np.where(row_err <= NOISE_ABS, np.minimum(ratio, 1.0), ratio)
         live = row_err > 0
+        iw = int(ratio.argmax())
+        worst_row = dict(row=iw, err=float(row_err[iw]), ref_noise=float(row_noise[iw]), floor=float(np.broadcast_to(floor, row_err.shape)[iw]),
+                         ref_abs_max=float(np.abs(a[iw]).max()))
         out[k] = dict(err_max=err_t, ref_noise_max=noise_t, err_over_ref_noise=(err_t / noise_t if noise_t > 0 else 0.0),
                       row_ratio_max=float(ratio.max()), row_ratio_p999=float(np.quantile(ratio[live], 0.999)) if live.any() else 0.0,
-                      rows_above_c=int((ratio > NOISE_C).sum()), rows=int(live.sum()),
+                      rows_above_c=int((ratio > NOISE_C).sum()), rows=int(live.sum()), worst_row=worst_row,
                       row_ratio_noise_only_p999=float(np.quantile((row_err / (row_noise + 1e-300))[live & (row_noise > 0)], 0.999)) if (live & (row_noise > 0)).any() else 0.0)
     rep["noise_floor"] = out
     for k, r in out.items():

@@ -77,7 +77,7 @@ for r in range(world):
 for name, a, b in zip(PARAM_ORDER, summed, acc):
     tol = 2e-5 * float(b.abs().max()) + 1e-12
     assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
-assert tr.exchange.bytes_on_wire() == 4 * sum(p.numel() for p in model.parameters())   # dense: every parameter gradient travels
+assert tr.exchange_bytes_on_wire() == 4 * sum(p.numel() for p in model.parameters())   # dense: every parameter gradient travels
 
 # (2) sharded optimizer == replicated optimizer, bit for bit, over K steps driven by real rasterizer gradients
 lrs = [1e-3 * (1 + i) for i in range(15)]

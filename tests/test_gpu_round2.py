@@ -370,8 +370,11 @@ def test_radam_nan_to_num_flag_and_device_side_window_positions(hip_lib):
         opt.step()
         radam_step_raw([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1e-2, step, 1)], (0.9, 0.999), 1e-8, p.device)
     torch.cuda.synchronize()
-    assert torch.isfinite(p).all() and torch.isfinite(m).all() and torch.isfinite(v[:99]).all()
-    assert float((p - ref.detach()).abs().max()) <= 2e-6 * float(ref.detach().abs().max())
+    r = ref.detach()
+    ok = torch.isfinite(r)                      # (+-inf -> +-FLT_MAX overflows exp_avg_sq in torch as well: those two entries follow torch)
+    assert torch.equal(torch.isfinite(p), ok) and bool(ok[17]) and int((~ok).sum()) <= 2
+    assert not torch.isnan(m).any() and torch.isfinite(m[17]) and torch.isfinite(v[17])
+    assert float(((p - r)[ok].abs() / r[ok].abs().clamp_min(1.0)).max()) <= 2e-6
     # without the flag the NaN goes through (the caller asked for the plain step)
     p2, m2, v2 = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
     radam_step_raw([(p2.data_ptr(), g.data_ptr(), m2.data_ptr(), v2.data_ptr(), p2.numel(), 1e-2, 1)], (0.9, 0.999), 1e-8, p.device)
