@@ -10,6 +10,8 @@
 #include <cstring>
 #include <mutex>
 
+extern int g_fwd_variant;      // ex4d_composite.hip (experiment)
+
 namespace {
 
 std::atomic<bool> g_prof_on{false};
@@ -168,7 +170,8 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     const int tb = tile_bits(T);
     const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
     b.sort_hist = c.take<uint32_t>(hw > hw2 ? hw : hw2);
-    b.cull_masks = c.take<unsigned long long>(ex4d_cull_mask_words(R, T));
+    b.qlist = c.take<uint2>(4 * n);
+    b.qcount = c.take<uint32_t>(4 * (size_t)T);
     l.total = c.off;
     if (lay) *lay = l;
     if (total) *total = c.off;
@@ -329,7 +332,7 @@ static int forward_impl(
     }
     // 8. compositing
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
-                                    out_color, out_depth, out_acc, out_flow, out_idx, b.cull_masks, g.total, stream), prm, stream);
+                                    out_color, out_depth, out_acc, out_flow, out_idx, b.qlist, b.qcount, g.total, stream), prm, stream);
     MARK(0, "composite_fwd");
     return EX4D_OK;
 }
@@ -368,7 +371,7 @@ static int backward_impl(
     if (num_rendered > 0)
         STAGE(ex4d_launch_composite_bwd(*prm, im.ranges, b.point_list, subpixel_offset, background, g.records,
                                         out_depth, out_acc, im.final_T, im.n_contrib,
-                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, b.cull_masks, variant, stream), prm, stream);
+                                        dL_dout_color, dL_dout_depth, dL_dout_flow, dL_dout_acc, acc16, b.qlist, b.qcount, variant, stream), prm, stream);
     MARK(1, "composite_bwd");
     // rasterizer_impl.cu:460 takes the forward's stored covariance when none was passed in; here the kernel recomputes it from
     // scale / rotation with the forward's own function (identical bits), so only a caller-provided covariance is read
@@ -467,6 +470,7 @@ int ex4d_backward_split_sh(
 int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "composite_fwd_variant") && value >= 0 && value <= 4) { g_fwd_variant = value; return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");

@@ -64,6 +64,9 @@ __device__ __forceinline__ int select_i(lanemask m, int if_set, int if_clear)
 __device__ __forceinline__ float power2_rows(float dx, float ap, float bdy, float cdydy) { return __builtin_fmaf(dx, __builtin_fmaf(dx, ap, bdy), cdydy); }
 __device__ __forceinline__ float power2_of(float dx, float dy, float ap, float bp, float cp) { return power2_rows(dx, ap, bp * dy, (cp * dy) * dy); }
 
+// a wave-uniform float into an SGPR (the builtin takes an int: go through the bit pattern, not through a value conversion)
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 __device__ __forceinline__ float wave_min(float v)
 {
 #pragma unroll
@@ -159,12 +162,12 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 // ellipse-vs-quadrant test, compaction and the staging of a handful of survivors with 60 idle lanes -- done four times per chunk.
 // Now the four waves of a tile share it:
 //   * every wave takes 64 of the next 256 list entries: ONE id load and ONE 32-byte record gather per entry and tile, the exact
-//     cull against all four quadrants (their boxes sit in SGPRs), four ballots -> the four survivor masks of its chunk, which are
-//     also what the backward kernel compacts from (BinState::cull_masks: same layout as before);
+//     cull against all four quadrants (their boxes sit in SGPRs), four ballots -> the four survivor masks of its chunk;
 //   * survivors are appended as (id, list position) to the four per-quadrant queues in LDS -- order preserved: per-wave counts,
 //     one barrier, prefix over the waves, ballot rank inside a wave;
 //   * wave q drains queue q in batches of 32: 64 lanes stage 32 Gaussians (lower half of the wave: mean / conic / weight and
-//     rows 0-3, upper half: colour / depth and rows 4-7), then the 64 pixels walk the batch.
+//     rows 0-3, upper half: colour / depth and rows 4-7), then the 64 pixels walk the batch; every drained batch is also appended
+//     to the quadrant's compacted list in global memory (BinState::qlist), which is all the backward kernel reads of the tile list.
 // Two workgroup barriers per 256 entries.  Finished quadrants keep culling for the others and stop draining; the loop ends when
 // all four are done.
 //
@@ -206,7 +209,7 @@ __device__ __forceinline__ void composite_fwd_body(
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
     FwdShared &S)
 {
     static_assert(!(FLOW && SEP), "frames with dir3D use the per-pixel evaluation");
@@ -218,14 +221,16 @@ __device__ __forceinline__ void composite_fwd_body(
     const float oy = (float)((tile / gx) * EX4D_TILE + (wave >> 1) * 8);               // SEP: p.fy == oy + row, exactly
     FwdStage &L = S.stage[wave];
     uint2 *const myq = S.queue[wave];
+    // this quadrant's compacted list for the backward pass (ex4d_internal.h: BinState::qlist)
+    uint2 *const my_list = qlist + 4 * (size_t)range.x + (size_t)wave * (size_t)n;
+    int consumed = 0;
 
     // the four quadrant boxes (wave-uniform: SGPRs)
     float bx0[4], bx1[4], by0[4], by1[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float4 b = S.box[q];
-        bx0[q] = __builtin_amdgcn_readfirstlane(b.x); bx1[q] = __builtin_amdgcn_readfirstlane(b.y);
-        by0[q] = __builtin_amdgcn_readfirstlane(b.z); by1[q] = __builtin_amdgcn_readfirstlane(b.w);
+        bx0[q] = uniform_f(b.x); bx1[q] = uniform_f(b.y); by0[q] = uniform_f(b.z); by1[q] = uniform_f(b.w);
     }
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
@@ -254,11 +259,6 @@ __device__ __forceinline__ void composite_fwd_body(
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) m[q] = __ballot(keep[q]);
-        }
-        if (base + 64 * wave < n) {
-            // the survivors of this chunk, for the backward pass (ex4d_internal.h: BinState::cull_masks): 4 words = 32 contiguous bytes
-            const unsigned long long mine = lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3]));
-            if (lane < 4) cull_masks[4 * ((size_t)((range.x + (uint32_t)(base + 64 * wave)) >> 6) + (size_t)tile) + lane] = mine;
         }
         if (lane < 4) S.cnt[wave][lane] = (uint32_t)__popcll(lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3])));
         __syncthreads();                       // B1: counts visible; everybody has finished draining the previous round
@@ -293,6 +293,8 @@ __device__ __forceinline__ void composite_fwd_body(
                 const int nb = (mytail - head) < FWD_BATCH ? (mytail - head) : FWD_BATCH;
                 // stage: lanes 0-31 mean / conic / weight + rows 0-3, lanes 32-63 colour / depth + rows 4-7 of Gaussian (lane & 31)
                 const int l = lane & 31, hi = lane >> 5;
+                if (lane < nb) my_list[consumed + lane] = myq[head + lane];       // 8 bytes per composited entry, coalesced
+                consumed += nb;
                 if (l < nb) {
                     const uint32_t gid = myq[head + l].x;
                     const float4 *r = records + 4 * (size_t)gid;
@@ -389,6 +391,7 @@ __device__ __forceinline__ void composite_fwd_body(
 #pragma unroll
         for (int q = 0; q < 4; q++) tail[q] = (alive[q] && !last_round) ? tail[q] % FWD_BATCH : 0;
     }
+    if (lane == 0) qcount[4 * tile + wave] = (uint32_t)consumed;
     if (p.inside) {
         // CR/forward.cu:426-460
         float Dout, Fx = F0, Fy = F1, Fz = F2;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ cull_masks,
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
     const uint32_t *__restrict__ frame_flags)
 {
     __shared__ FwdShared S;
@@ -431,12 +434,161 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     __syncthreads();
     const bool sep = (S.nosep[0] | S.nosep[1] | S.nosep[2] | S.nosep[3]) == 0u;        // uniform over the tile: one code path, matching barriers
 #define FWD_ARGS W, H, gx, tile, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
-                 cull_masks, S
+                 qlist, qcount, S
     // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
     if (frame_flags[2] != 0u) composite_fwd_body<true, false>(FWD_ARGS);
     else if (sep) composite_fwd_body<false, true>(FWD_ARGS);
     else composite_fwd_body<false, false>(FWD_ARGS);
 #undef FWD_ARGS
+}
+
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 3, bench only: integer pixel positions, no dir3D): the round-2 structure -- four independent quadrant waves per
+// tile, each culling every 64-entry chunk itself -- with NS staging slots per wave and, with ROWS, the per-row table.
+template <int NS, bool ROWS>
+struct FwdQuadLds {
+    float4 q[NS];
+    float2 rows[NS][ROWS ? 8 : 1];
+    float4 c[NS];
+    uint2 it[NS];
+};
+template <int NS, bool ROWS>
+__global__ __launch_bounds__(256) void composite_fwd_quad_kernel(
+    int W, int H, int gx, int num_tiles,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+    const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
+    const float *__restrict__ bg, float max_depth,
+    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+    float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount)
+{
+    __shared__ FwdQuadLds<NS, ROWS> lds[4];
+    int tile, quad;
+    tile_of_block<4>(num_tiles, tile, quad);
+    if (tile >= num_tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, row = lane >> 3;
+    FwdQuadLds<NS, ROWS> &L = lds[wave];
+    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const float oy = (float)((tile / gx) * EX4D_TILE + (wave >> 1) * 8);
+    uint2 *const my_list = qlist + 4 * (size_t)range.x + (size_t)wave * (size_t)n;
+    int consumed = 0;
+    lanemask live = LANES(p.inside);
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, max_vis = 0.f;
+    uint32_t last_contributor = 0;
+    int32_t best = -1;
+    const uint32_t keep_hi = 0xFFFFFFC0u;
+    for (int base = 0; base < n; base += 64) {
+        if (live == 0) break;
+        const int k = base + lane;
+        bool keep = false;
+        uint32_t id = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n) {
+            id = point_list[range.x + k];
+            const float4 *r = records + 4 * (size_t)id;
+            q0 = r[0]; q1 = r[1];
+            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
+        }
+        const uint64_t mask = __ballot(keep);
+        const int cnt = __popcll(mask);
+        const int slot_all = __popcll(mask & lt);
+        if (keep) my_list[consumed + slot_all] = make_uint2(id, (uint32_t)k);
+        consumed += cnt;
+        float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f), q3 = q2;
+        if (keep) { const float4 *r = records + 4 * (size_t)id; q2 = r[2]; q3 = r[3]; }
+        for (int s0 = 0; s0 < cnt; s0 += NS) {
+            if (live == 0) break;
+            const int slot = slot_all - s0;
+            if (keep && slot >= 0 && slot < NS) {
+                const float ap = q0.z * kHalfLog2e, bp = q0.w * kNegLog2e, cp = q1.x * kHalfLog2e;
+                if (ROWS) {
+                    L.q[slot] = make_float4(q0.x, ap, q3.w, 0.f);
+                    float4 *rw = reinterpret_cast<float4 *>(&L.rows[slot][0]);
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2++) {
+                        const float dy0 = q0.y - (oy + (float)(2 * r2)), dy1 = q0.y - (oy + (float)(2 * r2 + 1));
+                        rw[r2] = make_float4(bp * dy0, (cp * dy0) * dy0, bp * dy1, (cp * dy1) * dy1);
+                    }
+                } else {
+                    L.q[slot] = make_float4(q0.x, q0.y, ap, bp);
+                    L.rows[slot][0] = make_float2(cp, q3.w);
+                }
+                L.c[slot] = q2;
+                L.it[slot] = make_uint2(id, (uint32_t)k);
+            }
+            wave_lds_sync();
+            const int nb = (cnt - s0) < NS ? (cnt - s0) : NS;
+            int last_j = -1;
+            uint32_t best_key = 0;
+            auto pair = [&](const int j) {
+                const float4 g0 = L.q[j];
+                float power2, w;
+                if (ROWS) {
+                    const float2 rw = L.rows[j][row];
+                    power2 = power2_rows(g0.x - p.fx, g0.y, rw.x, rw.y);
+                    w = g0.z;
+                } else {
+                    const float2 g1 = L.rows[j][0];
+                    power2 = power2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
+                    w = g1.y;
+                }
+                const float alpha = fminf(0.99f, w * __builtin_amdgcn_exp2f(power2));
+                const float wgt_all = alpha * T;
+                const float test_T = T - wgt_all;
+                const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
+                const lanemask stop = ok & LANES(test_T < 0.0001f);
+                live &= ~stop;
+                const lanemask add = ok & ~stop;
+                if (add == 0) return;
+                const float4 g2 = L.c[j];
+                const float wgt = select_f(add, wgt_all, 0.f);
+                C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
+                Dm += g2.x * wgt;
+                acc += wgt;
+                uint32_t key;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
+                best_key = best_key > key ? best_key : key;
+                T -= wgt;
+                last_j = select_i(add, j, last_j);
+            };
+            {
+                int j = 0;
+                for (; j + 1 < nb; j += 2) {
+                    if (live == 0) break;
+                    pair(j);
+                    if (live == 0) break;
+                    pair(j + 1);
+                }
+                if (j < nb && live != 0) pair(j);
+            }
+            if (last_j >= 0) last_contributor = L.it[last_j].y + 1;
+            if (best_key > 63u) {
+                const float wq = __uint_as_float(best_key & keep_hi);
+                if (wq > max_vis) { max_vis = wq; best = (int32_t)L.it[63 - (int)(best_key & 63u)].x; }
+            }
+            wave_lds_sync();
+        }
+    }
+    if (lane == 0) qcount[4 * tile + wave] = (uint32_t)consumed;
+    if (p.inside) {
+        float Dout;
+        if (acc == 0.0f) { Dout = Dm + (1.0f - acc) * max_depth; }
+        else { Dout = Dm / acc; }
+        const size_t HW = (size_t)H * W;
+        final_T[p.pix_id] = T;
+        n_contrib[p.pix_id] = last_contributor;
+        out_color[p.pix_id] = C0 + T * bg[0];
+        out_color[HW + p.pix_id] = C1 + T * bg[1];
+        out_color[2 * HW + p.pix_id] = C2 + T * bg[2];
+        out_depth[p.pix_id] = Dout;
+        out_acc[p.pix_id] = acc;
+        out_flow[p.pix_id] = 0.f; out_flow[HW + p.pix_id] = 0.f; out_flow[2 * HW + p.pix_id] = 0.f;
+        out_idx[p.pix_id] = best;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -718,7 +870,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpixels, const float *__restrict__ dL_ddepths,
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
-    float *__restrict__ acc16, const unsigned long long *__restrict__ cull_masks)
+    float *__restrict__ acc16, const uint2 *__restrict__ qlist, const uint32_t *__restrict__ qcount)
 {
     constexpr int RING = BWD_RING;
     __shared__ BwdLdsT<RING> lds[WPB];
@@ -768,36 +920,30 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 
     int head = 0, tail = 0, count = 0;                            // wave-uniform ring indices in [0, RING) and the number of staged entries
     {
-        // The forward kernel walked this list in the same 64-entry chunks and left the survivors of its quadrant cull as one 64-bit
-        // mask per chunk: no gather / test of the ~70 % of entries that miss the quadrant.  Chunks from the deepest contributor
-        // back to the front; inside a chunk lane l takes list position 64 c + 63 - l, so survivors compact in descending order.
-        const int nchunks = ((int)deepest + 63) >> 6;
-        const size_t mbase = (size_t)__builtin_amdgcn_readfirstlane((int)(4u * (uint32_t)tile + (uint32_t)quad));
-        const uint32_t rx = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
-        // the survivor mask and the ids of chunk c - 1 are requested while chunk c is processed (ids for all 64 positions: one
-        // coalesced load, no dependence on the mask): a chunk then waits for ONE memory round trip (its records), not three
-        const int b = 63 - lane;
+        // The forward kernel left this quadrant's compacted list -- (Gaussian id, list position) of every entry it composited, in list
+        // order.  Chunks of 64 from the back; inside a chunk lane l takes entry 64 c + 63 - l, so the ring fills in descending list
+        // order.  Entries at or behind the quadrant's deepest contributor touch no pixel and are dropped (they form the tail of the list).
+        const uint32_t qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcount[4 * tile + quad]);
         const uint32_t list_len = range.y - range.x;
-        uint64_t mask_n = cull_masks[mbase + 4 * (size_t)((rx + 64u * (uint32_t)(nchunks - 1)) >> 6)];
-        uint32_t id_n = 0;
-        { const uint32_t k = 64u * (uint32_t)(nchunks - 1) + (uint32_t)b; if (k < list_len) id_n = point_list[range.x + k]; }
+        const uint2 *ql = qlist + 4 * (size_t)range.x + (size_t)quad * (size_t)list_len;
+        const int nchunks = (int)((qn + 63u) >> 6);
+        const int b = 63 - lane;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        // the entries of chunk c - 1 are requested while chunk c is processed: a chunk waits for ONE memory round trip (its records)
+        uint2 it_n = make_uint2(0u, 0xFFFFFFFFu);
+        if (nchunks > 0) { const uint32_t e = 64u * (uint32_t)(nchunks - 1) + (uint32_t)b; if (e < qn) it_n = ql[e]; }
         for (int c = nchunks - 1; c >= 0; c--) {
-            uint64_t mask = mask_n;
-            const uint32_t id = id_n;
-            if (c > 0) {
-                mask_n = cull_masks[mbase + 4 * (size_t)((rx + 64u * (uint32_t)(c - 1)) >> 6)];
-                id_n = point_list[range.x + 64u * (uint32_t)(c - 1) + (uint32_t)b];          // chunk c - 1 lies wholly inside the list
-            }
-            const int rem = (int)deepest - 64 * c;                // list positions of this chunk that are in front of the deepest contributor
-            if (rem < 64) mask &= (1ull << rem) - 1ull;
-            if ((mask >> b) & 1ull) {
-                const int k = 64 * c + b;
-                const float4 *r = records + 4 * (size_t)id;
+            const uint2 it = it_n;
+            if (c > 0) it_n = ql[64u * (uint32_t)(c - 1) + (uint32_t)b];          // chunk c - 1 lies wholly inside the list
+            const bool valid = it.y < deepest;                    // (entries past the end carry position 0xFFFFFFFF)
+            const uint64_t mask = __ballot(valid);
+            if (valid) {
+                const float4 *r = records + 4 * (size_t)it.x;
                 const float4 q0 = r[0], q2 = r[2];
-                const int slot = ring_wrap<RING>(tail + __popcll(b == 63 ? 0ull : (mask >> (b + 1))));
+                const int slot = ring_wrap<RING>(tail + __popcll(mask & lt));
                 L.ring[0][slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
-                L.ring[1][slot] = make_float4(r[1].x * kHalfLog2e, r[3].w, q2.x, __uint_as_float(id));
-                L.ring[2][slot] = make_float4(q2.y, q2.z, q2.w, __uint_as_float((uint32_t)k));
+                L.ring[1][slot] = make_float4(r[1].x * kHalfLog2e, r[3].w, q2.x, __uint_as_float(it.x));
+                L.ring[2][slot] = make_float4(q2.y, q2.z, q2.w, __uint_as_float(it.y));
             }
             tail = ring_wrap<RING>(tail + __popcll(mask));
             count += __popcll(mask);
@@ -822,6 +968,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 
 }  // namespace
 
+int g_fwd_variant = 0;        // EXPERIMENT: forward kernel selection (ex4d_set_option "composite_fwd_variant")
+
 hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long));
@@ -831,14 +979,20 @@ hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks,
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
     const uint32_t *frame_flags, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
-        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, cull_masks, frame_flags);
+#define QARGS prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg, prm.max_depth, final_T, n_contrib, out_color, out_depth, \
+              out_acc, out_flow, out_idx, qlist, qcount
+    const int fv = g_fwd_variant;
+    if (fv == 1) hipLaunchKernelGGL((composite_fwd_quad_kernel<64, false>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
+    else if (fv == 2) hipLaunchKernelGGL((composite_fwd_quad_kernel<64, true>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
+    else if (fv == 3) hipLaunchKernelGGL((composite_fwd_quad_kernel<32, true>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
+    else if (fv == 4) hipLaunchKernelGGL((composite_fwd_quad_kernel<32, false>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
+    else hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS, frame_flags);
+#undef QARGS
     return hipGetLastError();
 }
 
@@ -847,15 +1001,15 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, const unsigned long long *cull_masks, int variant, hipStream_t stream)
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount, int variant, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
     const int Tpad = 8 * ((T + 7) / 8);
 #define BWD_ARGS prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, out_depth, out_acc, prm.min_depth, \
                  final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16
-    if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, true>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
-    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, false>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, cull_masks);
+    if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, true>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, qlist, qcount);
+    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, false>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, qlist, qcount);
 #undef BWD_ARGS
     return hipGetLastError();
 }

@@ -40,12 +40,15 @@ struct BinState {
     uint32_t *tile_ids;       // final sorted tile ids
     uint32_t *vals_tmp, *keys_tmp;   // ping-pong
     uint32_t *sort_hist;
-    // per (64-entry chunk of a tile list, quadrant): the lanes that survived the forward kernel's quadrant cull; the compositing
-    // backward compacts its lists from these masks instead of gathering and testing every entry again.
-    // slot of chunk c of tile t: 4 * (((range.x + 64 c) >> 6) + t) + quadrant   (unique: ranges are disjoint and ascending in t)
-    unsigned long long *cull_masks;
+    // The forward compositing kernel leaves, per (tile, quadrant), the COMPACTED list of the entries that survived its quadrant cull and
+    // were composited: (Gaussian id, position in the tile list), in list order.  The backward streams these lists back to front
+    // instead of walking the tile list and culling again (round 2 kept one survivor bit mask per 64-entry chunk and quadrant: the
+    // backward still paid a load + compaction round per chunk for ~4 survivors).
+    // Quadrant q of a tile whose range is [r0, r1) owns qlist[4 r0 + q (r1 - r0) ...) (capacity = the list length: every entry could
+    // survive); qcount[4 tile + q] entries of it are valid.  Only the valid prefix is ever touched (~6 % of 4 R entries).
+    uint2 *qlist;
+    uint32_t *qcount;
 };
-static inline size_t ex4d_cull_mask_words(uint32_t R, int T) { return 4 * ((size_t)(R >> 6) + (size_t)T + 2); }
 struct ImgState {
     float *final_T;
     uint32_t *n_contrib;
@@ -102,13 +105,13 @@ hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, 
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, unsigned long long *cull_masks,
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
     const uint32_t *frame_flags, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, const unsigned long long *cull_masks, int variant, hipStream_t stream);
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount, int variant, hipStream_t stream);
 
 // developer statistics of the scan compositing backward (variant 8)
 hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset);
