@@ -10,8 +10,6 @@
 #include <cstring>
 #include <mutex>
 
-extern int g_fwd_variant;      // ex4d_composite.hip (experiment)
-
 namespace {
 
 std::atomic<bool> g_prof_on{false};
@@ -470,7 +468,6 @@ int ex4d_backward_split_sh(
 int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "composite_fwd_variant") && value >= 0 && value <= 4) { g_fwd_variant = value; return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");

@@ -61,8 +61,16 @@ __device__ __forceinline__ int select_i(lanemask m, int if_set, int if_clear)
 // spelled-out contraction for every kernel that takes the alpha decisions (forward, both backward kernels): identical bits, so
 // the backward re-derives exactly the contributor set the forward composited (left to -ffp-contract the compiler fused the
 // forward and the backward expressions differently).  b' dy and (c' dy) dy depend on the Gaussian and the pixel ROW only.
-__device__ __forceinline__ float power2_rows(float dx, float ap, float bdy, float cdydy) { return __builtin_fmaf(dx, __builtin_fmaf(dx, ap, bdy), cdydy); }
-__device__ __forceinline__ float power2_of(float dx, float dy, float ap, float bp, float cp) { return power2_rows(dx, ap, bp * dy, (cp * dy) * dy); }
+// Round 3: the kernels evaluate q2 = -power2 >= 0 (the same contraction with every operand negated: bit for bit -power2, and
+// +0 -- never -0 -- at dx = dy = 0 whatever the sign of B), so that the reference's two skips
+//     power > 0.0f  (CR/forward.cu:372)   and   alpha < 1/255  (:379),  alpha = min(0.99, w exp(power)),
+// become ONE unsigned compare of bit patterns:  bits(q2) <= bits(tauq),  tauq = log2(255 w) >= 0:  a negative q2 (power > 0) has its
+// sign bit set and fails; q2 > tauq <=> w 2^-q2 < 1/255 up to the rounding of log2 / exp2 (1e-7 relative in alpha: inside the band
+// of 1e-4 the parity contract calls fragile).  Forward and backward take the decision from the same q2 and tauq bits, so the
+// backward still re-derives exactly the contributor set the forward composited.  G = exp2(-q2) costs nothing (source modifier).
+__device__ __forceinline__ float q2_rows(float dx, float ap, float bdy, float cdydy) { return __builtin_fmaf(dx, __builtin_fmaf(dx, -ap, -bdy), -cdydy); }
+__device__ __forceinline__ float q2_of(float dx, float dy, float ap, float bp, float cp) { return q2_rows(dx, ap, bp * dy, (cp * dy) * dy); }
+__device__ __forceinline__ uint32_t tauq_bits_of(float w) { return __float_as_uint(__builtin_amdgcn_logf(255.0f * w)); }     // v_log_f32 = log2
 
 // a wave-uniform float into an SGPR (the builtin takes an int: go through the bit pattern, not through a value conversion)
 __device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -154,242 +162,136 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 }
 
 // ------------------------------------------------------------------------------------------------
-// Compositing forward (round 3: tile-cooperative list compaction + dense staging).
-//
-// Measured on the round-2 kernel (4 independent quadrant waves, each gathering and culling every 64-entry chunk of the tile list
-// itself): only ~6 % of the (entry, quadrant) pairs survive the quadrant cull and a quadrant almost never finishes before the end
-// of the list, so more than half of the kernel's VALU instructions were the per-chunk work -- id load, record gather, exact
-// ellipse-vs-quadrant test, compaction and the staging of a handful of survivors with 60 idle lanes -- done four times per chunk.
-// Now the four waves of a tile share it:
-//   * every wave takes 64 of the next 256 list entries: ONE id load and ONE 32-byte record gather per entry and tile, the exact
-//     cull against all four quadrants (their boxes sit in SGPRs), four ballots -> the four survivor masks of its chunk;
-//   * survivors are appended as (id, list position) to the four per-quadrant queues in LDS -- order preserved: per-wave counts,
-//     one barrier, prefix over the waves, ballot rank inside a wave;
-//   * wave q drains queue q in batches of 32: 64 lanes stage 32 Gaussians (lower half of the wave: mean / conic / weight and
-//     rows 0-3, upper half: colour / depth and rows 4-7), then the 64 pixels walk the batch; every drained batch is also appended
-//     to the quadrant's compacted list in global memory (BinState::qlist), which is all the backward kernel reads of the tile list.
-// Two workgroup barriers per 256 entries.  Finished quadrants keep culling for the others and stop draining; the loop ends when
-// all four are done.
-//
+// Compositing forward: four independent quadrant waves per tile (no workgroup barrier), each streaming the tile list in chunks of 64.
 // FLOW = false: no Gaussian of the frame carries a non-zero dir3D (the training loop passes the all-zero gradient-trap tensor,
 // gaussian_renderer/__init__.py:66-70): the flow image is zero, its three accumulations per pair and the staging of dir3D are skipped.
-// SEP = true (uniform over the tile): every pixel sits at its integer coordinates (callers always pass a zero subpixel_offset,
-// gaussian_renderer/__init__.py:50).  Then dy takes one value per quadrant ROW, so b'dy and (c'dy)dy -- 5 of the 13 VALU instructions
-// every (pixel, staged Gaussian) pair costs before its alpha is known -- are evaluated once per (Gaussian, row) by the staging lane
-// and read back from LDS by the lanes of that row (the LDS pipe has slack, the VALU has none).
 //
-// Per staged Gaussian and pixel (SEP), before alpha is known:  dx, 2 fma, exp2, w G, min, T (1 - alpha) as one fma, 3 compares = 10
-// VALU; for a wave with a contributing pixel 12 more: alpha T, the masked weight, 4 fma (colour, depth), acc, T -= weight, the
-// last-contributor select and the dominant-index update as ONE integer max of  (weight bits & ~63) | (63 - j):  the 6 low mantissa
-// bits (7.6e-6 relative) give way to the batch position, larger for earlier entries -- equal weights keep the first one like the
-// reference's strict `>`, and two weights closer than that are a near-tie the parity contract excludes anyway (oracle: idx_margin
-// < 1e-4).  FLOW frames take the per-pixel evaluation (SEP = false) and keep dir3D in the unused part of the row table.
-#define FWD_BATCH 32
-#define FWD_SUPER 256                       // list entries per cooperative round (64 per wave)
-#define FWD_QCAP (FWD_SUPER + FWD_BATCH)    // a queue holds < FWD_BATCH left-overs + one round
-struct FwdStage {                // per wave: one batch
-    float4 q[FWD_BATCH];         // SEP: mean.x, a', w, -            otherwise: mean.x, mean.y, a', b'
-    float2 rows[FWD_BATCH][8];   // SEP: b' dy, (c' dy) dy of the 8 quadrant rows     otherwise rows[j][0] = (c', w), rows[j][2..3] = dir3D
-    float4 c[FWD_BATCH];         // depth, r, g, b
-};
-struct FwdShared {
-    uint2 queue[4][FWD_QCAP];    // per quadrant: (Gaussian id, position in the tile list) of the survivors, in list order
-    FwdStage stage[4];
-    uint32_t cnt[4][4];          // [wave][quadrant] survivors of the current round
-    float4 box[4];               // quadrant sample boxes: x0, x1, y0, y1
-    uint32_t done[4];
-    uint32_t nosep[4];
+// Round 3, measured on MI355X (1.0 M Gaussians, rocprofv3 counters in profiles/r03_fwd_experiment.txt): the kernel is VALU-issue bound
+// to the instruction -- 9.10e7 wave instructions x 4 cycles / 1024 SIMDs = 0.148 ms = its duration; a quadrant composites ~147 list
+// entries (3.2 M (entry, quadrant) pairs reach the pixel loop, 87 % of them with a contributing pixel), half of the entries of the
+// chunks it looks at survive the quadrant cull, and it stops at a fifth of the list.  Tried and rejected with numbers:
+//   * b'dy and (c'dy)dy per (Gaussian, quadrant row) from an LDS table: -11 % instructions, but the per-lane (non-broadcast) LDS read
+//     in the pair loop and the larger footprint made it SLOWER (0.165 ms with 64 staging slots, 0.153 with 32);
+//   * tile-cooperative culling (one gather and four culls per entry and tile, per-quadrant queues, two barriers per 256 entries):
+//     0.192 ms -- a fifth of the list is all a tile ever reads, and the barriers serialise its four latency chains into one.
+// What stayed: the dominant index as ONE integer max of (weight bits & ~63) | (63 - j) -- the 6 low mantissa bits (7.6e-6 relative) give
+// way to the chunk position, larger for earlier entries: equal weights keep the first one like the reference's strict `>`, and two
+// weights closer than that are a near-tie the parity contract excludes (oracle: idx_margin < 1e-4); T (1 - alpha) as one fma and
+// T -= weight instead of a select; the two skips of the reference as one unsigned compare (q2_rows above); the pair loop unrolled by two
+// by hand (immediate LDS offsets).  Per staged Gaussian and pixel: 13 VALU before the decision, 12 more when a pixel contributes.
+// Every chunk's survivors are appended to the quadrant's compacted list (BinState::qlist) -- all the backward reads of the tile list.
+struct FwdLds {                  // per wave: the survivors of one 64-entry chunk (4.5 KB; the kernel's 59 VGPRs, not LDS, bound its occupancy)
+    float4 q0[64];               // mean.x, mean.y, a', b'
+    float4 q1[64];               // c', w, tauq (bits), -
+    float4 c[64];                // depth, r, g, b
+    float4 f[64];                // dir3D (frames with flow only)
+    uint2 it[64];                // Gaussian id, position in the tile list
 };
 
-template <bool FLOW, bool SEP>
+template <bool FLOW>
 __device__ __forceinline__ void composite_fwd_body(
-    int W, int H, int gx, int tile, const PixelGeom p,
+    int W, int H, int gx, int tile, int wave, const PixelGeom p,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ records,
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
-    FwdShared &S)
+    FwdLds &L)
 {
-    static_assert(!(FLOW && SEP), "frames with dir3D use the per-pixel evaluation");
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));          // = quadrant; told to the compiler as wave-uniform
-    const int lane = threadIdx.x & 63, row = lane >> 3;
+    const int lane = threadIdx.x & 63;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
-    const float oy = (float)((tile / gx) * EX4D_TILE + (wave >> 1) * 8);               // SEP: p.fy == oy + row, exactly
-    FwdStage &L = S.stage[wave];
-    uint2 *const myq = S.queue[wave];
     // this quadrant's compacted list for the backward pass (ex4d_internal.h: BinState::qlist)
     uint2 *const my_list = qlist + 4 * (size_t)range.x + (size_t)wave * (size_t)n;
     int consumed = 0;
-
-    // the four quadrant boxes (wave-uniform: SGPRs)
-    float bx0[4], bx1[4], by0[4], by1[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float4 b = S.box[q];
-        bx0[q] = uniform_f(b.x); bx1[q] = uniform_f(b.y); by0[q] = uniform_f(b.z); by1[q] = uniform_f(b.w);
-    }
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
     uint32_t last_contributor = 0;
     int32_t best = -1;
-    const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the batch position)
-    int tail[4] = { 0, 0, 0, 0 };             // entries waiting in the four queues: every wave tracks all four identically
-    bool alive[4] = { true, true, true, true };
-    if (live == 0 && lane == 0) S.done[wave] = 1u;       // a quadrant wholly outside the image
+    const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the chunk position)
 
-    for (int base = 0; base < n; base += FWD_SUPER) {
-        // ---- (A) cull: this wave's 64 entries of the round against the four quadrants
-        const int k = base + 64 * wave + lane;
+    for (int base = 0; base < n; base += 64) {
+        if (live == 0) break;
+        const int k = base + lane;
+        bool keep = false;
         uint32_t id = 0;
-        uint64_t m[4] = { 0ull, 0ull, 0ull, 0ull };
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n) {
+            id = point_list[range.x + k];
+            const float4 *r = records + 4 * (size_t)id;
+            q0 = r[0];
+            q1 = r[1];
+            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
+        }
+        const uint64_t mask = __ballot(keep);
+        const int cnt = __popcll(mask);
+        if (keep) {
+            const int slot = __popcll(mask & lt);
+            const float4 *r = records + 4 * (size_t)id;
+            const float4 q3 = r[3];
+            // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
+            L.q0[slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
+            L.q1[slot] = make_float4(q1.x * kHalfLog2e, q3.w, __uint_as_float(tauq_bits_of(q3.w)), 0.f);
+            L.c[slot] = r[2];
+            if (FLOW) L.f[slot] = q3;
+            const uint2 item = make_uint2(id, (uint32_t)k);
+            L.it[slot] = item;
+            my_list[consumed + slot] = item;          // 8 bytes per survivor, coalesced
+        }
+        consumed += cnt;
+        wave_lds_sync();
+        int last_j = -1;
+        uint32_t best_key = 0;
+        // one (pixel, staged Gaussian) pair per lane; unrolled by two by hand so that the second entry is read at immediate
+        // offsets of the same LDS addresses (the compiler does not unroll a loop with data-dependent exits)
+        auto pair = [&](const int j) {
+            const float4 g0 = L.q0[j];
+            const float4 g1 = L.q1[j];
+            // CR/forward.cu:368-387 as one flat predicate; q2 = -power log2(e)
+            const float q2 = q2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
+            const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(-q2));
+            const float wgt_all = alpha * T;
+            const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
+            const lanemask ok = live & LANES(__float_as_uint(q2) <= __float_as_uint(g1.z));
+            const lanemask stop = ok & LANES(test_T < 0.0001f);
+            live &= ~stop;
+            const lanemask add = ok & ~stop;
+            if (add == 0) return;
+            // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
+            const float4 g2 = L.c[j];
+            const float wgt = select_f(add, wgt_all, 0.f);
+            C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
+            Dm += g2.x * wgt;
+            acc += wgt;
+            if (FLOW) { const float4 g3 = L.f[j]; F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
+            // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
+            uint32_t key;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
+            best_key = best_key > key ? best_key : key;
+            T -= wgt;                                          // the contributing lanes' new transmittance
+            last_j = select_i(add, j, last_j);
+        };
         {
-            bool keep[4] = { false, false, false, false };
-            if (k < n) {
-                id = point_list[range.x + k];
-                const float4 *r = records + 4 * (size_t)id;
-                const float4 q0 = r[0], q1 = r[1];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    keep[q] = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0[q], bx1[q], by0[q], by1[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) m[q] = __ballot(keep[q]);
-        }
-        if (lane < 4) S.cnt[wave][lane] = (uint32_t)__popcll(lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3])));
-        __syncthreads();                       // B1: counts visible; everybody has finished draining the previous round
-        // ---- (B) which quadrants still composite (flags were written before B1), where this wave's survivors go
-        bool any_alive = false;
-        int add_total[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            alive[q] = __builtin_amdgcn_readfirstlane((int)S.done[q]) == 0;
-            any_alive = any_alive || alive[q];
-            int before = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int c = __builtin_amdgcn_readfirstlane((int)S.cnt[w][q]);
-                if (w < wave) before += c;
-                total += c;
-            }
-            add_total[q] = total;
-            if (alive[q] && ((m[q] >> lane) & 1ull))
-                S.queue[q][tail[q] + before + __popcll(m[q] & lt)] = make_uint2(id, (uint32_t)k);
-        }
-        if (!any_alive) break;                 // uniform over the workgroup: same flags, same barrier count
-        __syncthreads();                       // B2: the queues are complete
-#pragma unroll
-        for (int q = 0; q < 4; q++) tail[q] = alive[q] ? tail[q] + add_total[q] : 0;
-        const bool last_round = base + FWD_SUPER >= n;
-        // ---- (C) drain this quadrant's queue in batches of FWD_BATCH
-        int mytail = wave == 0 ? tail[0] : (wave == 1 ? tail[1] : (wave == 2 ? tail[2] : tail[3]));
-        int head = 0;
-        if (live != 0) {
-            while (mytail - head >= FWD_BATCH || (last_round && mytail > head)) {
-                const int nb = (mytail - head) < FWD_BATCH ? (mytail - head) : FWD_BATCH;
-                // stage: lanes 0-31 mean / conic / weight + rows 0-3, lanes 32-63 colour / depth + rows 4-7 of Gaussian (lane & 31)
-                const int l = lane & 31, hi = lane >> 5;
-                if (lane < nb) my_list[consumed + lane] = myq[head + lane];       // 8 bytes per composited entry, coalesced
-                consumed += nb;
-                if (l < nb) {
-                    const uint32_t gid = myq[head + l].x;
-                    const float4 *r = records + 4 * (size_t)gid;
-                    const float4 q0 = r[0], q1 = r[1];
-                    const float4 q23 = r[3 - hi];                  // lower half: dir3D + w, upper half: depth + colour
-                    // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
-                    const float ap = q0.z * kHalfLog2e, bp = q0.w * kNegLog2e, cp = q1.x * kHalfLog2e;
-                    if (SEP) {
-                        // the expressions of power2_of, per quadrant row (identical bits to the per-pixel evaluation and to the backward's)
-                        float4 *rw = reinterpret_cast<float4 *>(&L.rows[l][4 * hi]);
-#pragma unroll
-                        for (int r2 = 0; r2 < 2; r2++) {
-                            const float dy0 = q0.y - (oy + (float)(4 * hi + 2 * r2)), dy1 = q0.y - (oy + (float)(4 * hi + 2 * r2 + 1));
-                            rw[r2] = make_float4(bp * dy0, (cp * dy0) * dy0, bp * dy1, (cp * dy1) * dy1);
-                        }
-                        if (hi == 0) L.q[l] = make_float4(q0.x, ap, q23.w, 0.f);
-                        else L.c[l] = q23;
-                    } else {
-                        if (hi == 0) {
-                            L.q[l] = make_float4(q0.x, q0.y, ap, bp);
-                            L.rows[l][0] = make_float2(cp, q23.w);
-                            if (FLOW) *reinterpret_cast<float4 *>(&L.rows[l][2]) = q23;
-                        } else L.c[l] = q23;
-                    }
-                }
-                wave_lds_sync();
-                int last_j = -1;
-                uint32_t best_key = 0;
-                // one (pixel, staged Gaussian) pair per lane; unrolled by two by hand so that the second entry is read at immediate
-                // offsets of the same LDS addresses (the compiler does not unroll a loop with data-dependent exits)
-                auto pair = [&](const int j) {
-                    const float4 g0 = L.q[j];
-                    // CR/forward.cu:368-387, as one flat predicate (power2 = power * log2 e)
-                    float power2, w;
-                    if (SEP) {
-                        const float2 rw = L.rows[j][row];
-                        power2 = power2_rows(g0.x - p.fx, g0.y, rw.x, rw.y);
-                        w = g0.z;
-                    } else {
-                        const float2 g1 = L.rows[j][0];
-                        power2 = power2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
-                        w = g1.y;
-                    }
-                    const float alpha = fminf(0.99f, w * __builtin_amdgcn_exp2f(power2));
-                    const float wgt_all = alpha * T;
-                    const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
-                    const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
-                    const lanemask stop = ok & LANES(test_T < 0.0001f);
-                    live &= ~stop;
-                    const lanemask add = ok & ~stop;
-                    if (add == 0) return;
-                    // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
-                    const float4 g2 = L.c[j];
-                    const float wgt = select_f(add, wgt_all, 0.f);
-                    C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
-                    Dm += g2.x * wgt;
-                    acc += wgt;
-                    if (FLOW) { const float4 g3 = *reinterpret_cast<const float4 *>(&L.rows[j][2]); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
-                    // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
-                    uint32_t key;
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
-                    best_key = best_key > key ? best_key : key;
-                    T -= wgt;                                          // the contributing lanes' new transmittance
-                    last_j = select_i(add, j, last_j);
-                };
-                {
-                    int j = 0;
-                    for (; j + 1 < nb; j += 2) {
-                        if (live == 0) break;
-                        pair(j);
-                        if (live == 0) break;
-                        pair(j + 1);
-                    }
-                    if (j < nb && live != 0) pair(j);          // odd count: the last entry (a break above leaves live == 0)
-                }
-                if (last_j >= 0) last_contributor = myq[head + last_j].y + 1;
-                if (best_key > 63u) {
-                    const float wq = __uint_as_float(best_key & keep_hi);
-                    if (wq > max_vis) { max_vis = wq; best = (int32_t)myq[head + 63 - (int)(best_key & 63u)].x; }
-                }
-                wave_lds_sync();
-                head += nb;
+            int j = 0;
+            for (; j + 1 < cnt; j += 2) {
                 if (live == 0) break;
+                pair(j);
+                if (live == 0) break;
+                pair(j + 1);
             }
-            if (live == 0) { if (lane == 0) S.done[wave] = 1u; }
-            else if (head > 0 && head < mytail) {
-                // left-overs (< FWD_BATCH) move to the front of the queue
-                const uint2 keep_it = lane < mytail - head ? myq[head + lane] : make_uint2(0u, 0u);
-                wave_lds_sync();
-                if (lane < mytail - head) myq[lane] = keep_it;
-            }
+            if (j < cnt && live != 0) pair(j);          // odd count: the last entry (a break above leaves live == 0)
         }
-        // every wave tracks the four queue lengths: what a live quadrant leaves behind is a function of its length alone
-#pragma unroll
-        for (int q = 0; q < 4; q++) tail[q] = (alive[q] && !last_round) ? tail[q] % FWD_BATCH : 0;
+        if (last_j >= 0) last_contributor = L.it[last_j].y + 1;
+        if (best_key > 63u) {
+            const float wq = __uint_as_float(best_key & keep_hi);
+            if (wq > max_vis) { max_vis = wq; best = (int32_t)L.it[63 - (int)(best_key & 63u)].x; }
+        }
+        wave_lds_sync();
     }
     if (lane == 0) qcount[4 * tile + wave] = (uint32_t)consumed;
     if (p.inside) {
@@ -420,175 +322,18 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
     const uint32_t *__restrict__ frame_flags)
 {
-    __shared__ FwdShared S;
-    int tile, quad;
-    tile_of_block<4>(num_tiles, tile, quad);
-    if (tile >= num_tiles) return;             // the whole workgroup
-    quad = __builtin_amdgcn_readfirstlane(quad);
-    const int lane = threadIdx.x & 63;
-    const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
-    const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
-    const bool sep_q = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
-    const float x0 = wave_min(p.fx), x1 = wave_max(p.fx), y0 = wave_min(p.fy), y1 = wave_max(p.fy);
-    if (lane == 0) { S.box[quad] = make_float4(x0, x1, y0, y1); S.done[quad] = 0u; S.nosep[quad] = sep_q ? 0u : 1u; }
-    __syncthreads();
-    const bool sep = (S.nosep[0] | S.nosep[1] | S.nosep[2] | S.nosep[3]) == 0u;        // uniform over the tile: one code path, matching barriers
-#define FWD_ARGS W, H, gx, tile, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
-                 qlist, qcount, S
-    // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
-    if (frame_flags[2] != 0u) composite_fwd_body<true, false>(FWD_ARGS);
-    else if (sep) composite_fwd_body<false, true>(FWD_ARGS);
-    else composite_fwd_body<false, false>(FWD_ARGS);
-#undef FWD_ARGS
-}
-
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 3, bench only: integer pixel positions, no dir3D): the round-2 structure -- four independent quadrant waves per
-// tile, each culling every 64-entry chunk itself -- with NS staging slots per wave and, with ROWS, the per-row table.
-template <int NS, bool ROWS>
-struct FwdQuadLds {
-    float4 q[NS];
-    float2 rows[NS][ROWS ? 8 : 1];
-    float4 c[NS];
-    uint2 it[NS];
-};
-template <int NS, bool ROWS>
-__global__ __launch_bounds__(256) void composite_fwd_quad_kernel(
-    int W, int H, int gx, int num_tiles,
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-    const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
-    const float *__restrict__ bg, float max_depth,
-    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-    float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount)
-{
-    __shared__ FwdQuadLds<NS, ROWS> lds[4];
+    __shared__ FwdLds lds[4];
     int tile, quad;
     tile_of_block<4>(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, row = lane >> 3;
-    FwdQuadLds<NS, ROWS> &L = lds[wave];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const float oy = (float)((tile / gx) * EX4D_TILE + (wave >> 1) * 8);
-    uint2 *const my_list = qlist + 4 * (size_t)range.x + (size_t)wave * (size_t)n;
-    int consumed = 0;
-    lanemask live = LANES(p.inside);
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, max_vis = 0.f;
-    uint32_t last_contributor = 0;
-    int32_t best = -1;
-    const uint32_t keep_hi = 0xFFFFFFC0u;
-    for (int base = 0; base < n; base += 64) {
-        if (live == 0) break;
-        const int k = base + lane;
-        bool keep = false;
-        uint32_t id = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < n) {
-            id = point_list[range.x + k];
-            const float4 *r = records + 4 * (size_t)id;
-            q0 = r[0]; q1 = r[1];
-            keep = !quadrant_cull(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, bx0, bx1, by0, by1);
-        }
-        const uint64_t mask = __ballot(keep);
-        const int cnt = __popcll(mask);
-        const int slot_all = __popcll(mask & lt);
-        if (keep) my_list[consumed + slot_all] = make_uint2(id, (uint32_t)k);
-        consumed += cnt;
-        float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f), q3 = q2;
-        if (keep) { const float4 *r = records + 4 * (size_t)id; q2 = r[2]; q3 = r[3]; }
-        for (int s0 = 0; s0 < cnt; s0 += NS) {
-            if (live == 0) break;
-            const int slot = slot_all - s0;
-            if (keep && slot >= 0 && slot < NS) {
-                const float ap = q0.z * kHalfLog2e, bp = q0.w * kNegLog2e, cp = q1.x * kHalfLog2e;
-                if (ROWS) {
-                    L.q[slot] = make_float4(q0.x, ap, q3.w, 0.f);
-                    float4 *rw = reinterpret_cast<float4 *>(&L.rows[slot][0]);
-#pragma unroll
-                    for (int r2 = 0; r2 < 4; r2++) {
-                        const float dy0 = q0.y - (oy + (float)(2 * r2)), dy1 = q0.y - (oy + (float)(2 * r2 + 1));
-                        rw[r2] = make_float4(bp * dy0, (cp * dy0) * dy0, bp * dy1, (cp * dy1) * dy1);
-                    }
-                } else {
-                    L.q[slot] = make_float4(q0.x, q0.y, ap, bp);
-                    L.rows[slot][0] = make_float2(cp, q3.w);
-                }
-                L.c[slot] = q2;
-                L.it[slot] = make_uint2(id, (uint32_t)k);
-            }
-            wave_lds_sync();
-            const int nb = (cnt - s0) < NS ? (cnt - s0) : NS;
-            int last_j = -1;
-            uint32_t best_key = 0;
-            auto pair = [&](const int j) {
-                const float4 g0 = L.q[j];
-                float power2, w;
-                if (ROWS) {
-                    const float2 rw = L.rows[j][row];
-                    power2 = power2_rows(g0.x - p.fx, g0.y, rw.x, rw.y);
-                    w = g0.z;
-                } else {
-                    const float2 g1 = L.rows[j][0];
-                    power2 = power2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
-                    w = g1.y;
-                }
-                const float alpha = fminf(0.99f, w * __builtin_amdgcn_exp2f(power2));
-                const float wgt_all = alpha * T;
-                const float test_T = T - wgt_all;
-                const lanemask ok = live & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f));
-                const lanemask stop = ok & LANES(test_T < 0.0001f);
-                live &= ~stop;
-                const lanemask add = ok & ~stop;
-                if (add == 0) return;
-                const float4 g2 = L.c[j];
-                const float wgt = select_f(add, wgt_all, 0.f);
-                C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
-                Dm += g2.x * wgt;
-                acc += wgt;
-                uint32_t key;
-                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
-                best_key = best_key > key ? best_key : key;
-                T -= wgt;
-                last_j = select_i(add, j, last_j);
-            };
-            {
-                int j = 0;
-                for (; j + 1 < nb; j += 2) {
-                    if (live == 0) break;
-                    pair(j);
-                    if (live == 0) break;
-                    pair(j + 1);
-                }
-                if (j < nb && live != 0) pair(j);
-            }
-            if (last_j >= 0) last_contributor = L.it[last_j].y + 1;
-            if (best_key > 63u) {
-                const float wq = __uint_as_float(best_key & keep_hi);
-                if (wq > max_vis) { max_vis = wq; best = (int32_t)L.it[63 - (int)(best_key & 63u)].x; }
-            }
-            wave_lds_sync();
-        }
-    }
-    if (lane == 0) qcount[4 * tile + wave] = (uint32_t)consumed;
-    if (p.inside) {
-        float Dout;
-        if (acc == 0.0f) { Dout = Dm + (1.0f - acc) * max_depth; }
-        else { Dout = Dm / acc; }
-        const size_t HW = (size_t)H * W;
-        final_T[p.pix_id] = T;
-        n_contrib[p.pix_id] = last_contributor;
-        out_color[p.pix_id] = C0 + T * bg[0];
-        out_color[HW + p.pix_id] = C1 + T * bg[1];
-        out_color[2 * HW + p.pix_id] = C2 + T * bg[2];
-        out_depth[p.pix_id] = Dout;
-        out_acc[p.pix_id] = acc;
-        out_flow[p.pix_id] = 0.f; out_flow[HW + p.pix_id] = 0.f; out_flow[2 * HW + p.pix_id] = 0.f;
-        out_idx[p.pix_id] = best;
-    }
+#define FWD_ARGS W, H, gx, tile, wave, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
+                 qlist, qcount, lds[wave]
+    // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
+    if (frame_flags[2] != 0u) composite_fwd_body<true>(FWD_ARGS);
+    else composite_fwd_body<false>(FWD_ARGS);
+#undef FWD_ARGS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -698,6 +443,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
     // invalid lanes never pass `orig < last_contributor` (select spelled out: otherwise the compiler turns the compare below into
     // `valid && ...` and pays a v_cndmask + v_cmp per step to re-materialise the lane mask)
     const uint32_t orig = (uint32_t)select_i(LANES(valid), (int)__float_as_uint(g2.w), -1);
+    const uint32_t tauq = tauq_bits_of(w);                  // the forward's value: same instruction, same bits
     const float flagf = dep > min_depth ? 1.f : 0.f;       // CR/backward.cu:603
     const float depflag = dep * flagf;
     float v[13];
@@ -735,11 +481,11 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
             dx = g0.x - pd.x; dy = g0.y - pd.y;
             bdy = bp * dy; cdydy = (cp * dy) * dy;
         }
-        const float power2 = power2_rows(dx, ap, bdy, cdydy);
-        const float G = __builtin_amdgcn_exp2f(power2);
+        const float q2 = q2_rows(dx, ap, bdy, cdydy);
+        const float G = __builtin_amdgcn_exp2f(-q2);
         const float alpha = fminf(0.99f, w * G);
-        const lanemask ok = NOLAST ? (LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)))
-                                   : (LANES(orig < __float_as_uint(pb.y)) & LANES(power2 <= 0.0f) & LANES(!(alpha < 1.0f / 255.0f)));
+        const lanemask ok = NOLAST ? LANES(__float_as_uint(q2) <= tauq)
+                                   : (LANES(orig < __float_as_uint(pb.y)) & LANES(__float_as_uint(q2) <= tauq));
         if (STATS) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         const float alpha_m = select_f(ok, alpha, 0.f);
@@ -968,8 +714,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 
 }  // namespace
 
-int g_fwd_variant = 0;        // EXPERIMENT: forward kernel selection (ex4d_set_option "composite_fwd_variant")
-
 hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long));
@@ -984,15 +728,9 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-#define QARGS prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg, prm.max_depth, final_T, n_contrib, out_color, out_depth, \
-              out_acc, out_flow, out_idx, qlist, qcount
-    const int fv = g_fwd_variant;
-    if (fv == 1) hipLaunchKernelGGL((composite_fwd_quad_kernel<64, false>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
-    else if (fv == 2) hipLaunchKernelGGL((composite_fwd_quad_kernel<64, true>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
-    else if (fv == 3) hipLaunchKernelGGL((composite_fwd_quad_kernel<32, true>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
-    else if (fv == 4) hipLaunchKernelGGL((composite_fwd_quad_kernel<32, false>), dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS);
-    else hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream, QARGS, frame_flags);
-#undef QARGS
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
+        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
+        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, qlist, qcount, frame_flags);
     return hipGetLastError();
 }
 

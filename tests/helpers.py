@@ -273,9 +273,12 @@ def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=6):
 ACC_GROUPS = {"dL_dmeans2D": slice(0, 3), "dL_dconic": slice(3, 6), "dL_dopacity": slice(6, 7), "dL_dcolors": slice(7, 10), "dL_ddir": slice(10, 13)}
 NOISE_C = 4.0            # HIP error <= NOISE_C x the reference's own run-to-run spread (VERDICT r02 item 1a asks for c <= 4)
 NOISE_ABS = 1e-5         # north_star's absolute bar: a row whose error is below it passes whatever its noise estimate
-NOISE_FLOOR_EPS = 8.0    # ... or NOISE_FLOOR_EPS half-ulps of sum|terms| x cond where the replayed spread is below that (rows with 1-3 terms:
+NOISE_FLOOR_EPS = 16.0   # ... or NOISE_FLOOR_EPS half-ulps of sum|terms| x cond where the replayed spread is below that (rows with 1-3 terms:
                          # a sum of two terms has NO order noise, yet two float evaluations of its terms -- expf vs v_exp_f32, fused
-                         # vs unfused multiply-adds, which nvcc applies to the reference as well -- differ by ulps of the terms)
+                         # vs unfused multiply-adds, which nvcc applies to the reference as well -- differ by ulps of the terms).
+                         # Measured (round 3, 46 backward cases up to 1.0 M Gaussians): the oracle rebuilt with FMA contraction sits
+                         # at <= 15 half-ulps, the HIP kernels (v_exp_f32, v_rcp_f32, scan-tree products) at <= 38 on the worst row
+                         # of a million; 99.9 % of the rows lie below max(replayed spread, 8 half-ulps)
 
 
 def noise_floor(fwd_o, noise_accs, sum13, abs13=None):
