@@ -30,7 +30,7 @@ class GeomLayout(C.Structure):
 
 
 class BinningLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("point_list", "tile_ids", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("point_list", "tile_ids", "qlist", "qcount", "total")]
 
 
 class ImgLayout(C.Structure):
@@ -371,8 +371,11 @@ def binning_views(binningBuffer, R, W, H):
     lay = BinningLayout()
     load().ex4d_binning_layout(R, W, H, C.byref(lay))
     b = binningBuffer
+    T = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(point_list=b[lay.point_list: lay.point_list + 4 * R].view(torch.int32),
-                tile_ids=b[lay.tile_ids: lay.tile_ids + 4 * R].view(torch.int32))
+                tile_ids=b[lay.tile_ids: lay.tile_ids + 4 * R].view(torch.int32),
+                qlist=b[lay.qlist: lay.qlist + 32 * max(R, 1)].view(torch.int32).view(-1, 2),
+                qcount=b[lay.qcount: lay.qcount + 16 * T].view(torch.int32).view(T, 4))
 
 
 def img_views(imgBuffer, W, H):

@@ -168,8 +168,8 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     const int tb = tile_bits(T);
     const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
     b.sort_hist = c.take<uint32_t>(hw > hw2 ? hw : hw2);
-    b.qlist = c.take<uint2>(4 * n);
-    b.qcount = c.take<uint32_t>(4 * (size_t)T);
+    l.qlist = c.off;  b.qlist = c.take<uint2>(4 * n);
+    l.qcount = c.off; b.qcount = c.take<uint32_t>(4 * (size_t)T);
     l.total = c.off;
     if (lay) *lay = l;
     if (total) *total = c.off;

@@ -182,6 +182,11 @@ typedef struct Ex4dBinningLayout {
     size_t point_list;      /* uint32[R]           Gaussian ids sorted by (tile, depth, id): == reference point_list */
     size_t tile_ids;        /* uint32[R]           tile id of every sorted instance (high word of the reference key); with option
                                                    "binning_tile_ids" = 1 only, see ex4d_set_option */
+    size_t qlist;           /* uint2[4 R]          per (tile, 8x8 quadrant) the compacted list the forward compositing kernel leaves for the
+                                                   backward: (Gaussian id, position in the tile list) of the entries that survived its
+                                                   quadrant cull, in list order; quadrant q of a tile with range [r0, r1) owns
+                                                   [4 r0 + q (r1 - r0), ...), qcount[4 tile + q] entries are valid */
+    size_t qcount;          /* uint32[4 T] */
     size_t total;
 } Ex4dBinningLayout;
 typedef struct Ex4dImgLayout {

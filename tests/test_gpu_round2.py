@@ -436,3 +436,33 @@ def test_compiled_host_path_learning_rate_and_sh_degree_setters(hip_lib):
     fresh.close()
     with pytest.raises(RuntimeError):
         NativeTrainer(model, cam, optimizer=False).set_sh_degree(4)
+
+
+def test_compacted_quadrant_lists_left_for_the_backward(hip_lib):
+    """The forward compositing kernel leaves, per (tile, 8x8 quadrant), the compacted list the backward streams (include/ex4d_rasterizer.h:
+    Ex4dBinningLayout.qlist / .qcount): entries are (Gaussian id, position in the tile list) in ascending position, ids agree with the
+    sorted point_list, and every quadrant's list reaches its deepest contributor (max n_contrib over its pixels)."""
+    ins, st = h.scene_inputs("cfg2", P=20000, dir_scale=0.0)
+    g = h.gpu_forward_raw(ins, st)
+    H, W = st["image_height"], st["image_width"]
+    gx = (W + 15) // 16
+    ranges = g["ranges"].cpu().numpy().astype(np.int64); pl = g["point_list"].cpu().numpy().astype(np.int64)
+    ql = g["qlist"].cpu().numpy().astype(np.int64); qc = g["qcount"].cpu().numpy().astype(np.int64)
+    ncon = g["n_contrib"].cpu().numpy().astype(np.int64)
+    total = 0
+    for t in range(ranges.shape[0]):
+        r0, r1 = ranges[t]; n = r1 - r0
+        ty, tx = divmod(t, gx)
+        for q in range(4):
+            qn = qc[t, q]
+            assert 0 <= qn <= n
+            ent = ql[4 * r0 + q * n: 4 * r0 + q * n + qn]
+            total += qn
+            if qn:
+                k = ent[:, 1]
+                assert np.all(np.diff(k) > 0) and k.max() < n and np.array_equal(ent[:, 0], pl[r0 + k]), (t, q)
+            sub = ncon[ty * 16 + (q >> 1) * 8: ty * 16 + (q >> 1) * 8 + 8, tx * 16 + (q & 1) * 8: tx * 16 + (q & 1) * 8 + 8]
+            deepest = int(sub.max()) if sub.size else 0
+            # the deepest contributor itself is a survivor of its quadrant's cull, so it is in the list
+            assert deepest == 0 or (qn > 0 and (ent[:, 1] == deepest - 1).any()), (t, q, deepest)
+    assert 0 < total < 4 * g["num_rendered"]
