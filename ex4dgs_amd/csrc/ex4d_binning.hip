@@ -387,16 +387,41 @@ __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint
 
 // ---------------------------------------------------------------- duplication
 // The 64 Gaussians of a wave are consecutive in depth order, so their instances form ONE contiguous output
-// range.  The wave walks that range 64 outputs at a time: every lane finds the Gaussian owning its output
-// slot (6-step search over the lanes' offsets), derives the tile from the rect, and the wave issues fully
-// coalesced stores -- no serial per-Gaussian loops, no tail behind large rects.
+// range.  The wave walks that range 64 outputs at a time and issues fully coalesced stores -- no serial per-Gaussian
+// loops, no tail behind large rects.  Which Gaussian owns output slot t?
+// Round 2 answered with a 6-step binary search over the lanes' offsets: 6 dependent ds_bpermute + 5 more to fetch the
+// owner's fields per 64 outputs -- the kernel was bound by that LDS round-trip chain (rocprofv3: 7.3e6 VALU instructions
+// but 28 us; SQ_WAIT_INST_LDS 1.8e7).  Round 3: owners are monotone in t, so every Gaussian that STARTS inside the
+// current 64 outputs drops its lane index at its first slot (one LDS write), an inclusive max-scan over the lanes (DPP,
+// no LDS) spreads it to the slots behind, and the owner's fields come out of one 20-byte LDS record: 2 LDS writes + 3
+// reads per 64 outputs, a dependent chain of 3 round trips instead of 7.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t x)
+{
+    // lanes without a source (or outside row_mask) keep x: max(x, x) = x
+    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xf, false);
+    return y > x ? y : x;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_max_u32(uint32_t x)
+{
+    x = dpp_max_u32<0x111, 0xf>(x);       // row_shr:1
+    x = dpp_max_u32<0x112, 0xf>(x);       // row_shr:2
+    x = dpp_max_u32<0x114, 0xf>(x);       // row_shr:4
+    x = dpp_max_u32<0x118, 0xf>(x);       // row_shr:8
+    x = dpp_max_u32<0x142, 0xa>(x);       // row_bcast:15 -> rows 1 and 3
+    x = dpp_max_u32<0x143, 0xc>(x);       // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+struct DupRec { uint32_t off, gid, xy, w, magic; };
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
     const uint2 *__restrict__ sorted_rects,
     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals)
 {
+    __shared__ DupRec s_rec[4][64];
+    __shared__ uint32_t s_mark[4][64];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t gid = 0, off = 0, count = 0;
     int x0 = 0, y0 = 0, w = 1;
     if (k < P) {
@@ -426,32 +451,31 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
     // row = local / w without a per-output division: local < 2^16 (a rect has at most gx*gy tiles; images with more than 65535 tiles
     // take the plain division below) and w < 2^16, so floor(local / w) == umulhi(local, floor((2^32 - 1) / w) + 1) exactly; one division per Gaussian
     const uint32_t magic = 0xFFFFFFFFu / (uint32_t)w + 1u;
-    // lanes past P take the end of the wave's range as offset so the search below never selects them
     uint32_t end = off + count;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(end, o, 64); end = t > end ? t : end; }
-    if (k >= P) off = end;
+    if (k >= P) { off = end; count = 0; }
     const uint32_t start = __shfl(off, 0, 64);
-    const uint32_t xy = (uint32_t)x0 | ((uint32_t)y0 << 16);
-    for (uint32_t tb = start; tb < end; tb += 64) {       // wave-uniform trip count: every lane takes part in the shuffles
+    s_rec[wave][lane] = { off, gid, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)w, magic };
+    uint32_t carry = 0;                      // owner (lane index + 1) of the last output of the previous round
+    for (uint32_t tb = start; tb < end; tb += 64) {       // wave-uniform trip count
         const uint32_t t = tb + lane;
-        // largest lane i with off_i <= t (zero-count lanes share their successor's offset, so this is the owner);
-        // branch-free and select-free: lo += step when the probe's offset is <= t
-        uint32_t lo = 0;
-#pragma unroll
-        for (uint32_t step = 32; step > 0; step >>= 1) {
-            const uint32_t v = __shfl(off, (int)(lo + step), 64);
-            lo += step & (0u - (uint32_t)(v <= t));
-        }
-        const uint32_t o_off = __shfl(off, (int)lo, 64), o_gid = __shfl(gid, (int)lo, 64);
-        const uint32_t o_xy = __shfl(xy, (int)lo, 64), o_w = (uint32_t)__shfl(w, (int)lo, 64), o_magic = __shfl(magic, (int)lo, 64);
-        const uint32_t local = t - o_off;
-        uint32_t row = (o_w == 1u) ? local : __umulhi(local, o_magic);           // magic wraps to 0 for w == 1
-        if (gx * gy > 65535) row = local / o_w;                                   // > 4080 x 4080 pixels: plain division
-        const uint32_t ty = (o_xy >> 16) + row, tx = (o_xy & 0xFFFFu) + (local - row * o_w);
-        if (t < end) {
+        s_mark[wave][lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // Gaussians with instances whose first slot lies in this round (distinct slots: their ranges are disjoint)
+        if (count != 0u && off - tb < 64u) s_mark[wave][off - tb] = (uint32_t)lane + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t owner = wave_inclusive_max_u32(s_mark[wave][lane]);
+        owner = owner > carry ? owner : carry;
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)owner, 63);
+        if (t < end) {                       // owner >= 1 here: slot `start` belongs to the first Gaussian with instances
+            const DupRec r = s_rec[wave][owner - 1u];
+            const uint32_t local = t - r.off;
+            uint32_t row = (r.w == 1u) ? local : __umulhi(local, r.magic);           // magic wraps to 0 for w == 1
+            if (gx * gy > 65535) row = local / r.w;                                   // > 4080 x 4080 pixels: plain division
+            const uint32_t ty = (r.xy >> 16) + row, tx = (r.xy & 0xFFFFu) + (local - row * r.w);
             tile_keys[t] = ty * (uint32_t)gx + tx;
-            vals[t] = o_gid;
+            vals[t] = r.gid;
         }
     }
 }

@@ -44,34 +44,25 @@ __device__ __forceinline__ void wave_lds_sync()
 // scalar unit, "no lane" is a scalar test (a ballot of a combined bool costs a v_cndmask + v_cmp round trip instead).
 typedef unsigned long long lanemask;
 #define LANES(cmp) __builtin_amdgcn_ballot_w64(cmp)
-// gfx940 / gfx950: a VALU instruction that reads an SGPR written by the VALU instruction(s) right before it (a v_cmp_e64 result
-// used as lane mask) needs wait states the compiler pads for its own instructions but NOT for a consumer inside an asm string.
-// Masks that come straight out of ONE compare therefore pass through an SALU move before they reach the selects below (masks that
-// were combined with s_and / s_andn2 already are SALU results).  Round 3: a build whose compare fed the asm select directly returned
-// garbage gradients in every test; the same source with an SALU op in between was exact.
-__device__ __forceinline__ lanemask salu_mask(lanemask m)
-{
-    lanemask r;
-    asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(m));
-    return r;
-}
+// gfx940 / gfx950 hazards the compiler pads for its OWN instructions but not for a consumer inside an asm string (it treats the
+// statement as one opaque instruction and only pads behind it): a transcendental result (v_exp / v_rcp / v_log ...) read by the next
+// VALU instruction needs 1 wait state, an SGPR pair written by a VALU compare and read as lane mask needs 2.  Round 3: once the
+// scheduler had sunk v_exp_f32 behind the skip branch of the backward step, `v_exp_f32 v2, ...` sat directly in front of
+// `v_cndmask_b32_e64 v21, v5, v2, s[8:9]` and every gradient came out wrong (deterministically; the forward was unaffected) -- while
+// the same source with one more instruction in between was exact.  The selects therefore carry their own two wait states.
 __device__ __forceinline__ float select_f(lanemask m, float if_set, float if_clear)
 {
     float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
 }
 __device__ __forceinline__ int select_i(lanemask m, int if_set, int if_clear)
 {
     int r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
 }
 
-// power * log2(e) of CR/forward.cu:368-372 from the pre-scaled conic (a' = -0.5 log2e A, b' = -log2e B, c' = -0.5 log2e C).  ONE
-// spelled-out contraction for every kernel that takes the alpha decisions (forward, both backward kernels): identical bits, so
-// the backward re-derives exactly the contributor set the forward composited (left to -ffp-contract the compiler fused the
-// forward and the backward expressions differently).  b' dy and (c' dy) dy depend on the Gaussian and the pixel ROW only.
 // Round 3: the kernels evaluate q2 = -power2 >= 0 (the same contraction with every operand negated: bit for bit -power2, and
 // +0 -- never -0 -- at dx = dy = 0 whatever the sign of B), so that the reference's two skips
 //     power > 0.0f  (CR/forward.cu:372)   and   alpha < 1/255  (:379),  alpha = min(0.99, w exp(power)),
@@ -453,7 +444,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
     const float ap = g0.z, bp = g0.w, cp = g1.x, w = g1.y, dep = g1.z;
     // invalid lanes never pass `orig < last_contributor` (select spelled out: otherwise the compiler turns the compare below into
     // `valid && ...` and pays a v_cndmask + v_cmp per step to re-materialise the lane mask)
-    const uint32_t orig = (uint32_t)select_i(salu_mask(LANES(valid)), (int)__float_as_uint(g2.w), -1);
+    const uint32_t orig = (uint32_t)select_i(LANES(valid), (int)__float_as_uint(g2.w), -1);
     const uint32_t tauq = tauq_bits_of(w);                  // the forward's value: same instruction, same bits
     const float flagf = dep > min_depth ? 1.f : 0.f;       // CR/backward.cu:603
     const float depflag = dep * flagf;
@@ -495,7 +486,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         const float q2 = q2_rows(dx, ap, bdy, cdydy);
         const float G = __builtin_amdgcn_exp2f(-q2);
         const float alpha = fminf(0.99f, w * G);
-        const lanemask ok = NOLAST ? salu_mask(LANES(__float_as_uint(q2) <= tauq))
+        const lanemask ok = NOLAST ? LANES(__float_as_uint(q2) <= tauq)
                                    : (LANES(orig < __float_as_uint(pb.y)) & LANES(__float_as_uint(q2) <= tauq));
         if (STATS) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros

@@ -5,7 +5,7 @@ from tests import helpers as h
 from oracle import oracle
 from ex4dgs_amd import _C
 _C.load(); _C.set_option("binning_tile_ids", 1); _C.set_option("geom_debug_arrays", 1)
-for cfg, P, ds in (("cfg1", None, 0.1), ("cfg1", None, 0.0), ("cfg2", 20000, 0.0)):
+for cfg, P, ds in (("cfg1", None, 0.1),):
     ins, st = h.scene_inputs(cfg, P=P, dir_scale=ds)
     o = h.oracle_forward(ins, st)
     g = h.gpu_forward_raw(ins, st)
@@ -41,4 +41,7 @@ for cfg, P, ds in (("cfg1", None, 0.1), ("cfg1", None, 0.0), ("cfg2", 20000, 0.0
         gb = h.gpu_backward_raw(ins, g, grads)
         acc = h.acc16_in_reference_units(gb["acc16"], W, H)[:, :13].astype(np.float64)
         err = np.abs(acc - ob["sum13"]); scale = np.maximum(1.0, np.abs(ob["sum13"]).max(0))
+        tol = 1e-5 + 64 * 2.0 ** -24 * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
+        iw = np.unravel_index((err / tol).argmax(), err.shape)
+        print("    worst err/tol", float((err / tol).max()), "at", iw, "gpu", acc[iw], "oracle", ob["sum13"][iw], "abs13", ob["abs13"][iw], "row gpu", np.round(acc[iw[0]], 4), "row oracle", np.round(ob["sum13"][iw[0]], 4))
         print("  run", rep, "old test" if rep // 2 else "new test", "max err / column scale:", np.round(err.max(0) / scale, 6), "rows wrong:", int((err.max(1) > 1e-3 * np.maximum(1, np.abs(ob["sum13"]).max(1))).sum()), "of", int((o["radii"] > 0).sum()))
