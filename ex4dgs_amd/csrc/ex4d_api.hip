@@ -108,6 +108,30 @@ struct Readback {
 };
 thread_local Readback g_readback;
 
+// Second stream + two events per host thread and device: work that only the compositing kernels need (the SH colours) runs beside the
+// binning chain of the caller's stream -- fork after the geometry kernel, join in front of the compositing forward.  Created on first
+// use; never destroyed (the process owns a handful of them).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork, join;
+    bool ready = false;
+    int device = -1;
+    bool init()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (ready && dev == device) return true;
+        if (ready) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(stream); ready = false; }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        ready = true; device = dev;
+        return true;
+    }
+};
+thread_local SideStream g_side;
+std::atomic<int> g_side_stream{1};    // "color_side_stream": 0 = the colour kernel runs in line on the caller's stream
+
 struct Carver {
     char *base; size_t off;
     explicit Carver(void *b) : base((char *)b), off(0) {}
@@ -271,6 +295,21 @@ static int forward_impl(
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
                                      keys0, vals0, key_base, key_invisible, stream), prm, stream);
     MARK(0, "preprocess_fwd");
+    // SH -> RGB: only the compositing kernels read the colours, so the kernel runs on the side stream beside the binning chain below
+    const bool has_sh = shs != nullptr || is_split;
+    bool color_on_side = false;
+    if (has_sh) {
+        if (g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init()) {
+            HIP_TRY(hipEventRecord(g_side.fork, stream));
+            HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
+            HIP_TRY(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, g_side.stream));
+            HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
+            color_on_side = true;
+        } else {
+            STAGE(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, stream), prm, stream);
+            MARK(0, "preprocess_color");
+        }
+    }
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
     // (g.total[0..63] and the per-workgroup counts are adjacent in the geometry buffer: one copy)
@@ -292,14 +331,18 @@ static int forward_impl(
     uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
     for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
     const uint32_t host_total[2] = { instance_sum, g_readback.host[1] };
-    if (prm->prefiltered && host_total[1])
+    // (error exits behind the fork first make the caller's stream wait for the colour kernel: it writes into the caller's buffers)
+    auto join_side = [&]() { if (color_on_side) (void)hipStreamWaitEvent(stream, g_side.join, 0); };
+    if (prm->prefiltered && host_total[1]) {
+        join_side();
         return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
     const uint32_t R = host_total[0];
-    if (R > 0x7FFFFFFFu) return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances");
+    if (R > 0x7FFFFFFFu) { join_side(); return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances"); }
     *num_rendered = (int32_t)R;
 
     void *bin_buf = binning_alloc(binning_user, ex4d_binning_bytes((int32_t)R, W, H));
-    if (!bin_buf) return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed");
+    if (!bin_buf) { join_side(); return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed"); }
     BinState b = carve_binning(bin_buf, R, W, H, nullptr, nullptr);
 
     // 5. emit (tile, id) instances in depth order, 6. stable sort by tile, 7. ranges
@@ -328,7 +371,8 @@ static int forward_impl(
         STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
         MARK(0, "tile_ranges");
     }
-    // 8. compositing
+    // 8. compositing (joins the colour kernel first)
+    if (color_on_side) HIP_TRY(hipStreamWaitEvent(stream, g_side.join, 0));
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
                                     out_color, out_depth, out_acc, out_flow, out_idx, b.qlist, b.qcount, g.total, stream), prm, stream);
     MARK(0, "composite_fwd");
@@ -468,6 +512,7 @@ int ex4d_backward_split_sh(
 int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "color_side_stream") && (value == 0 || value == 1)) { g_side_stream.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
@@ -479,6 +524,7 @@ int ex4d_get_option(const char *name)
 {
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "acc_layout")) return 0;
+    if (name && !strcmp(name, "color_side_stream")) return g_side_stream.load();
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     return -1;

@@ -75,6 +75,9 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
     uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream);
 
+hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *means3D, const float *shs, const float *campos,
+    const int32_t *radii, GeomState g, ShSplit split, hipStream_t stream);
+
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);
 
