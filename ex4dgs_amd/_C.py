@@ -22,7 +22,8 @@ NUM_CHANNELS = 3   # cuda_rasterizer/config.h:15
 class Ex4dParams(C.Structure):
     _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
                 ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("kernel_size", C.c_float), ("scale_modifier", C.c_float),
-                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("prepare_backward", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GeomLayout(C.Structure):
@@ -160,8 +161,9 @@ def _require_rocm(t, name):
         raise RuntimeError(f"{name} is on {t.device}: the ex4dgs_amd rasterizer only runs on a ROCm GPU (no CPU fallback)")
 
 
-def _params(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug):
-    return Ex4dParams(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, int(bool(prefiltered)), int(bool(debug)))
+def _params(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug, prepare_backward=False):
+    return Ex4dParams(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, int(bool(prefiltered)), int(bool(debug)),
+                      int(bool(prepare_backward)), 0)
 
 
 def _resizer(t):
@@ -174,9 +176,11 @@ def _resizer(t):
 
 def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width,
-                        sh, degree, campos, prefiltered, min_depth, max_depth, debug):
+                        sh, degree, campos, prefiltered, min_depth, max_depth, debug, prepare_backward=False):
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-133): 24 positional arguments ->
-    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idx)."""
+    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idx).
+    prepare_backward (keyword, not in the reference): a backward will follow -- the forward clears the backward's accumulator rows
+    beside its binning chain (include/ex4d_rasterizer.h: Ex4dParams.prepare_backward); hand `prepared=True` to that backward."""
     lib = load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -219,7 +223,7 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos), ("subpixel_offset", subpixel_offset)):
         kt, ptr[name] = _dev_f32(t, name, dev)
         keep.append(kt)
-    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug)
+    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug, prepare_backward)
     cbs = [_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer)]
     num_rendered = C.c_int32(0)
     with torch.cuda.device(dev):
@@ -249,7 +253,7 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, acc_depth, acc, min_depth, max_depth,
                                  scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size,
                                  subpixel_offset, dL_dout_color, dL_dout_depth, dL_grad_out_flow, dL_grad_out_acc, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, need_colors=True, need_cov3D=True):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, need_colors=True, need_cov3D=True, prepared=False):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:135-234): 30 positional arguments ->
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dflow).
     need_colors / need_cov3D = False: that gradient is not written at all (the C ABI takes NULL) and comes back as an empty tensor --
@@ -298,8 +302,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         kt, ptr[name] = _dev_f32(t, name, dev)
         keep.append(kt)
     radii_c = radii.contiguous()
-    scratch = torch.empty(lib.ex4d_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
-    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, False, debug)
+    # prepared: the forward that produced the buffers already cleared the accumulator rows inside geomBuffer (first backward only)
+    scratch = None if prepared else torch.empty(lib.ex4d_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+    scratch_ptr = None if prepared else scratch.data_ptr()
+    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, False, debug, prepared)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
         if split is not None:
@@ -314,7 +320,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ptr["dL_dout_color"], ptr["dL_dout_depth"], ptr["dL_grad_out_flow"], ptr["dL_grad_out_acc"],
                 outs[0].data_ptr(), optr(outs[1]), outs[2].data_ptr(), outs[3].data_ptr(), optr(outs[4]),
                 C.byref(gst), outs[6].data_ptr(), outs[7].data_ptr(), outs[8].data_ptr(),
-                scratch.data_ptr(), C.c_void_p(stream))
+                scratch_ptr, C.c_void_p(stream))
             _check(code)
             rasterize_gaussians_backward.last_scratch = scratch
             return tuple(outs)
@@ -326,7 +332,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             ptr["dL_dout_color"], ptr["dL_dout_depth"], ptr["dL_grad_out_flow"], ptr["dL_grad_out_acc"],
             outs[0].data_ptr(), optr(outs[1]), outs[2].data_ptr(), outs[3].data_ptr(), optr(outs[4]),
             outs[5].data_ptr() if M > 0 else None, outs[6].data_ptr(), outs[7].data_ptr(), outs[8].data_ptr(),
-            scratch.data_ptr(), C.c_void_p(stream))
+            scratch_ptr, C.c_void_p(stream))
     _check(code)
     rasterize_gaussians_backward.last_scratch = scratch      # kept for parity tests (internal accumulators)
     return tuple(outs)

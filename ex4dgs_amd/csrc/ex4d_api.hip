@@ -122,7 +122,9 @@ struct SideStream {
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (ready && dev == device) return true;
         if (ready) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(stream); ready = false; }
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        int lo = 0, hi = 0;             // lowest priority: the binning chain on the caller's stream is the critical path
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, lo) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
         ready = true; device = dev;
@@ -163,6 +165,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
     g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-workgroup instance counts
     g.block_totals = c.take<uint32_t>((P + 255) / 256);
+    g.acc16 = c.take<float>(16 * (size_t)P);
     l.total = c.off;
     if (lay) *lay = l;
     if (total) *total = c.off;
@@ -221,7 +224,7 @@ ImgState carve_img(void *buf, int W, int H, Ex4dImgLayout *lay, size_t *total)
 extern "C" {
 
 const char *ex4d_last_error(void) { return g_err; }
-int ex4d_abi_version(void) { return 2; }
+int ex4d_abi_version(void) { return 3; }
 const char *ex4d_target_arch(void) { return "gfx950"; }
 
 size_t ex4d_geom_bytes(int32_t P) { size_t t; carve_geom(nullptr, P, nullptr, &t); return t; }
@@ -302,11 +305,12 @@ static int forward_impl(
         if (g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init()) {
             HIP_TRY(hipEventRecord(g_side.fork, stream));
             HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
-            HIP_TRY(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, g_side.stream));
+            HIP_TRY(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, true, g_side.stream));
+            if (prm->prepare_backward) HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), g_side.stream));
             HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
             color_on_side = true;
         } else {
-            STAGE(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, stream), prm, stream);
+            STAGE(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, false, stream), prm, stream);
             MARK(0, "preprocess_color");
         }
     }
@@ -373,6 +377,7 @@ static int forward_impl(
     }
     // 8. compositing (joins the colour kernel first)
     if (color_on_side) HIP_TRY(hipStreamWaitEvent(stream, g_side.join, 0));
+    else if (prm->prepare_backward) HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), stream));
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
                                     out_color, out_depth, out_acc, out_flow, out_idx, b.qlist, b.qcount, g.total, stream), prm, stream);
     MARK(0, "composite_fwd");
@@ -395,7 +400,7 @@ static int backward_impl(
     if (!prm) return fail(EX4D_ERR_ARG, "null params");
     const int P = prm->P, W = prm->W, H = prm->H;
     if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
-    if (!geom_buffer || !binning_buffer || !img_buffer || !bwd_scratch) return fail(EX4D_ERR_ARG, "null state buffer");
+    if (!geom_buffer || !binning_buffer || !img_buffer || (!bwd_scratch && !prm->prepare_backward)) return fail(EX4D_ERR_ARG, "null state buffer");
     if ((size_t)P * 64 > 0xFFFFFFFFull) return fail(EX4D_ERR_ARG, "more than 2^26 Gaussians: the accumulator rows are addressed with 32-bit byte offsets");
     // any of the four upstream gradients may be NULL (= zeros: that output is not part of the loss)
     if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
@@ -403,11 +408,12 @@ static int backward_impl(
     GeomState g = carve_geom((void *)geom_buffer, P, nullptr, nullptr);
     BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, W, H, nullptr, nullptr);
     ImgState im = carve_img((void *)img_buffer, W, H, nullptr, nullptr);
-    float *acc16 = (float *)bwd_scratch;
+    // accumulator rows: cleared by the forward that produced these buffers (prepare_backward) or here, in the caller's scratch
+    float *acc16 = prm->prepare_backward ? g.acc16 : (float *)bwd_scratch;
 
     const int variant = g_bwd_variant.load(std::memory_order_relaxed);
     g_prof.begin(1, stream);
-    HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+    if (!prm->prepare_backward) HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
     MARK(1, "zero_accumulators");
     // colours (SH or precomputed, rasterizer_impl.cu:426) already sit in the records
     if (num_rendered > 0)

@@ -34,6 +34,7 @@ struct GeomState {
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
     uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0
     uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
+    float *acc16;                                        // [P][16] accumulator rows of the backward, zeroed by the forward on request (Ex4dParams.prepare_backward)
 };
 struct BinState {
     uint32_t *point_list;     // final sorted Gaussian ids
@@ -76,7 +77,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream);
 
 hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *means3D, const float *shs, const float *campos,
-    const int32_t *radii, GeomState g, ShSplit split, hipStream_t stream);
+    const int32_t *radii, GeomState g, ShSplit split, bool persistent, hipStream_t stream);
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);

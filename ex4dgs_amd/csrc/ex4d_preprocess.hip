@@ -479,18 +479,20 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
 // return at once; writes the three colour floats of the 64-byte record and the clamp bits.
 __global__ __launch_bounds__(256) void preprocess_color_kernel(
     int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ shs, const float *__restrict__ campos,
-    const int32_t *__restrict__ radii, float4 *__restrict__ records, uint8_t *__restrict__ clamped, const ShSplit sp)
+    const int32_t *__restrict__ radii, float4 *__restrict__ records, uint8_t *__restrict__ clamped, const ShSplit sp, int nblocks)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // persistent workgroups (one per CU, see the launcher): block b of 256 Gaussians at a time; a wave is on its own (no barrier)
+    for (int block = blockIdx.x; block < nblocks; block += gridDim.x) {
+    const int idx = block * 256 + threadIdx.x;
     const bool in_range = idx < P;
     const bool visible = in_range && radii[idx] > 0;
-    if (__ballot(visible) == 0ull) return;                 // (no workgroup barrier in this kernel)
+    if (__ballot(visible) == 0ull) continue;
     const int ncoef = (D + 1) * (D + 1);
     const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
     const bool staged = (shs != nullptr || split) && (M == 16);
-    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int wave_first = block * 256 + wave * 64;
     const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
     ShPrefetch pf;
     bool prefetched = false;
@@ -601,6 +603,8 @@ __global__ __launch_bounds__(256) void preprocess_color_kernel(
         }
         float *rec2 = reinterpret_cast<float *>(records + 4 * (size_t)idx + 2);
         rec2[1] = res[0]; rec2[2] = res[1]; rec2[3] = res[2];
+    }
+    wave_sync_lds();               // the slice is reused by the wave's next block
     }
 }
 
@@ -1015,10 +1019,17 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
 
 // SH -> RGB of the visible Gaussians into the records (nothing to do for precomputed colours: the geometry kernel copied them)
 hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *means3D, const float *shs, const float *campos,
-    const int32_t *radii, GeomState g, ShSplit split, hipStream_t stream)
+    const int32_t *radii, GeomState g, ShSplit split, bool persistent, hipStream_t stream)
 {
-    hipLaunchKernelGGL(preprocess_color_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, shs, campos, radii, g.records, g.clamped, split);
+    const int nblocks = (prm.P + 255) / 256;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int grid = persistent ? (nblocks < cus ? nblocks : cus) : nblocks;
+    hipLaunchKernelGGL(preprocess_color_kernel, dim3(grid), dim3(256), 0, stream,
+        prm.P, prm.D, prm.M, means3D, shs, campos, radii, g.records, g.clamped, split, nblocks);
     return hipGetLastError();
 }
 

@@ -198,7 +198,7 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
     Ex4dParams prm;
     prm.P = t->P; prm.D = c.sh_degree; prm.M = 16; prm.W = c.W; prm.H = c.H; prm.tanfovx = c.tanfovx; prm.tanfovy = c.tanfovy;
     prm.kernel_size = c.kernel_size; prm.scale_modifier = 1.0f; prm.min_depth = c.min_depth; prm.max_depth = c.max_depth;
-    prm.prefiltered = 0; prm.debug = 0;
+    prm.prefiltered = 0; prm.debug = 0; prm.prepare_backward = 1; prm.reserved = 0;
     Ex4dSplitSH sh;
     sh.dc[0] = p[5]; sh.rest[0] = p[6]; sh.dc[1] = p[13]; sh.rest[1] = p[14]; sh.n_static = c.Ns;
     int32_t R = 0;

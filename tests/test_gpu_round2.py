@@ -466,3 +466,30 @@ def test_compacted_quadrant_lists_left_for_the_backward(hip_lib):
             # the deepest contributor itself is a survivor of its quadrant's cull, so it is in the list
             assert deepest == 0 or (qn > 0 and (ent[:, 1] == deepest - 1).any()), (t, q, deepest)
     assert 0 < total < 4 * g["num_rendered"]
+
+
+def test_accumulators_prepared_by_the_forward_and_second_backward(hip_lib):
+    """Ex4dParams.prepare_backward: under autograd the forward clears the backward's accumulator rows (inside the geometry buffer, on its
+    side stream); the first backward consumes them, a second backward through a retained graph clears its own scratch.  Both give the
+    gradients of the plain path (raw `_C` call with its own scratch) up to the order of the float atomics."""
+    from ex4dgs_amd.diff_gaussian_rasterization_df import rasterize_gaussians
+    ins, st = h.scene_inputs("cfg3", P=9000, dir_scale=0.0)
+    s = h.gpu_settings(st, "cuda")
+    leaves = {k: ins[k].cuda().requires_grad_(True) for k in ("means3D", "dir3D", "shs", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    e = torch.Tensor([])
+    color, radii, depth, flow, acc, idx = rasterize_gaussians(leaves["means3D"], means2D, leaves["dir3D"], leaves["shs"], e, leaves["opacities"],
+                                                            leaves["scales"], leaves["rotations"], e, s)
+    H, W = st["image_height"], st["image_width"]
+    grads = [x.cuda() for x in h.upstream_grads(acc.detach().cpu(), H, W, seed=4)]
+    names = list(leaves)
+    first = torch.autograd.grad([color, depth, flow, acc], [leaves[n] for n in names] + [means2D], grads, retain_graph=True)
+    second = torch.autograd.grad([color, depth, flow, acc], [leaves[n] for n in names] + [means2D], grads)
+    g = h.gpu_forward_raw(ins, st)
+    raw = h.gpu_backward_raw(ins, g, grads)
+    ref = dict(means3D=raw["dL_dmeans3D"], dir3D=raw["dL_ddir"], shs=raw["dL_dsh"], opacities=raw["dL_dopacity"], scales=raw["dL_dscales"],
+               rotations=raw["dL_drotations"])
+    for n, a, b in zip(names + ["means2D"], first, second):
+        r = ref[n] if n != "means2D" else raw["dL_dmeans2D"]
+        scale = max(1.0, float(r.abs().max()))
+        assert float((a - r).abs().max()) <= 1e-5 * scale and float((b - r).abs().max()) <= 1e-5 * scale, n
