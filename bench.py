@@ -319,6 +319,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--color-wgs", type=int, default=None, help="tuning: persistent workgroups per CU of the colour kernel")
+    ap.add_argument("--color-fork", type=int, default=None, help="tuning: 0 = colour kernel forks behind the geometry kernel, 1 = behind the tile scan")
     ap.add_argument("--no-side-stream", action="store_true", help="tuning: run the SH colour kernel in line instead of beside the binning chain")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     args = ap.parse_args()
@@ -343,6 +345,10 @@ def main():
         _C.set_option("composite_bwd_variant", args.bwd_variant)
     if args.no_side_stream:
         _C.set_option("color_side_stream", 0)
+    if args.color_wgs is not None:
+        _C.set_option("color_wgs_per_cu", args.color_wgs)
+    if args.color_fork is not None:
+        _C.set_option("color_fork", args.color_fork)
 
     cfg = CONFIGS[args.config]
     train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only

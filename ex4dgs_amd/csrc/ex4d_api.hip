@@ -133,6 +133,8 @@ struct SideStream {
 };
 thread_local SideStream g_side;
 std::atomic<int> g_side_stream{1};    // "color_side_stream": 0 = the colour kernel runs in line on the caller's stream
+std::atomic<int> g_color_wgs{2};      // "color_wgs_per_cu": persistent workgroups per CU of the colour kernel on the side stream
+std::atomic<int> g_color_fork{1};     // "color_fork": 0 = fork behind the geometry kernel, 1 = behind the tile scan
 
 struct Carver {
     char *base; size_t off;
@@ -166,6 +168,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-workgroup instance counts
     g.block_totals = c.take<uint32_t>((P + 255) / 256);
     g.acc16 = c.take<float>(16 * (size_t)P);
+    g.sh_dsums = c.take<float>(9 * (size_t)P);
     l.total = c.off;
     if (lay) *lay = l;
     if (total) *total = c.off;
@@ -298,22 +301,27 @@ static int forward_impl(
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
                                      keys0, vals0, key_base, key_invisible, stream), prm, stream);
     MARK(0, "preprocess_fwd");
-    // SH -> RGB: only the compositing kernels read the colours, so the kernel runs on the side stream beside the binning chain below
+    // SH -> RGB: only the compositing kernels read the colours, so the kernel runs on the side stream beside the binning chain below.
+    // Where it forks matters: beside the depth sort (nine launches of 5-13 us, each a chain of dependent memory round trips) it
+    // cost that chain as much as it saved (measured: depth sort 74 -> 120 us); it is started behind the tile scan and runs beside
+    // the duplication and the tile sort, whose kernels are large enough to share the machine.
     const bool has_sh = shs != nullptr || is_split;
     bool color_on_side = false;
-    if (has_sh) {
-        if (g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init()) {
-            HIP_TRY(hipEventRecord(g_side.fork, stream));
-            HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
-            HIP_TRY(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, true, g_side.stream));
-            if (prm->prepare_backward) HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), g_side.stream));
-            HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
-            color_on_side = true;
-        } else {
-            STAGE(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, false, stream), prm, stream);
-            MARK(0, "preprocess_color");
-        }
+    const bool use_side = has_sh && g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init();
+    auto fork_color = [&]() -> int {
+        HIP_TRY(hipEventRecord(g_side.fork, stream));
+        HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
+        HIP_TRY(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, g_color_wgs.load(std::memory_order_relaxed), g_side.stream));
+        if (prm->prepare_backward) HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), g_side.stream));
+        HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
+        color_on_side = true;
+        return EX4D_OK;
+    };
+    if (has_sh && !use_side) {
+        STAGE(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, 0, stream), prm, stream);
+        MARK(0, "preprocess_color");
     }
+    if (use_side && g_color_fork.load(std::memory_order_relaxed) == 0) { const int rc = fork_color(); if (rc) return rc; }
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
     // (g.total[0..63] and the per-workgroup counts are adjacent in the geometry buffer: one copy)
@@ -330,6 +338,7 @@ static int forward_impl(
     // 3. instance offsets in depth order + total
     STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, stream), prm, stream);
     MARK(0, "scan_tiles");
+    if (use_side && !color_on_side) { const int rc = fork_color(); if (rc) return rc; }
     // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
     HIP_TRY(hipEventSynchronize(g_readback.ev));
     uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
@@ -519,6 +528,8 @@ int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "color_side_stream") && (value == 0 || value == 1)) { g_side_stream.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "color_wgs_per_cu") && value >= 0 && value <= 16) { g_color_wgs.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "color_fork") && (value == 0 || value == 1)) { g_color_fork.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");

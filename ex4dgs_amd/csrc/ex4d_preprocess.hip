@@ -471,6 +471,59 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
     if (threadIdx.x == 0) total_instances[blockIdx.x] = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
 }
 
+// d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): the part that reads the SH VALUES (sh[3 k + ch], k >= 1).
+// One inlined function, so that every caller reads through its own address space (LDS slice or global row).
+__device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float x, float y, float z,
+                                                  float (&dRGBdx)[3], float (&dRGBdy)[3], float (&dRGBdz)[3])
+{
+#define SHK(k) sh[3 * (k) + ch]
+    if (D > 0) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dRGBdx[ch] = -kSH_C1 * SHK(3);
+            dRGBdy[ch] = -kSH_C1 * SHK(1);
+            dRGBdz[ch] = kSH_C1 * SHK(2);
+        }
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
+                dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
+                dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
+            }
+            if (D > 2) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] += (
+                        kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
+                        kSH_C3[1] * SHK(10) * yz +
+                        kSH_C3[2] * SHK(11) * -2.f * xy +
+                        kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
+                        kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
+                        kSH_C3[5] * SHK(14) * 2.f * xz +
+                        kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
+                    dRGBdy[ch] += (
+                        kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
+                        kSH_C3[1] * SHK(10) * xz +
+                        kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
+                        kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
+                        kSH_C3[4] * SHK(13) * -2.f * xy +
+                        kSH_C3[5] * SHK(14) * -2.f * yz +
+                        kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
+                    dRGBdz[ch] += (
+                        kSH_C3[1] * SHK(10) * xy +
+                        kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
+                        kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
+                        kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
+                        kSH_C3[5] * SHK(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SHK
+}
+
 // SH -> RGB (CR/forward.cu:20-71) of the VISIBLE Gaussians, in its own kernel (round 3).  It only feeds the compositing kernels, so it
 // runs on a second stream beside the whole binning chain (depth sort, scan, duplication, tile sort: ~0.2 ms of small launch- and
 // latency-bound kernels that leave the memory system idle), instead of in front of it inside the per-Gaussian kernel, where its 12 KB
@@ -479,7 +532,8 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
 // return at once; writes the three colour floats of the 64-byte record and the clamp bits.
 __global__ __launch_bounds__(256) void preprocess_color_kernel(
     int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ shs, const float *__restrict__ campos,
-    const int32_t *__restrict__ radii, float4 *__restrict__ records, uint8_t *__restrict__ clamped, const ShSplit sp, int nblocks)
+    const int32_t *__restrict__ radii, float4 *__restrict__ records, uint8_t *__restrict__ clamped, const ShSplit sp, int nblocks,
+    float *__restrict__ sh_dsums)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -603,62 +657,21 @@ __global__ __launch_bounds__(256) void preprocess_color_kernel(
         }
         float *rec2 = reinterpret_cast<float *>(records + 4 * (size_t)idx + 2);
         rec2[1] = res[0]; rec2[2] = res[1]; rec2[3] = res[2];
+        if (sh_dsums) {
+            // d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): they depend on the SH values and the direction
+            // only, both in registers here -- stored (36 B per visible Gaussian) so that the backward does not read the 192-byte SH
+            // rows again.  Same function, same operands as the backward used: identical bits.
+            const float len = sqrtf((p.x - campos[0]) * (p.x - campos[0]) + (p.y - campos[1]) * (p.y - campos[1]) + (p.z - campos[2]) * (p.z - campos[2]));
+            const float x = (p.x - campos[0]) / len, y = (p.y - campos[1]) / len, z = (p.z - campos[2]) / len;
+            float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+            sh_direction_sums(&coefv[0][0], D, x, y, z, dRGBdx, dRGBdy, dRGBdz);
+            float *o = sh_dsums + 9 * (size_t)idx;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { o[ch] = dRGBdx[ch]; o[3 + ch] = dRGBdy[ch]; o[6 + ch] = dRGBdz[ch]; }
+        }
     }
     wave_sync_lds();               // the slice is reused by the wave's next block
     }
-}
-
-// d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): the part that reads the SH VALUES (sh[3 k + ch], k >= 1).
-// One inlined function, so that every caller reads through its own address space (LDS slice or global row).
-__device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float x, float y, float z,
-                                                  float (&dRGBdx)[3], float (&dRGBdy)[3], float (&dRGBdz)[3])
-{
-#define SHK(k) sh[3 * (k) + ch]
-    if (D > 0) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            dRGBdx[ch] = -kSH_C1 * SHK(3);
-            dRGBdy[ch] = -kSH_C1 * SHK(1);
-            dRGBdz[ch] = kSH_C1 * SHK(2);
-        }
-        if (D > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
-                dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
-                dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
-            }
-            if (D > 2) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    dRGBdx[ch] += (
-                        kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
-                        kSH_C3[1] * SHK(10) * yz +
-                        kSH_C3[2] * SHK(11) * -2.f * xy +
-                        kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
-                        kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
-                        kSH_C3[5] * SHK(14) * 2.f * xz +
-                        kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
-                    dRGBdy[ch] += (
-                        kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
-                        kSH_C3[1] * SHK(10) * xz +
-                        kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
-                        kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
-                        kSH_C3[4] * SHK(13) * -2.f * xy +
-                        kSH_C3[5] * SHK(14) * -2.f * yz +
-                        kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
-                    dRGBdz[ch] += (
-                        kSH_C3[1] * SHK(10) * xy +
-                        kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
-                        kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
-                        kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
-                        kSH_C3[5] * SHK(14) * (xx - yy));
-                }
-            }
-        }
-    }
-#undef SHK
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -685,6 +698,9 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *_
 //             sG = dL_dG G and d = mean2D - pixel; rest as layout 0.  dG/dmean2D = -G (A dx + B dy, C dy + B dx) (CR/backward.cu:
 //             :664-670), dG/dconic = -1/2 G (dx^2, dx dy, dy^2) (:673-675): linear in those sums, conic (A, B, C) from the record.
 // ------------------------------------------------------------------------------------------------
+// DSUMS = true: the forward's colour kernel left the SH direction sums (GeomState::sh_dsums, Ex4dParams.prepare_backward): the SH
+// rows are not read at all (-155 MB of 535 at 1.0 M Gaussians), the staging slice only serves the coalesced stores
+template <bool DSUMS>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const int32_t *__restrict__ radii, const float *__restrict__ shs,
@@ -695,7 +711,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const float *__restrict__ acc16, const float4 *__restrict__ records,
     float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
-    float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir, const ShSplit sp, const ShSplitGrad gsp)
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir, const ShSplit sp, const ShSplitGrad gsp,
+    const float *__restrict__ sh_dsums)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -756,7 +773,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
         const int r = lane & 31;
         const uint64_t need_rows = __ballot(visible);
-        if (staged && prefetched) {
+        if (DSUMS) {
+            if (visible) {
+                const float *o = sh_dsums + 9 * (size_t)idx;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { dRGBdx[ch] = o[ch]; dRGBdy[ch] = o[3 + ch]; dRGBdz[ch] = o[6 + ch]; }
+            }
+        } else if (staged && prefetched) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (split) wave_load_sh_split_half(sp, wave_first, lds_row_base, lane, h, need_rows);
@@ -1019,7 +1042,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
 
 // SH -> RGB of the visible Gaussians into the records (nothing to do for precomputed colours: the geometry kernel copied them)
 hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *means3D, const float *shs, const float *campos,
-    const int32_t *radii, GeomState g, ShSplit split, bool persistent, hipStream_t stream)
+    const int32_t *radii, GeomState g, ShSplit split, int wgs_per_cu, hipStream_t stream)
 {
     const int nblocks = (prm.P + 255) / 256;
     static int cus = 0;
@@ -1027,9 +1050,10 @@ hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *mean
         int dev = 0; hipDeviceProp_t prop;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    const int grid = persistent ? (nblocks < cus ? nblocks : cus) : nblocks;
+    // wgs_per_cu > 0: persistent workgroups (the kernel runs in the background of the binning chain); 0: one workgroup per block
+    const int grid = (wgs_per_cu > 0 && nblocks > wgs_per_cu * cus) ? wgs_per_cu * cus : nblocks;
     hipLaunchKernelGGL(preprocess_color_kernel, dim3(grid), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, shs, campos, radii, g.records, g.clamped, split, nblocks);
+        prm.P, prm.D, prm.M, means3D, shs, campos, radii, g.records, g.clamped, split, nblocks, prm.prepare_backward ? g.sh_dsums : (float *)nullptr);
     return hipGetLastError();
 }
 
@@ -1049,9 +1073,14 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:417-418
     const float fx = prm.W / (2.0f * prm.tanfovx);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, radii, shs, g.clamped, scales, rotations, prm.scale_modifier, cov3D_ptr,
-        viewmatrix, projmatrix, campos, prm.W, prm.H, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16, g.records,
-        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir, split, gsplit);
+#define PB_ARGS prm.P, prm.D, prm.M, means3D, radii, shs, g.clamped, scales, rotations, prm.scale_modifier, cov3D_ptr, \
+        viewmatrix, projmatrix, campos, prm.W, prm.H, fx, fy, prm.tanfovx, prm.tanfovy, prm.kernel_size, acc16, g.records, \
+        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir, split, gsplit
+    const bool has_sh = shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr;
+    if (prm.prepare_backward && has_sh)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PB_ARGS, (const float *)g.sh_dsums);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PB_ARGS, (const float *)nullptr);
+#undef PB_ARGS
     return hipGetLastError();
 }
