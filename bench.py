@@ -34,7 +34,18 @@ from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSetti
 from ex4dgs_amd.scene import CONFIGS, make_scene                                   # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+
+
+def pmc_counters_current(pmc):
+    """The committed counter file is only quoted while every kernel source still has the hash it was collected from."""
+    import hashlib
+    want = pmc.get("source_sha16")
+    if not want:
+        return False
+    d = os.path.join(ROOT, "ex4dgs_amd", "csrc")
+    have = {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))}
+    return have == want
 
 
 def frame_inputs(model, t, device):
@@ -319,9 +330,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--color-wgs", type=int, default=None, help="tuning: persistent workgroups per CU of the colour kernel")
-    ap.add_argument("--color-fork", type=int, default=None, help="tuning: 0 = colour kernel forks behind the geometry kernel, 1 = behind the tile scan")
-    ap.add_argument("--no-side-stream", action="store_true", help="tuning: run the SH colour kernel in line instead of beside the binning chain")
+    ap.add_argument("--no-side-stream", action="store_true", help="tuning: clear the backward's accumulators in line instead of beside the compositing forward")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     args = ap.parse_args()
 
@@ -344,11 +353,7 @@ def main():
     if args.bwd_variant is not None:
         _C.set_option("composite_bwd_variant", args.bwd_variant)
     if args.no_side_stream:
-        _C.set_option("color_side_stream", 0)
-    if args.color_wgs is not None:
-        _C.set_option("color_wgs_per_cu", args.color_wgs)
-    if args.color_fork is not None:
-        _C.set_option("color_fork", args.color_fork)
+        _C.set_option("side_stream", 0)
 
     cfg = CONFIGS[args.config]
     train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only
@@ -504,16 +509,19 @@ def main():
     try:   # HBM bytes per launch from the rocprofv3 --pmc passes of this command, collected separately and committed (tools/pmc.sh)
         with open(os.path.join(ROOT, PMC_FILE)) as fh:
             pmc = json.load(fh)
-        if args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
+        pmc_ok = pmc_counters_current(pmc)
+        if pmc_ok and args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
             valu_busy = pmc["kernels"][dom].get("valu_busy_frac")
     except Exception:
-        traffic = None
+        traffic, pmc_ok = None, False
     if dom is not None and dom_bytes:
         achieved = dom_bytes / (agg[dom] * 1e-3) / 1e9
         rast_ms = ms_per_step if not train_mode else kernel_ms
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": PMC_FILE + " (separate rocprofv3 --pmc passes of this command, committed; not re-measured in this run)",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": (PMC_FILE + " (separate rocprofv3 --pmc passes of this command, committed with the hashes of the kernel sources; not re-measured in this run)")
+                                  if traffic is not None else (PMC_FILE + " is missing or was collected from other kernel sources (hash mismatch): no counter figure is quoted"),
                 "kernel_ms": round(agg[dom], 4), "algorithmic_bytes": int(dom_bytes),
                 # the kernel the contract prices against HBM is VALU-issue bound in practice: SQ counters of the committed PMC pass
                 "valu_busy_frac_pmc": valu_busy,

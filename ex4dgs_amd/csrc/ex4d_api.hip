@@ -108,9 +108,9 @@ struct Readback {
 };
 thread_local Readback g_readback;
 
-// Second stream + two events per host thread and device: work that only the compositing kernels need (the SH colours) runs beside the
-// binning chain of the caller's stream -- fork after the geometry kernel, join in front of the compositing forward.  Created on first
-// use; never destroyed (the process owns a handful of them).
+// Second stream + two events per host thread and device: work nobody on the caller's stream waits for yet (clearing the backward's
+// accumulator rows) runs beside a kernel that leaves the memory system idle -- fork in front of the compositing forward, join behind
+// it.  Created on first use; never destroyed (the process owns a handful of them).
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork, join;
@@ -132,9 +132,7 @@ struct SideStream {
     }
 };
 thread_local SideStream g_side;
-std::atomic<int> g_side_stream{1};    // "color_side_stream": 0 = the colour kernel runs in line on the caller's stream
-std::atomic<int> g_color_wgs{2};      // "color_wgs_per_cu": persistent workgroups per CU of the colour kernel on the side stream
-std::atomic<int> g_color_fork{1};     // "color_fork": 0 = fork behind the geometry kernel, 1 = behind the tile scan
+std::atomic<int> g_side_stream{1};    // "side_stream": 0 = everything in line on the caller's stream
 
 struct Carver {
     char *base; size_t off;
@@ -301,27 +299,6 @@ static int forward_impl(
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
                                      keys0, vals0, key_base, key_invisible, stream), prm, stream);
     MARK(0, "preprocess_fwd");
-    // SH -> RGB: only the compositing kernels read the colours, so the kernel runs on the side stream beside the binning chain below.
-    // Where it forks matters: beside the depth sort (nine launches of 5-13 us, each a chain of dependent memory round trips) it
-    // cost that chain as much as it saved (measured: depth sort 74 -> 120 us); it is started behind the tile scan and runs beside
-    // the duplication and the tile sort, whose kernels are large enough to share the machine.
-    const bool has_sh = shs != nullptr || is_split;
-    bool color_on_side = false;
-    const bool use_side = has_sh && g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init();
-    auto fork_color = [&]() -> int {
-        HIP_TRY(hipEventRecord(g_side.fork, stream));
-        HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
-        HIP_TRY(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, g_color_wgs.load(std::memory_order_relaxed), g_side.stream));
-        if (prm->prepare_backward) HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), g_side.stream));
-        HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
-        color_on_side = true;
-        return EX4D_OK;
-    };
-    if (has_sh && !use_side) {
-        STAGE(ex4d_launch_preprocess_color(*prm, means3D, shs, campos, radii, g, split, 0, stream), prm, stream);
-        MARK(0, "preprocess_color");
-    }
-    if (use_side && g_color_fork.load(std::memory_order_relaxed) == 0) { const int rc = fork_color(); if (rc) return rc; }
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
     // (g.total[0..63] and the per-workgroup counts are adjacent in the geometry buffer: one copy)
@@ -338,24 +315,19 @@ static int forward_impl(
     // 3. instance offsets in depth order + total
     STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, stream), prm, stream);
     MARK(0, "scan_tiles");
-    if (use_side && !color_on_side) { const int rc = fork_color(); if (rc) return rc; }
     // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
     HIP_TRY(hipEventSynchronize(g_readback.ev));
     uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
     for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
     const uint32_t host_total[2] = { instance_sum, g_readback.host[1] };
-    // (error exits behind the fork first make the caller's stream wait for the colour kernel: it writes into the caller's buffers)
-    auto join_side = [&]() { if (color_on_side) (void)hipStreamWaitEvent(stream, g_side.join, 0); };
-    if (prm->prefiltered && host_total[1]) {
-        join_side();
+    if (prm->prefiltered && host_total[1])
         return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    }
     const uint32_t R = host_total[0];
-    if (R > 0x7FFFFFFFu) { join_side(); return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances"); }
+    if (R > 0x7FFFFFFFu) return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances");
     *num_rendered = (int32_t)R;
 
     void *bin_buf = binning_alloc(binning_user, ex4d_binning_bytes((int32_t)R, W, H));
-    if (!bin_buf) { join_side(); return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed"); }
+    if (!bin_buf) return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed");
     BinState b = carve_binning(bin_buf, R, W, H, nullptr, nullptr);
 
     // 5. emit (tile, id) instances in depth order, 6. stable sort by tile, 7. ranges
@@ -384,12 +356,27 @@ static int forward_impl(
         STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
         MARK(0, "tile_ranges");
     }
-    // 8. compositing (joins the colour kernel first)
-    if (color_on_side) HIP_TRY(hipStreamWaitEvent(stream, g_side.join, 0));
-    else if (prm->prepare_backward) HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+    // 8. compositing.  With prepare_backward the backward's accumulator rows (64 B per Gaussian) are cleared here, on the side stream,
+    // BESIDE the compositing kernel: that kernel is bound by VALU issue and leaves the memory system idle, the fill is pure HBM
+    // traffic -- and the backward no longer starts with a 12 us memset on its critical path.  (Measured alternatives, round 3: the SH
+    // colour evaluation as its own kernel on this stream beside the depth sort or beside the tile sort delayed whichever chain of
+    // small kernels it ran beside by about its own duration -- no gain over the fused per-Gaussian kernel)
+    bool forked = false;
+    if (prm->prepare_backward) {
+        if (g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init()) {
+            HIP_TRY(hipEventRecord(g_side.fork, stream));
+            HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
+            HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), g_side.stream));
+            HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
+            forked = true;
+        } else {
+            HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+        }
+    }
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
                                     out_color, out_depth, out_acc, out_flow, out_idx, b.qlist, b.qcount, g.total, stream), prm, stream);
     MARK(0, "composite_fwd");
+    if (forked) HIP_TRY(hipStreamWaitEvent(stream, g_side.join, 0));       // whatever the caller enqueues next sees cleared accumulators
     return EX4D_OK;
 }
 
@@ -527,9 +514,7 @@ int ex4d_backward_split_sh(
 int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "color_side_stream") && (value == 0 || value == 1)) { g_side_stream.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "color_wgs_per_cu") && value >= 0 && value <= 16) { g_color_wgs.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "color_fork") && (value == 0 || value == 1)) { g_color_fork.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "side_stream") && (value == 0 || value == 1)) { g_side_stream.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
@@ -541,7 +526,7 @@ int ex4d_get_option(const char *name)
 {
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "acc_layout")) return 0;
-    if (name && !strcmp(name, "color_side_stream")) return g_side_stream.load();
+    if (name && !strcmp(name, "side_stream")) return g_side_stream.load();
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     return -1;

@@ -35,7 +35,7 @@ struct GeomState {
     uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0
     uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
     float *acc16;                                        // [P][16] accumulator rows of the backward, zeroed by the forward on request (Ex4dParams.prepare_backward)
-    float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the colour kernel on the same request
+    float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on the same request
 };
 struct BinState {
     uint32_t *point_list;     // final sorted Gaussian ids
@@ -76,9 +76,6 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
     uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream);
-
-hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *means3D, const float *shs, const float *campos,
-    const int32_t *radii, GeomState g, ShSplit split, int wgs_per_cu, hipStream_t stream);
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);

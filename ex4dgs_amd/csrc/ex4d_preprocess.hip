@@ -329,7 +329,60 @@ __device__ __forceinline__ void wave_store_sh_half(float *__restrict__ dst_half,
 
 
 
-__global__ __launch_bounds__(256) void preprocess_geom_kernel(
+// d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): the part that reads the SH VALUES (sh[3 k + ch], k >= 1).
+// One inlined function, so that every caller reads through its own address space (LDS slice or global row).
+__device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float x, float y, float z,
+                                                  float (&dRGBdx)[3], float (&dRGBdy)[3], float (&dRGBdz)[3])
+{
+#define SHK(k) sh[3 * (k) + ch]
+    if (D > 0) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dRGBdx[ch] = -kSH_C1 * SHK(3);
+            dRGBdy[ch] = -kSH_C1 * SHK(1);
+            dRGBdz[ch] = kSH_C1 * SHK(2);
+        }
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
+                dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
+                dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
+            }
+            if (D > 2) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] += (
+                        kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
+                        kSH_C3[1] * SHK(10) * yz +
+                        kSH_C3[2] * SHK(11) * -2.f * xy +
+                        kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
+                        kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
+                        kSH_C3[5] * SHK(14) * 2.f * xz +
+                        kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
+                    dRGBdy[ch] += (
+                        kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
+                        kSH_C3[1] * SHK(10) * xz +
+                        kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
+                        kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
+                        kSH_C3[4] * SHK(13) * -2.f * xy +
+                        kSH_C3[5] * SHK(14) * -2.f * yz +
+                        kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
+                    dRGBdz[ch] += (
+                        kSH_C3[1] * SHK(10) * xy +
+                        kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
+                        kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
+                        kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
+                        kSH_C3[5] * SHK(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SHK
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
@@ -340,9 +393,9 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
-    uint32_t *__restrict__ total_instances, const ShSplit sp)
+    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums)
 {
-    (void)shs; (void)clamped; (void)M; (void)D; (void)campos; (void)sp;
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_range = idx < P;
@@ -351,7 +404,20 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
 #pragma unroll
     for (int i = 0; i < 16; i++) { vm[i] = viewmatrix[i]; pm[i] = projmatrix[i]; }
 
-    // ---- every global load of the kernel is issued here, before any arithmetic depends on one of them
+    // ---- every global load of the kernel is issued here, before any arithmetic depends on one of them: the wave's SH block (the
+    // bulk: 12 KB, coalesced), the Gaussian's own 12 + 32 + 12 bytes.  Culled Gaussians (~20 %) cost their bytes but no wave waits
+    // for a second or third memory round trip any more.
+    const int ncoef = (D + 1) * (D + 1);
+    const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
+    const bool staged = (shs != nullptr || split) && (M == 16);
+    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
+    ShPrefetch pf;
+    bool prefetched = false;
+    if (staged) {
+        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane);
+        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, (ncoef * 3 + 3) / 4, lane); prefetched = true; }
+    }
     float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
     float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f, in_op = 0.f, in_d0 = 0.f, in_d1 = 0.f, in_d2 = 0.f;
     if (in_range) {
@@ -361,6 +427,14 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
         }
         in_op = opacities[idx];
         if (dir3D) { in_d0 = dir3D[3 * (size_t)idx]; in_d1 = dir3D[3 * (size_t)idx + 1]; in_d2 = dir3D[3 * (size_t)idx + 2]; }
+    }
+
+    // rows 0..31 go to the LDS half-slice right away (their 26 staging registers are free during the projection arithmetic; rows
+    // 32..63 stay in registers until the first half has been consumed): peak register pressure = arithmetic + half a block
+    if (staged && prefetched) {
+        float *lds0 = sh_lds + wave * SH_HALF_FLOATS;
+        if (split) wave_commit_sh_split_half(lds0, pf, lane, 0);
+        else wave_commit_sh_half(lds0, pf, lane, 0);
     }
 
     int out_radius = 0;
@@ -425,142 +499,6 @@ __global__ __launch_bounds__(256) void preprocess_geom_kernel(
         depth_key = __float_as_uint(p_view.z) - depth_key_base;
     } while (0);
 
-    if (visible) {
-        float res[3] = { 0.f, 0.f, 0.f };      // SH colour: written by preprocess_color_kernel (its own kernel, its own stream)
-        if (colors_precomp) {
-            res[0] = colors_precomp[3 * (size_t)idx]; res[1] = colors_precomp[3 * (size_t)idx + 1]; res[2] = colors_precomp[3 * (size_t)idx + 2];
-        }
-        // per-Gaussian constants of the compositing kernels' quadrant cull (ex4d_composite.hip), evaluated once here
-        // instead of once per (Gaussian, tile, quadrant): tau = ln(255 w) + 1 % slack is the largest value of the quadratic
-        // form q(d) that still reaches alpha >= 1/255; -inf = never contributes (w < 1/255), +inf = never cull (conic
-        // not provably positive definite); k1, k2 = minimisers of q along a vertical / horizontal box edge
-        const float w_op = in_op * coef;
-        float tau;
-        if (w_op < (1.0f / 255.0f)) tau = -__builtin_inff();
-        else if (!(conic.x > 0.f && conic.z > 0.f && conic.x * conic.z - conic.y * conic.y > 0.f)) tau = __builtin_inff();
-        else tau = logf(255.0f * w_op) + 0.01f;
-        float4 *rec = records + 4 * (size_t)idx;
-        rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
-        rec[1] = make_float4(conic.z, tau, -conic.y / conic.z, -conic.y / conic.x);
-        rec[2] = make_float4(depth, res[0], res[1], res[2]);
-        rec[3] = make_float4(in_d0, in_d1, in_d2, w_op);
-    }
-    // frame flag for the compositing forward: does any visible Gaussian carry a flow vector?  (plain store of the same value by every
-    // wave that sees one: no atomic, no contention; the training loop's dir3D is the all-zero gradient trap and never sets it)
-    if (__ballot(visible && (in_d0 != 0.f || in_d1 != 0.f || in_d2 != 0.f)) != 0ull) {
-        if (lane == 0) prefilter_violation[1] = 1u;
-    }
-    if (in_range) {
-        radii[idx] = out_radius;
-        if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
-        rects[idx] = rect;
-        depth_keys[idx] = depth_key;
-        depth_vals[idx] = (uint32_t)idx;
-    }
-    // number of tile instances (the reference's num_rendered = last element of the inclusive scan,
-    // CR/rasterizer_impl.cu:295-299): it does not depend on the depth order, so it is summed here and read back by the
-    // host WHILE the depth sort runs -- the blocking read-back no longer leaves the GPU idle.
-    // (one plain store per workgroup; the host adds the few thousand partial sums -- a single atomic counter would
-    // serialise ~12 ns per arrival)
-    __shared__ uint32_t wave_totals[4];
-    uint32_t wave_sum = out_tiles;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wave_sum += __shfl_xor(wave_sum, o, 64);
-    if (lane == 0) wave_totals[wave] = wave_sum;
-    __syncthreads();
-    if (threadIdx.x == 0) total_instances[blockIdx.x] = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
-}
-
-// d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): the part that reads the SH VALUES (sh[3 k + ch], k >= 1).
-// One inlined function, so that every caller reads through its own address space (LDS slice or global row).
-__device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float x, float y, float z,
-                                                  float (&dRGBdx)[3], float (&dRGBdy)[3], float (&dRGBdz)[3])
-{
-#define SHK(k) sh[3 * (k) + ch]
-    if (D > 0) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            dRGBdx[ch] = -kSH_C1 * SHK(3);
-            dRGBdy[ch] = -kSH_C1 * SHK(1);
-            dRGBdz[ch] = kSH_C1 * SHK(2);
-        }
-        if (D > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                dRGBdx[ch] += kSH_C2[0] * y * SHK(4) + kSH_C2[2] * 2.f * -x * SHK(6) + kSH_C2[3] * z * SHK(7) + kSH_C2[4] * 2.f * x * SHK(8);
-                dRGBdy[ch] += kSH_C2[0] * x * SHK(4) + kSH_C2[1] * z * SHK(5) + kSH_C2[2] * 2.f * -y * SHK(6) + kSH_C2[4] * 2.f * -y * SHK(8);
-                dRGBdz[ch] += kSH_C2[1] * y * SHK(5) + kSH_C2[2] * 2.f * 2.f * z * SHK(6) + kSH_C2[3] * x * SHK(7);
-            }
-            if (D > 2) {
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    dRGBdx[ch] += (
-                        kSH_C3[0] * SHK(9) * 3.f * 2.f * xy +
-                        kSH_C3[1] * SHK(10) * yz +
-                        kSH_C3[2] * SHK(11) * -2.f * xy +
-                        kSH_C3[3] * SHK(12) * -3.f * 2.f * xz +
-                        kSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
-                        kSH_C3[5] * SHK(14) * 2.f * xz +
-                        kSH_C3[6] * SHK(15) * 3.f * (xx - yy));
-                    dRGBdy[ch] += (
-                        kSH_C3[0] * SHK(9) * 3.f * (xx - yy) +
-                        kSH_C3[1] * SHK(10) * xz +
-                        kSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) +
-                        kSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
-                        kSH_C3[4] * SHK(13) * -2.f * xy +
-                        kSH_C3[5] * SHK(14) * -2.f * yz +
-                        kSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
-                    dRGBdz[ch] += (
-                        kSH_C3[1] * SHK(10) * xy +
-                        kSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
-                        kSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) +
-                        kSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
-                        kSH_C3[5] * SHK(14) * (xx - yy));
-                }
-            }
-        }
-    }
-#undef SHK
-}
-
-// SH -> RGB (CR/forward.cu:20-71) of the VISIBLE Gaussians, in its own kernel (round 3).  It only feeds the compositing kernels, so it
-// runs on a second stream beside the whole binning chain (depth sort, scan, duplication, tile sort: ~0.2 ms of small launch- and
-// latency-bound kernels that leave the memory system idle), instead of in front of it inside the per-Gaussian kernel, where its 12 KB
-// per wave and its registers also kept that kernel at 4 waves per SIMD with load / compute / store phases in lockstep (84 us for
-// 321 MB).  Same staging as before: the wave's SH block through half a padded LDS slice at a time; waves without a visible Gaussian
-// return at once; writes the three colour floats of the 64-byte record and the clamp bits.
-__global__ __launch_bounds__(256) void preprocess_color_kernel(
-    int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ shs, const float *__restrict__ campos,
-    const int32_t *__restrict__ radii, float4 *__restrict__ records, uint8_t *__restrict__ clamped, const ShSplit sp, int nblocks,
-    float *__restrict__ sh_dsums)
-{
-    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // persistent workgroups (one per CU, see the launcher): block b of 256 Gaussians at a time; a wave is on its own (no barrier)
-    for (int block = blockIdx.x; block < nblocks; block += gridDim.x) {
-    const int idx = block * 256 + threadIdx.x;
-    const bool in_range = idx < P;
-    const bool visible = in_range && radii[idx] > 0;
-    if (__ballot(visible) == 0ull) continue;
-    const int ncoef = (D + 1) * (D + 1);
-    const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
-    const bool staged = (shs != nullptr || split) && (M == 16);
-    const int wave_first = block * 256 + wave * 64;
-    const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
-    ShPrefetch pf;
-    bool prefetched = false;
-    if (staged) {
-        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane);
-        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, (ncoef * 3 + 3) / 4, lane); prefetched = true; }
-    }
-    float3 p = make_float3(0.f, 0.f, 0.f);
-    if (visible) p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
-    if (staged && prefetched) {
-        float *lds0 = sh_lds + wave * SH_HALF_FLOATS;
-        if (split) wave_commit_sh_split_half(lds0, pf, lane, 0);
-        else wave_commit_sh_half(lds0, pf, lane, 0);
-    }
     // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
     float coefv[16][3];
     if (staged) {
@@ -617,7 +555,9 @@ __global__ __launch_bounds__(256) void preprocess_color_kernel(
     }
     if (visible) {
         float res[3];
-        {
+        if (colors_precomp) {
+            res[0] = colors_precomp[3 * (size_t)idx]; res[1] = colors_precomp[3 * (size_t)idx + 1]; res[2] = colors_precomp[3 * (size_t)idx + 2];
+        } else {
             float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             const float x = dx / len, y = dy / len, z = dz / len;
@@ -654,24 +594,56 @@ __global__ __launch_bounds__(256) void preprocess_color_kernel(
                 res[ch] = fmaxf(result, 0.0f);
             }
             clamped[idx] = clamp_bits;
-        }
-        float *rec2 = reinterpret_cast<float *>(records + 4 * (size_t)idx + 2);
-        rec2[1] = res[0]; rec2[2] = res[1]; rec2[3] = res[2];
-        if (sh_dsums) {
-            // d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): they depend on the SH values and the direction
-            // only, both in registers here -- stored (36 B per visible Gaussian) so that the backward does not read the 192-byte SH
-            // rows again.  Same function, same operands as the backward used: identical bits.
-            const float len = sqrtf((p.x - campos[0]) * (p.x - campos[0]) + (p.y - campos[1]) * (p.y - campos[1]) + (p.z - campos[2]) * (p.z - campos[2]));
-            const float x = (p.x - campos[0]) / len, y = (p.y - campos[1]) / len, z = (p.z - campos[2]) / len;
-            float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
-            sh_direction_sums(&coefv[0][0], D, x, y, z, dRGBdx, dRGBdy, dRGBdz);
-            float *o = sh_dsums + 9 * (size_t)idx;
+            if (sh_dsums) {
+                // d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): they depend on the SH values and the direction
+                // only, both in registers here -- stored (36 B per visible Gaussian, Ex4dParams.prepare_backward) so that the backward
+                // does not read the 192-byte SH rows again.  Same function, same operands as the backward's own evaluation: same bits.
+                float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+                sh_direction_sums(&coefv[0][0], D, x, y, z, dRGBdx, dRGBdy, dRGBdz);
+                float *o = sh_dsums + 9 * (size_t)idx;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) { o[ch] = dRGBdx[ch]; o[3 + ch] = dRGBdy[ch]; o[6 + ch] = dRGBdz[ch]; }
+                for (int ch = 0; ch < 3; ch++) { o[ch] = dRGBdx[ch]; o[3 + ch] = dRGBdy[ch]; o[6 + ch] = dRGBdz[ch]; }
+            }
         }
+        // per-Gaussian constants of the compositing kernels' quadrant cull (ex4d_composite.hip), evaluated once here
+        // instead of once per (Gaussian, tile, quadrant): tau = ln(255 w) + 1 % slack is the largest value of the quadratic
+        // form q(d) that still reaches alpha >= 1/255; -inf = never contributes (w < 1/255), +inf = never cull (conic
+        // not provably positive definite); k1, k2 = minimisers of q along a vertical / horizontal box edge
+        const float w_op = in_op * coef;
+        float tau;
+        if (w_op < (1.0f / 255.0f)) tau = -__builtin_inff();
+        else if (!(conic.x > 0.f && conic.z > 0.f && conic.x * conic.z - conic.y * conic.y > 0.f)) tau = __builtin_inff();
+        else tau = logf(255.0f * w_op) + 0.01f;
+        float4 *rec = records + 4 * (size_t)idx;
+        rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
+        rec[1] = make_float4(conic.z, tau, -conic.y / conic.z, -conic.y / conic.x);
+        rec[2] = make_float4(depth, res[0], res[1], res[2]);
+        rec[3] = make_float4(in_d0, in_d1, in_d2, w_op);
     }
-    wave_sync_lds();               // the slice is reused by the wave's next block
+    // frame flag for the compositing forward: does any visible Gaussian carry a flow vector?  (plain store of the same value by every
+    // wave that sees one: no atomic, no contention; the training loop's dir3D is the all-zero gradient trap and never sets it)
+    if (__ballot(visible && (in_d0 != 0.f || in_d1 != 0.f || in_d2 != 0.f)) != 0ull) {
+        if (lane == 0) prefilter_violation[1] = 1u;
     }
+    if (in_range) {
+        radii[idx] = out_radius;
+        if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
+        rects[idx] = rect;
+        depth_keys[idx] = depth_key;
+        depth_vals[idx] = (uint32_t)idx;
+    }
+    // number of tile instances (the reference's num_rendered = last element of the inclusive scan,
+    // CR/rasterizer_impl.cu:295-299): it does not depend on the depth order, so it is summed here and read back by the
+    // host WHILE the depth sort runs -- the blocking read-back no longer leaves the GPU idle.
+    // (one plain store per workgroup; the host adds the few thousand partial sums -- a single atomic counter would
+    // serialise ~12 ns per arrival)
+    __shared__ uint32_t wave_totals[4];
+    uint32_t wave_sum = out_tiles;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_sum += __shfl_xor(wave_sum, o, 64);
+    if (lane == 0) wave_totals[wave] = wave_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) total_instances[blockIdx.x] = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -698,7 +670,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *_
 //             sG = dL_dG G and d = mean2D - pixel; rest as layout 0.  dG/dmean2D = -G (A dx + B dy, C dy + B dx) (CR/backward.cu:
 //             :664-670), dG/dconic = -1/2 G (dx^2, dx dy, dy^2) (:673-675): linear in those sums, conic (A, B, C) from the record.
 // ------------------------------------------------------------------------------------------------
-// DSUMS = true: the forward's colour kernel left the SH direction sums (GeomState::sh_dsums, Ex4dParams.prepare_backward): the SH
+// DSUMS = true: the forward kernel left the SH direction sums (GeomState::sh_dsums, Ex4dParams.prepare_backward): the SH
 // rows are not read at all (-155 MB of 535 at 1.0 M Gaussians), the staging slice only serves the coalesced stores
 template <bool DSUMS>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
@@ -1032,28 +1004,12 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
     const int blocks = (prm.P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, stream,
         prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split);
-    return hipGetLastError();
-}
-
-// SH -> RGB of the visible Gaussians into the records (nothing to do for precomputed colours: the geometry kernel copied them)
-hipError_t ex4d_launch_preprocess_color(const Ex4dParams &prm, const float *means3D, const float *shs, const float *campos,
-    const int32_t *radii, GeomState g, ShSplit split, int wgs_per_cu, hipStream_t stream)
-{
-    const int nblocks = (prm.P + 255) / 256;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    // wgs_per_cu > 0: persistent workgroups (the kernel runs in the background of the binning chain); 0: one workgroup per block
-    const int grid = (wgs_per_cu > 0 && nblocks > wgs_per_cu * cus) ? wgs_per_cu * cus : nblocks;
-    hipLaunchKernelGGL(preprocess_color_kernel, dim3(grid), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, shs, campos, radii, g.records, g.clamped, split, nblocks, prm.prepare_backward ? g.sh_dsums : (float *)nullptr);
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split,
+        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr);
     return hipGetLastError();
 }
 
