@@ -330,7 +330,6 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--no-side-stream", action="store_true", help="tuning: clear the backward's accumulators in line instead of beside the compositing forward")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     args = ap.parse_args()
 
@@ -352,8 +351,6 @@ def main():
     _C.load()
     if args.bwd_variant is not None:
         _C.set_option("composite_bwd_variant", args.bwd_variant)
-    if args.no_side_stream:
-        _C.set_option("side_stream", 0)
 
     cfg = CONFIGS[args.config]
     train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only

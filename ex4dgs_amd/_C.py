@@ -179,8 +179,8 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
                         sh, degree, campos, prefiltered, min_depth, max_depth, debug, prepare_backward=False):
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-133): 24 positional arguments ->
     (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idx).
-    prepare_backward (keyword, not in the reference): a backward will follow -- the forward clears the backward's accumulator rows
-    beside its binning chain (include/ex4d_rasterizer.h: Ex4dParams.prepare_backward); hand `prepared=True` to that backward."""
+    prepare_backward (keyword, not in the reference): a backward will follow -- the forward also leaves the SH direction sums the
+    backward needs (include/ex4d_rasterizer.h: Ex4dParams.prepare_backward); hand `prepared=True` to the backward on these buffers."""
     lib = load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -302,9 +302,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         kt, ptr[name] = _dev_f32(t, name, dev)
         keep.append(kt)
     radii_c = radii.contiguous()
-    # prepared: the forward that produced the buffers already cleared the accumulator rows inside geomBuffer (first backward only)
-    scratch = None if prepared else torch.empty(lib.ex4d_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
-    scratch_ptr = None if prepared else scratch.data_ptr()
+    # prepared: the forward that produced geomBuffer left the SH direction sums in it (the backward then does not read the SH tensors)
+    scratch = torch.empty(lib.ex4d_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+    scratch_ptr = scratch.data_ptr()
     prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, False, debug, prepared)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream

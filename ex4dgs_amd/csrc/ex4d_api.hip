@@ -108,32 +108,6 @@ struct Readback {
 };
 thread_local Readback g_readback;
 
-// Second stream + two events per host thread and device: work nobody on the caller's stream waits for yet (clearing the backward's
-// accumulator rows) runs beside a kernel that leaves the memory system idle -- fork in front of the compositing forward, join behind
-// it.  Created on first use; never destroyed (the process owns a handful of them).
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork, join;
-    bool ready = false;
-    int device = -1;
-    bool init()
-    {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (ready && dev == device) return true;
-        if (ready) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(stream); ready = false; }
-        int lo = 0, hi = 0;             // lowest priority: the binning chain on the caller's stream is the critical path
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, lo) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
-        ready = true; device = dev;
-        return true;
-    }
-};
-thread_local SideStream g_side;
-std::atomic<int> g_side_stream{1};    // "side_stream": 0 = everything in line on the caller's stream
-
 struct Carver {
     char *base; size_t off;
     explicit Carver(void *b) : base((char *)b), off(0) {}
@@ -165,7 +139,6 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
     g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-workgroup instance counts
     g.block_totals = c.take<uint32_t>((P + 255) / 256);
-    g.acc16 = c.take<float>(16 * (size_t)P);
     g.sh_dsums = c.take<float>(9 * (size_t)P);
     l.total = c.off;
     if (lay) *lay = l;
@@ -320,6 +293,7 @@ static int forward_impl(
     uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
     for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
     const uint32_t host_total[2] = { instance_sum, g_readback.host[1] };
+    const bool has_flow = g_readback.host[2] != 0u;      // frame flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
     if (prm->prefiltered && host_total[1])
         return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     const uint32_t R = host_total[0];
@@ -356,27 +330,10 @@ static int forward_impl(
         STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
         MARK(0, "tile_ranges");
     }
-    // 8. compositing.  With prepare_backward the backward's accumulator rows (64 B per Gaussian) are cleared here, on the side stream,
-    // BESIDE the compositing kernel: that kernel is bound by VALU issue and leaves the memory system idle, the fill is pure HBM
-    // traffic -- and the backward no longer starts with a 12 us memset on its critical path.  (Measured alternatives, round 3: the SH
-    // colour evaluation as its own kernel on this stream beside the depth sort or beside the tile sort delayed whichever chain of
-    // small kernels it ran beside by about its own duration -- no gain over the fused per-Gaussian kernel)
-    bool forked = false;
-    if (prm->prepare_backward) {
-        if (g_side_stream.load(std::memory_order_relaxed) && !prm->debug && g_side.init()) {
-            HIP_TRY(hipEventRecord(g_side.fork, stream));
-            HIP_TRY(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
-            HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), g_side.stream));
-            HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
-            forked = true;
-        } else {
-            HIP_TRY(hipMemsetAsync(g.acc16, 0, (size_t)P * 16 * sizeof(float), stream));
-        }
-    }
+    // 8. compositing
     STAGE(ex4d_launch_composite_fwd(*prm, im.ranges, b.point_list, subpixel_offset, g.records, background, im.final_T, im.n_contrib,
-                                    out_color, out_depth, out_acc, out_flow, out_idx, b.qlist, b.qcount, g.total, stream), prm, stream);
+                                    out_color, out_depth, out_acc, out_flow, out_idx, b.qlist, b.qcount, has_flow, stream), prm, stream);
     MARK(0, "composite_fwd");
-    if (forked) HIP_TRY(hipStreamWaitEvent(stream, g_side.join, 0));       // whatever the caller enqueues next sees cleared accumulators
     return EX4D_OK;
 }
 
@@ -396,7 +353,7 @@ static int backward_impl(
     if (!prm) return fail(EX4D_ERR_ARG, "null params");
     const int P = prm->P, W = prm->W, H = prm->H;
     if (P <= 0 || W <= 0 || H <= 0) return fail(EX4D_ERR_ARG, "P, W, H must be positive (P == 0 is handled by the caller)");
-    if (!geom_buffer || !binning_buffer || !img_buffer || (!bwd_scratch && !prm->prepare_backward)) return fail(EX4D_ERR_ARG, "null state buffer");
+    if (!geom_buffer || !binning_buffer || !img_buffer || !bwd_scratch) return fail(EX4D_ERR_ARG, "null state buffer");
     if ((size_t)P * 64 > 0xFFFFFFFFull) return fail(EX4D_ERR_ARG, "more than 2^26 Gaussians: the accumulator rows are addressed with 32-bit byte offsets");
     // any of the four upstream gradients may be NULL (= zeros: that output is not part of the loss)
     if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_ddir || (prm->M > 0 && !dL_dsh && !(gsplit.rest[0] || gsplit.rest[1])))
@@ -404,12 +361,11 @@ static int backward_impl(
     GeomState g = carve_geom((void *)geom_buffer, P, nullptr, nullptr);
     BinState b = carve_binning((void *)binning_buffer, (uint32_t)num_rendered, W, H, nullptr, nullptr);
     ImgState im = carve_img((void *)img_buffer, W, H, nullptr, nullptr);
-    // accumulator rows: cleared by the forward that produced these buffers (prepare_backward) or here, in the caller's scratch
-    float *acc16 = prm->prepare_backward ? g.acc16 : (float *)bwd_scratch;
+    float *acc16 = (float *)bwd_scratch;
 
     const int variant = g_bwd_variant.load(std::memory_order_relaxed);
     g_prof.begin(1, stream);
-    if (!prm->prepare_backward) HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+    HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
     MARK(1, "zero_accumulators");
     // colours (SH or precomputed, rasterizer_impl.cu:426) already sit in the records
     if (num_rendered > 0)
@@ -514,7 +470,6 @@ int ex4d_backward_split_sh(
 int ex4d_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "side_stream") && (value == 0 || value == 1)) { g_side_stream.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
@@ -526,7 +481,6 @@ int ex4d_get_option(const char *name)
 {
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "acc_layout")) return 0;
-    if (name && !strcmp(name, "side_stream")) return g_side_stream.load();
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     return -1;

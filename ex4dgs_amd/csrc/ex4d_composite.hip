@@ -26,6 +26,7 @@
 // to the oracle within 1e-5, not bit-exactly) and exp() is the hardware v_exp_f32.
 #include "ex4d_internal.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <atomic>
 
 namespace {
 
@@ -151,16 +152,19 @@ __device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int quad, int gx, i
     return p;
 }
 
-// workgroup -> tile, XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs, so XCD x gets
-// the contiguous tile band [x*chunk, (x+1)*chunk)
-// WPB = waves (quadrants) per workgroup: 4 -> one workgroup per tile, 1 -> one workgroup per quadrant
-template <int WPB>
+// workgroup -> (tile, quadrant), XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2), so XCD x
+// gets the contiguous tile band [x*chunk, (x+1)*chunk).  One workgroup = one wave = one quadrant of a tile: the four quadrant waves of
+// a tile are independent, and as separate workgroups each gives its wave slot and LDS back as soon as IT is done (round 3: as one
+// 256-thread workgroup the forward held four slots until its slowest quadrant finished, 0.150 -> 0.144 ms).
+// Measured and dropped in round 3 (profiles/r03_tile_mapping_experiment.txt): stripes of 1 / 2 / 4 / 8 tile rows dealt to the XCDs
+// instead of bands, and "heaviest tiles of a band first" (a counting sort of the band's tiles by list length in front of the
+// forward) -- neither moved either compositing kernel by more than the box-to-box noise: they do not end on a few late heavy tiles.
 __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &quad)
 {
     const int chunk = (num_tiles + 7) >> 3;
     const int i = (int)(blockIdx.x >> 3);
-    if (WPB == 4) { tile = (int)(blockIdx.x & 7) * chunk + i; quad = threadIdx.x >> 6; }
-    else { tile = (int)(blockIdx.x & 7) * chunk + (i >> 2); quad = i & 3; }
+    tile = (int)(blockIdx.x & 7) * chunk + (i >> 2);
+    quad = i & 3;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,13 +186,16 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 // T -= weight instead of a select; the two skips of the reference as one unsigned compare (q2_rows above); the pair loop unrolled by two
 // by hand (immediate LDS offsets).  Per staged Gaussian and pixel: 13 VALU before the decision, 12 more when a pixel contributes.
 // Every chunk's survivors are appended to the quadrant's compacted list (BinState::qlist) -- all the backward reads of the tile list.
-struct FwdLds {                  // per wave: the survivors of one 64-entry chunk (4.5 KB; the kernel's 59 VGPRs, not LDS, bound its occupancy)
+struct FwdLds {                  // per wave: the survivors of one 64-entry chunk (4.5 KB; the kernel's VGPRs, not LDS, bound its occupancy)
     float4 q0[64];               // mean.x, mean.y, a', b'
-    float4 q1[64];               // c', w, tauq (bits), -
-    float4 c[64];                // depth, r, g, b
+    float4 q1[64];               // c', w, tauq (bits), blue
+    float4 c[64];                // red, green, depth, 1.0   (two register pairs: (C0, C1) += (r, g) wgt and (Dm, acc) += (depth, 1) wgt are one v_pk_fma_f32 each)
     float4 f[64];                // dir3D (frames with flow only)
     uint2 it[64];                // Gaussian id, position in the tile list
 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
 
 template <bool FLOW>
 __device__ __forceinline__ void composite_fwd_body(
@@ -211,10 +218,13 @@ __device__ __forceinline__ void composite_fwd_body(
     int consumed = 0;
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dm = 0.f, acc = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
+    float T = 1.0f, C2 = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
+    f32x2 Crg = { 0.f, 0.f }, Dacc = { 0.f, 0.f };           // (C0, C1), (sum of depth weight, sum of weights)
     uint32_t last_contributor = 0;
     int32_t best = -1;
     const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the chunk position)
+    // LDS byte address of this wave's staging area (the low half of the flat address of a __shared__ object IS its LDS address)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)&L.q0[0];
 
     for (int base = 0; base < n; base += 64) {
         if (live == 0) break;
@@ -235,11 +245,12 @@ __device__ __forceinline__ void composite_fwd_body(
         if (keep) {
             const int slot = __popcll(mask & lt);
             const float4 *r = records + 4 * (size_t)id;
+            const float4 q2 = r[2];
             const float4 q3 = r[3];
             // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
             L.q0[slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
-            L.q1[slot] = make_float4(q1.x * kHalfLog2e, q3.w, __uint_as_float(tauq_bits_of(q3.w)), 0.f);
-            L.c[slot] = r[2];
+            L.q1[slot] = make_float4(q1.x * kHalfLog2e, q3.w, __uint_as_float(tauq_bits_of(q3.w)), q2.w);
+            L.c[slot] = make_float4(q2.y, q2.z, q2.x, 1.0f);
             if (FLOW) L.f[slot] = q3;
             const uint2 item = make_uint2(id, (uint32_t)k);
             L.it[slot] = item;
@@ -247,13 +258,17 @@ __device__ __forceinline__ void composite_fwd_body(
         }
         consumed += cnt;
         wave_lds_sync();
-        int last_j = -1;
+        // The walk over the staged entries keeps the entry's LDS address in a VGPR that the compiler cannot prove uniform (a uniform
+        // index lives in an SGPR and costs a v_mov per ds_read): one v_add per two entries, every read at an immediate offset, and the
+        // last contributing entry is remembered as that address (even / odd entries apart) instead of as a materialised index.
+        uint32_t va;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(lds_base));
+        int last_even = -1, last_odd = -1;     // LDS address of the pair whose even / odd entry contributed last
         uint32_t best_key = 0;
-        // one (pixel, staged Gaussian) pair per lane; unrolled by two by hand so that the second entry is read at immediate
-        // offsets of the same LDS addresses (the compiler does not unroll a loop with data-dependent exits)
-        auto pair = [&](const int j) {
-            const float4 g0 = L.q0[j];
-            const float4 g1 = L.q1[j];
+        // one (pixel, staged Gaussian) pair per lane
+        auto pair = [&](const int j, const int off, int &last_addr) {
+            const f32x4 g0 = *(lds_float4_ptr)(uintptr_t)(va + off);
+            const f32x4 g1 = *(lds_float4_ptr)(uintptr_t)(va + off + 1024);
             // CR/forward.cu:368-387 as one flat predicate; q2 = -power log2(e)
             const float q2 = q2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
             const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(-q2));
@@ -265,29 +280,33 @@ __device__ __forceinline__ void composite_fwd_body(
             const lanemask add = ok & ~stop;
             if (add == 0) return;
             // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
-            const float4 g2 = L.c[j];
+            const f32x4 g2 = *(lds_float4_ptr)(uintptr_t)(va + off + 2048);
             const float wgt = select_f(add, wgt_all, 0.f);
-            C0 += g2.y * wgt; C1 += g2.z * wgt; C2 += g2.w * wgt;
-            Dm += g2.x * wgt;
-            acc += wgt;
-            if (FLOW) { const float4 g3 = L.f[j]; F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
+            const f32x2 ww = { wgt, wgt };
+            Crg = __builtin_elementwise_fma((f32x2){ g2.x, g2.y }, ww, Crg);
+            Dacc = __builtin_elementwise_fma((f32x2){ g2.z, g2.w }, ww, Dacc);
+            C2 = __builtin_fmaf(g1.w, wgt, C2);
+            if (FLOW) { const f32x4 g3 = *(lds_float4_ptr)(uintptr_t)(va + off + 3072); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
             // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
             uint32_t key;
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
             best_key = best_key > key ? best_key : key;
             T -= wgt;                                          // the contributing lanes' new transmittance
-            last_j = select_i(add, j, last_j);
+            last_addr = select_i(add, (int)va, last_addr);
         };
         {
             int j = 0;
-            for (; j + 1 < cnt; j += 2) {
+            for (; j + 1 < cnt; j += 2, va += 32) {
                 if (live == 0) break;
-                pair(j);
+                pair(j, 0, last_even);
                 if (live == 0) break;
-                pair(j + 1);
+                pair(j + 1, 16, last_odd);
             }
-            if (j < cnt && live != 0) pair(j);          // odd count: the last entry (a break above leaves live == 0)
+            if (j < cnt && live != 0) pair(j, 0, last_even);          // odd count: the last entry (a break above leaves live == 0)
         }
+        const int je = last_even < 0 ? -1 : (int)(((uint32_t)last_even - lds_base) >> 4);
+        const int jo = last_odd < 0 ? -1 : (int)(((uint32_t)last_odd - lds_base) >> 4) + 1;
+        const int last_j = je > jo ? je : jo;
         if (last_j >= 0) last_contributor = L.it[last_j].y + 1;
         if (best_key > 63u) {
             const float wq = __uint_as_float(best_key & keep_hi);
@@ -298,6 +317,7 @@ __device__ __forceinline__ void composite_fwd_body(
     if (lane == 0) qcount[4 * tile + wave] = (uint32_t)consumed;
     if (p.inside) {
         // CR/forward.cu:426-460
+        const float C0 = Crg.x, C1 = Crg.y, Dm = Dacc.x, acc = Dacc.y;
         float Dout, Fx = F0, Fy = F1, Fz = F2;
         if (acc == 0.0f) { Dout = Dm + (1.0f - acc) * max_depth; }
         else { Dout = Dm / acc; Fx = F0 / acc; Fy = F1 / acc; Fz = F2 / acc; }
@@ -314,28 +334,25 @@ __device__ __forceinline__ void composite_fwd_body(
     }
 }
 
-__global__ __launch_bounds__(256) void composite_fwd_kernel(
+// FLOW is a launch-time choice (the frame flag travels with the instance count's read-back): the flow-free kernel needs 43 VGPRs, the
+// one with both paths behind a run-time branch needed 66
+template <bool FLOW>
+__global__ __launch_bounds__(64) void composite_fwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
     const float *__restrict__ subpixel_offset, const float4 *__restrict__ records,
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
-    const uint32_t *__restrict__ frame_flags)
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount)
 {
-    __shared__ FwdLds lds[4];
+    __shared__ FwdLds lds;
     int tile, quad;
-    tile_of_block<4>(num_tiles, tile, quad);
+    tile_of_block(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
-#define FWD_ARGS W, H, gx, tile, wave, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, \
-                 qlist, qcount, lds[wave]
-    // frame_flags[2]: set by the preprocess kernel iff some visible Gaussian has a non-zero dir3D (uniform scalar load + branch)
-    if (frame_flags[2] != 0u) composite_fwd_body<true>(FWD_ARGS);
-    else composite_fwd_body<false>(FWD_ARGS);
-#undef FWD_ARGS
+    composite_fwd_body<FLOW>(W, H, gx, tile, quad, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc,
+                             out_flow, out_idx, qlist, qcount, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,10 +449,12 @@ __device__ __forceinline__ float row_scan_add_asm(float x)
 // SEP = true: every pixel of the quadrant sits at its integer coordinates (no sub-pixel offsets), so dx / dy are not read per pixel
 // NOLAST = true: the batch is full and all of its entries lie in front of every pixel's last contributor (wave-uniform, decided
 // by the caller from the first = deepest entry): the per-pair test `list position < last contributor` is dropped
-template <bool STATS, bool EXTRA, bool SEP, bool NOLAST>
-__device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nvalid, float ox, float oy, float min_depth, bool use_gacc,
+// GACC = true: some pixel of the quadrant has an upstream dL_dacc (a third scan per step and its carry)
+template <bool STATS, bool EXTRA, bool SEP, bool NOLAST, bool GACC>
+__device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nvalid, float ox, float oy, float min_depth,
                                           float *__restrict__ acc16)
 {
+    constexpr bool use_gacc = GACC;
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     constexpr int RING = BWD_RING;
     const int slot = ring_wrap<RING>(head + n);
@@ -448,13 +467,20 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
     const uint32_t tauq = tauq_bits_of(w);                  // the forward's value: same instruction, same bits
     const float flagf = dep > min_depth ? 1.f : 0.f;       // CR/backward.cu:603
     const float depflag = dep * flagf;
-    float v[13];
-#pragma unroll
-    for (int q = 0; q < 13; q++) v[q] = 0.f;
+    // The 13 sums live in explicit register PAIRS fed by v_pk_fma_f32 (pair += pair * broadcast scalar).  Left to itself the compiler
+    // packs scalar accumulators into pairs on its own and shuffles them in and out of the pairs with ~10 v_mov per step (round 3:
+    // 53 VALU per step, 10 of them moves).  The factor w of sG = w G dL_dalpha is applied once per batch instead of once per step.
+    f32x2 SYe = { 0.f, 0.f }, SYo = { 0.f, 0.f };        // MOMENTS: (sum s6, sum s6 dy) over the even / odd steps
+    f32x2 M01 = { 0.f, 0.f }, M34 = { 0.f, 0.f };        // otherwise: (sum s6 dx, sum s6 dy), (sum s6 dx dx, sum s6 dx dy)
+    f32x2 M56 = { 0.f, 0.f };                            // (sum s6 dy dy, sum s6 [+ G gacc])
+    f32x2 C78 = { 0.f, 0.f }, C1011 = { 0.f, 0.f };      // (v7, v8), (v10, v11)
+    float c9 = 0.f, c12 = 0.f, v2 = 0.f;
+    f32x2 one_dy = { 1.f, 0.f }, dy2_one = { 0.f, 1.f }; // (1, dy), (dy dy, 1): the multiplicands of the moment pairs
+    f32x2 dxy = { 0.f, 0.f };
     // carries of pixel 4s+g are written by lane n == 15 of row g; the other lanes write into the dump area (no exec masking)
     float2 *wTQ = (n == 15) ? reinterpret_cast<float2 *>(&L.pb[g].z) : reinterpret_cast<float2 *>(&L.dump[2 * (lane & 31)]);
     float *wG = (n == 15) ? (&L.pc[g].w) : (&L.dump[lane]);
-    const bool rd_pc = EXTRA || use_gacc;       // wave-uniform
+    constexpr bool rd_pc = EXTRA || use_gacc;
     // the per-pixel constants / carries of step s + 1 are requested before step s runs (its LDS latency hides behind the step;
     // the carries of pixels 4(s+1)+g are last written one batch earlier, so the early read sees the right values)
     float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = make_float4(0.f, 0.f, 0.f, 0.f), pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -462,7 +488,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
     if (!SEP) pd_n = L.pd[g];
     unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
     const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
-    float dyr = 0.f, bdy = 0.f, cdydy = 0.f, dy2 = 0.f;
+    float dyr = 0.f, bdy = 0.f, cdydy = 0.f;
     constexpr bool MOMENTS = SEP;     // see the accumulation below
 #pragma unroll
     for (int s = 0; s < 16; s++) {
@@ -477,26 +503,27 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         float dx, dy;
         if (SEP) {
             dx = (s & 1) ? dxo : dxe;
-            if ((s & 1) == 0) { dyr = g0.y - (oy + (float)(s >> 1)); bdy = bp * dyr; cdydy = (cp * dyr) * dyr; if (MOMENTS) dy2 = dyr * dyr; }
+            if ((s & 1) == 0) { dyr = g0.y - (oy + (float)(s >> 1)); bdy = bp * dyr; cdydy = (cp * dyr) * dyr; one_dy.y = dyr; dy2_one.x = dyr * dyr; }
             dy = dyr;
         } else {
-            dx = g0.x - pd.x; dy = g0.y - pd.y;
+            dxy = (f32x2){ g0.x, g0.y } - (f32x2){ pd.x, pd.y };
+            dx = dxy.x; dy = dxy.y;
             bdy = bp * dy; cdydy = (cp * dy) * dy;
         }
         const float q2 = q2_rows(dx, ap, bdy, cdydy);
-        const float G = __builtin_amdgcn_exp2f(-q2);
-        const float alpha = fminf(0.99f, w * G);
         const lanemask ok = NOLAST ? LANES(__float_as_uint(q2) <= tauq)
                                    : (LANES(orig < __float_as_uint(pb.y)) & LANES(__float_as_uint(q2) <= tauq));
         if (STATS) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
-        const float alpha_m = select_f(ok, alpha, 0.f);
-        const float G_m = select_f(ok, G, 0.f);
+        // G and alpha of the contributing lanes, exact zeros elsewhere (one select: w is finite, so w * 0 = 0)
+        const float G_m = select_f(ok, __builtin_amdgcn_exp2f(-q2), 0.f);
+        const float alpha_m = fminf(0.99f, w * G_m);
         const float inv = __builtin_amdgcn_rcpf(1.f - alpha_m);
         // T_i = T_carry * prod_{j <= i} inv_j   (the carry is row-uniform: every lane of the row read it from LDS)
         const float T = pb.z * row_scan_mul(inv);
         const float dcc = alpha_m * T;                                  // dchannel_dcolor
-        const float cgp = g2.x * pa.x + g2.y * pa.y + g2.z * pa.z;      // c . dL_dpixel
+        // c . dL_dpixel (explicit chain: the compiler's own packing of the three products costs two moves and a packed multiply)
+        const float cgp = __builtin_fmaf(g2.z, pa.z, __builtin_fmaf(g2.y, pa.y, g2.x * pa.x));
         const float e = dcc * cgp;
         // the carry slot holds Q = bgT - E (E = sum of e over everything behind this batch): one subtraction gives bgT - E_inclusive
         const float Q = pb.w - row_scan_add_asm(e);
@@ -509,30 +536,29 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
             gdT = pa.w * T;                                             // dL_ddepth T; the flag of the dL_dmean2D.z sum is applied per Gaussian
             dLa += ((pb.x * flagf - depflag) * gdT) * T;
         }
-        float s6 = G_m * dLa;
-        const float sG = w * s6;                                        // dL_dG G = (w dL_dalpha) G
-        if (use_gacc) {             // wave-uniform
+        const float s6 = G_m * dLa;                                     // dL_dG G / w
+        const f32x2 s66 = { s6, s6 }, dd = { dcc, dcc };
+        if (use_gacc) {
             // dL_dacc *= T for every contributor (CR/backward.cu:650), then dL_dopacity += G (dL_dalpha + dL_dacc)
             const float ga = pc.w * row_scan_mul(select_f(ok, T, 1.f));
-            v[6] += G_m * ga;
+            M56.y = __builtin_fmaf(G_m, ga, M56.y);
             wG[16 * s] = ga;
         }
-        {
-            if (EXTRA) v[2] += alpha_m * gdT;
-            v[7] += dcc * pa.x; v[8] += dcc * pa.y; v[9] += dcc * pa.z;
-            if (EXTRA) { v[10] += dcc * pc.x; v[11] += dcc * pc.y; v[12] += dcc * pc.z; }
-            if (MOMENTS) {
-                // dx takes one value on the even steps and one on the odd steps of a batch: the sums over sG dx, sG dx^2, sG dx dy
-                // follow from S = sum sG and Y = sum sG dy kept separately for the two step parities (7 VALU per step -> 3)
-                if (s & 1) { v[3] += sG; v[4] += sG * dy; } else { v[0] += sG; v[1] += sG * dy; }
-                v[5] += sG * dy2;
-            } else {
-                v[0] += sG * dx; v[1] += sG * dy;
-                const float sdx = sG * dx;
-                v[3] += sdx * dx; v[4] += sdx * dy; v[5] += (sG * dy) * dy;
-            }
-            v[6] += s6;
+        if (EXTRA) v2 = __builtin_fmaf(alpha_m, gdT, v2);
+        C78 = __builtin_elementwise_fma((f32x2){ pa.x, pa.y }, dd, C78);
+        c9 = __builtin_fmaf(pa.z, dcc, c9);
+        if (EXTRA) { C1011 = __builtin_elementwise_fma((f32x2){ pc.x, pc.y }, dd, C1011); c12 = __builtin_fmaf(pc.z, dcc, c12); }
+        if (MOMENTS) {
+            // dx takes one value on the even steps and one on the odd steps of a batch: the sums over s6 dx, s6 dx^2, s6 dx dy
+            // follow from S = sum s6 and Y = sum s6 dy kept separately for the two step parities
+            if (s & 1) SYo = __builtin_elementwise_fma(one_dy, s66, SYo); else SYe = __builtin_elementwise_fma(one_dy, s66, SYe);
+        } else {
+            const float tdx = s6 * dx;
+            dy2_one.x = dy * dy;
+            M01 = __builtin_elementwise_fma(dxy, s66, M01);
+            M34 = __builtin_elementwise_fma(dxy, (f32x2){ tdx, tdx }, M34);
         }
+        M56 = __builtin_elementwise_fma(dy2_one, s66, M56);
         wTQ[8 * s] = make_float2(T, Q);
     }
     // The sums leave the wave like in the per-pixel kernel -- one atomic instruction covers whole 64-byte accumulator rows
@@ -546,13 +572,19 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
     wave_lds_sync();
     float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
     {
+        float v[13];
         if (MOMENTS) {
-            const float Se = v[0], Ye = v[1], So = v[3], Yo = v[4];
+            const float Se = SYe.x, Ye = SYe.y, So = SYo.x, Yo = SYo.y;
             v[0] = dxe * Se + dxo * So;
             v[1] = Ye + Yo;
             v[3] = (dxe * dxe) * Se + (dxo * dxo) * So;
             v[4] = dxe * Ye + dxo * Yo;
+        } else {
+            v[0] = M01.x; v[1] = M01.y; v[3] = M34.x; v[4] = M34.y;
         }
+        v[0] *= w; v[1] *= w; v[3] *= w; v[4] *= w;           // sG = w s6
+        v[5] = w * M56.x;
+        v[2] = v2; v[6] = M56.y; v[7] = C78.x; v[8] = C78.y; v[9] = c9; v[10] = C1011.x; v[11] = C1011.y; v[12] = c12;
         // accumulator layout 0 (what the per-pixel kernel writes): dL_dmean2D.xy as sums of sG (2 a' dx + b' dy), sG (2 c' dy + b' dx)
         // with the pre-scaled conic -- linear in the moments, so the conic is applied once per lane here
         {
@@ -623,7 +655,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     constexpr int RING = BWD_RING;
     __shared__ BwdLdsT<RING> lds[WPB];
     int tile, quad;
-    tile_of_block<WPB>(num_tiles, tile, quad);
+    tile_of_block(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
     const int wave = (WPB == 4) ? (threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
     BwdLdsT<RING> &L = lds[wave];
@@ -701,10 +733,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
                 // first entry of the batch = its deepest: wave-uniform read of its list position
                 const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(L.ring[2][head].w));
                 const bool nolast = nb == 16 && kfirst < min_last;
-#define BATCH(E, S, N) bwd_batch<STATS, E, S, N>(L, head, nb, ox, oy, min_depth, use_gacc, acc16)
-                if (!sep) BATCH(true, false, false);
-                else if (use_extra) { if (nolast) BATCH(true, true, true); else BATCH(true, true, false); }
-                else { if (nolast) BATCH(false, true, true); else BATCH(false, true, false); }
+#define BATCH(E, S, N, G) bwd_batch<STATS, E, S, N, G>(L, head, nb, ox, oy, min_depth, acc16)
+                // (quadrants with sub-pixel offsets take the general variant: all scans, all sums)
+                if (!sep) BATCH(true, false, false, true);
+                else if (use_extra) {
+                    if (use_gacc) { if (nolast) BATCH(true, true, true, true); else BATCH(true, true, false, true); }
+                    else { if (nolast) BATCH(true, true, true, false); else BATCH(true, true, false, false); }
+                } else if (use_gacc) { if (nolast) BATCH(false, true, true, true); else BATCH(false, true, false, true); }
+                else { if (nolast) BATCH(false, true, true, false); else BATCH(false, true, false, false); }
 #undef BATCH
                 head = ring_wrap<RING>(head + nb);
                 count -= nb;
@@ -726,13 +762,16 @@ hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
-    const uint32_t *frame_flags, hipStream_t stream)
+    bool has_flow, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(8 * ((T + 7) / 8)), dim3(256), 0, stream,
-        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg,
-        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, qlist, qcount, frame_flags);
+    const int slots = 8 * ((T + 7) / 8);
+#define FWD_LAUNCH(FLOW) hipLaunchKernelGGL(composite_fwd_kernel<FLOW>, dim3(4 * slots), dim3(64), 0, stream, \
+        prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg, \
+        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, qlist, qcount)
+    if (has_flow) FWD_LAUNCH(true); else FWD_LAUNCH(false);
+#undef FWD_LAUNCH
     return hipGetLastError();
 }
 
@@ -741,7 +780,8 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount, int variant, hipStream_t stream)
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount,
+    int variant, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;

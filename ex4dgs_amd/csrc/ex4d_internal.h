@@ -34,8 +34,7 @@ struct GeomState {
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
     uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0
     uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
-    float *acc16;                                        // [P][16] accumulator rows of the backward, zeroed by the forward on request (Ex4dParams.prepare_backward)
-    float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on the same request
+    float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on request (Ex4dParams.prepare_backward)
 };
 struct BinState {
     uint32_t *point_list;     // final sorted Gaussian ids
@@ -108,12 +107,13 @@ hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
-    const uint32_t *frame_flags, hipStream_t stream);
+    bool has_flow, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount, int variant, hipStream_t stream);
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount,
+    int variant, hipStream_t stream);
 
 // developer statistics of the scan compositing backward (variant 8)
 hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset);

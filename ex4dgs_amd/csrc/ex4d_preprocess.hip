@@ -600,6 +600,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 // does not read the 192-byte SH rows again.  Same function, same operands as the backward's own evaluation: same bits.
                 float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
                 sh_direction_sums(&coefv[0][0], D, x, y, z, dRGBdx, dRGBdy, dRGBdz);
+                // one 36-byte row per Gaussian (measured against nine planes of P floats: rows 0.100 / 0.076 ms for this kernel / the
+                // backward, planes 0.111 / 0.080 -- nine DRAM pages per wave instead of one region)
                 float *o = sh_dsums + 9 * (size_t)idx;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) { o[ch] = dRGBdx[ch]; o[3 + ch] = dRGBdy[ch]; o[6 + ch] = dRGBdz[ch]; }

@@ -70,8 +70,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (s.bg, means3D, dir3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                 s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size, s.subpixel_offset,
                 s.image_height, s.image_width, sh, s.sh_degree, s.campos, s.prefiltered, s.min_depth, s.max_depth, s.debug)
-        # a backward will follow iff some input wants a gradient: the forward then also clears the backward's accumulator rows (beside
-        # its binning chain, on its side stream) -- consumed by the FIRST backward on these buffers
+        # a backward will follow iff some input wants a gradient: the forward then also leaves the SH direction sums of the SH
+        # backward in its geometry buffer (it has the SH rows in registers anyway), and the backward does not read the SH tensors
         ctx.prepared = any(ctx.needs_input_grad)
         native_fwd = lambda *a: _C.rasterize_gaussians(*a, prepare_backward=ctx.prepared)
         (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idxs) = _call_native(
@@ -105,7 +105,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, s.debug)
         # gradients of inputs the forward did not have are not even written (the reference fills dL_dcolors / dL_dcov3D and drops them)
         need_colors, need_cov3D = colors_precomp.numel() != 0, cov3Ds_precomp.numel() != 0
-        prepared, ctx.prepared = ctx.prepared, False           # (a second backward through a retained graph clears its own scratch)
+        prepared = ctx.prepared                                # (read-only state: any number of backward passes may use it)
         native = lambda *a: _C.rasterize_gaussians_backward(*a, need_colors=need_colors, need_cov3D=need_cov3D, prepared=prepared)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
          grad_scales, grad_rotations, grad_dir3D) = _call_native(native, args, s.debug, "snapshot_bw.dump", "backward")

@@ -274,7 +274,8 @@ def test_wrapper_marshalling_matches_reference_golden(monkeypatch):
     assert list(dgr.GaussianRasterizationSettings._fields) == gold["settings_fields"]
     rec = {}
 
-    def fwd(*args):
+    def fwd(*args, **extension):      # prepare_backward: keyword-only extension, the positional arguments are the reference's
+        assert set(extension) <= {"prepare_backward"}
         rec["fwd"] = args
         P, H, W = args[1].shape[0], args[15], args[16]
         z = torch.zeros
@@ -282,7 +283,7 @@ def test_wrapper_marshalling_matches_reference_golden(monkeypatch):
                 z(1, H, W), z(1, H, W), z(3, H, W), z(1, H, W, dtype=torch.int32))
 
     def bwd(*args, **extension):      # need_colors / need_cov3D: keyword-only extension, the 30 positional arguments are the reference's
-        assert set(extension) <= {"need_colors", "need_cov3D"}
+        assert set(extension) <= {"need_colors", "need_cov3D", "prepared"}
         rec["bwd"] = args
         P, M = args[1].shape[0], args[22].shape[1]
         return tuple(torch.full(s, float(i + 1)) for i, s in enumerate([(P, 3), (P, 3), (P, 1), (P, 3), (P, 6), (P, M, 3), (P, 3), (P, 4), (P, 3)]))
@@ -592,7 +593,7 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     assert lay.total == l.ex4d_geom_bytes(P) and lay.cov3D >= 64 * P and lay.cov3D % 256 == 0 and lay.records == 0
     assert l.ex4d_binning_bytes(0, 64, 64) > 0 and l.ex4d_img_bytes(1352, 1014) >= 1352 * 1014 * 8 + 5440 * 8
     assert l.ex4d_backward_scratch_bytes(P) >= P * 64
-    assert ctypes.sizeof(_C.Ex4dParams) == 13 * 4
+    assert ctypes.sizeof(_C.Ex4dParams) == 15 * 4
     # the kernels are gfx950 code objects
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={lib}"], capture_output=True, text=True)
     if out.returncode == 0 and out.stdout.strip():

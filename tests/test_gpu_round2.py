@@ -468,10 +468,10 @@ def test_compacted_quadrant_lists_left_for_the_backward(hip_lib):
     assert 0 < total < 4 * g["num_rendered"]
 
 
-def test_accumulators_prepared_by_the_forward_and_second_backward(hip_lib):
-    """Ex4dParams.prepare_backward: under autograd the forward clears the backward's accumulator rows (inside the geometry buffer, on its
-    side stream); the first backward consumes them, a second backward through a retained graph clears its own scratch.  Both give the
-    gradients of the plain path (raw `_C` call with its own scratch) up to the order of the float atomics."""
+def test_sh_direction_sums_prepared_by_the_forward_and_second_backward(hip_lib):
+    """Ex4dParams.prepare_backward: under autograd the forward leaves the SH direction sums in its geometry buffer and the backward does
+    not read the SH tensors; a second backward through a retained graph reads the same (read-only) state.  Both give the gradients of
+    the plain path (raw `_C` calls, the backward evaluating the SH derivative itself) up to the order of the float atomics."""
     from ex4dgs_amd.diff_gaussian_rasterization_df import rasterize_gaussians
     ins, st = h.scene_inputs("cfg3", P=9000, dir_scale=0.0)
     s = h.gpu_settings(st, "cuda")
