@@ -156,7 +156,7 @@ __device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int quad, int gx, i
 // gets the contiguous tile band [x*chunk, (x+1)*chunk).  One workgroup = one wave = one quadrant of a tile: the four quadrant waves of
 // a tile are independent, and as separate workgroups each gives its wave slot and LDS back as soon as IT is done (round 3: as one
 // 256-thread workgroup the forward held four slots until its slowest quadrant finished, 0.150 -> 0.144 ms).
-// Measured and dropped in round 3 (profiles/r03_tile_mapping_experiment.txt): stripes of 1 / 2 / 4 / 8 tile rows dealt to the XCDs
+// Measured and dropped in round 3 (profiles/r03_compositing_experiments.txt): stripes of 1 / 2 / 4 / 8 tile rows dealt to the XCDs
 // instead of bands, and "heaviest tiles of a band first" (a counting sort of the band's tiles by list length in front of the
 // forward) -- neither moved either compositing kernel by more than the box-to-box noise: they do not end on a few late heavy tiles.
 __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &quad)
