@@ -318,6 +318,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--points", type=int, default=None, help="override the Gaussian count (parity/debug only)")
+    ap.add_argument("--fwd-asm", type=int, default=None, choices=[0, 1], help="tuning: compositing forward with the hand-scheduled entry walk (1, default) or the compiler's loop (0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allreduce", action="store_true", help="N > 1 without the gradient exchange (pure replicas)")
     ap.add_argument("--forward-only", action="store_true", help="render only (BASELINE config 5 is quoted as forward-only FPS); not the headline metric")
@@ -349,6 +350,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     _C.load()
+    if args.fwd_asm is not None:
+        _C.set_option("composite_fwd_asm", args.fwd_asm)
     if args.bwd_variant is not None:
         _C.set_option("composite_bwd_variant", args.bwd_variant)
 

@@ -186,6 +186,8 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 // T -= weight instead of a select; the two skips of the reference as one unsigned compare (q2_rows above); the pair loop unrolled by two
 // by hand (immediate LDS offsets).  Per staged Gaussian and pixel: 13 VALU before the decision, 12 more when a pixel contributes.
 // Every chunk's survivors are appended to the quadrant's compacted list (BinState::qlist) -- all the backward reads of the tile list.
+std::atomic<int> g_fwd_asm{1};      // compositing forward: hand-scheduled walk (1, default) or the compiler's (0)
+
 struct FwdLds {                  // per wave: the survivors of one 64-entry chunk (4.5 KB; the kernel's VGPRs, not LDS, bound its occupancy)
     float4 q0[64];               // mean.x, mean.y, a', b'
     float4 q1[64];               // c', w, tauq (bits), blue
@@ -197,7 +199,57 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
 
-template <bool FLOW>
+// One staged entry of the hand-scheduled walk (see composite_fwd_body): CUR0 / CUR1 = the register quads holding this entry's test
+// operands (mean.x mean.y a' b' | c' w tauq blue), NXT0 / NXT1 = the quads the NEXT entry's operands are requested into; this entry's
+// (red, green, depth, 1) is requested into CUR0 as soon as the mean and the conic have been consumed; v60-v63 temporaries.  Branch targets carry the statement's unique id (%=) and the set's letter.
+#define EX4D_FWD_ENTRY(S, CUR0, CX, CY, CA, CB, CC, CW, CT, CBLUE, NXT0, NXT1, G2RG, G2DA) \
+    "ds_read_b128 " NXT0 ", %[va] offset:16\n\t" \
+    "ds_read_b128 " NXT1 ", %[va] offset:1040\n\t" \
+    "s_waitcnt lgkmcnt(2)\n\t"                                   /* this entry's operands (requested one entry earlier) have arrived */ \
+    "v_sub_f32 v60, " CY ", %[fy]\n\t" \
+    "v_sub_f32 v61, " CX ", %[fx]\n\t" \
+    "v_mul_f32 v62, v60, " CC "\n\t" \
+    "v_mul_f32_e64 v63, " CB ", -v60\n\t" \
+    "v_fma_f32 v63, v61, -" CA ", v63\n\t" \
+    "ds_read_b128 " CUR0 ", %[va] offset:2048\n\t"               /* (red, green, depth, 1) into the quad whose mean / conic are consumed */ \
+    "v_mul_f32_e64 v62, v62, -v60\n\t" \
+    "v_fmac_f32 v62, v61, v63\n\t"                               /* q2 = -power log2(e) */ \
+    "v_exp_f32_e64 v60, -v62\n\t" \
+    "v_cmp_ge_u32_e64 %[ok], " CT ", v62\n\t"                    /* bits(q2) <= bits(tauq): CR/forward.cu:372 and :379 in one compare */ \
+    "s_and_b64 %[ok], %[ok], %[live]\n\t" \
+    "s_cbranch_scc0 Lskip" S "_%=\n\t"                           /* no live lane in range: nothing to do for this entry */ \
+    "v_mul_f32 v60, " CW ", v60\n\t" \
+    "v_min_f32 v60, 0x3f7d70a4, v60\n\t"                         /* alpha = min(0.99, w G) */ \
+    "v_fma_f32 v61, -%[T], v60, %[T]\n\t"                        /* test_T = T (1 - alpha), CR/forward.cu:383 */ \
+    "v_cmp_gt_f32_e64 %[stop], %[thr], v61\n\t" \
+    "s_and_b64 %[stop], %[stop], %[ok]\n\t" \
+    "s_cbranch_scc1 Lrare" S "_%=\n"                              /* some lane saturates here (CR/forward.cu:384-388): off the common path */ \
+    "Ladd" S "_%=:\n\t" \
+    "s_mov_b64 exec, %[ok]\n\t"                                  /* CR/forward.cu:389-422 for the contributing lanes only */ \
+    "v_mul_f32 v62, %[T], v60\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                                   /* this entry's colours */ \
+    "v_pk_fma_f32 %[crg], " G2RG ", v[62:63], %[crg] op_sel_hi:[1,0,1]\n\t" \
+    "v_pk_fma_f32 %[dacc], " G2DA ", v[62:63], %[dacc] op_sel_hi:[1,0,1]\n\t" \
+    "v_fmac_f32 %[c2], " CBLUE ", v62\n\t" \
+    "v_bfi_b32 v61, %[keep], v62, %[jkey]\n\t"                   /* dominant index key: (weight bits & ~63) | (63 - j) */ \
+    "v_sub_f32 %[T], %[T], v62\n\t" \
+    "v_max_u32 %[best], %[best], v61\n\t" \
+    "v_mov_b32 %[last], %[va]\n\t" \
+    "s_mov_b64 exec, -1\n" \
+    "Lskip" S "_%=:\n\t" \
+    "s_add_i32 %[jkey], %[jkey], -1\n\t" \
+    "v_add_u32 %[va], 16, %[va]\n\t" \
+    "s_cmp_lg_u32 %[jkey], %[jend]\n\t"
+#define EX4D_FWD_RARE(S) \
+    "Lrare" S "_%=:\n\t" \
+    "s_andn2_b64 %[live], %[live], %[stop]\n\t" \
+    "s_andn2_b64 %[ok], %[ok], %[stop]\n\t"                      /* the lanes that still add */ \
+    "s_cbranch_scc1 Ladd" S "_%=\n\t" \
+    "s_cmp_eq_u64 %[live], 0\n\t" \
+    "s_cbranch_scc1 Ldone_%=\n\t" \
+    "s_branch Lskip" S "_%=\n"
+
+template <bool FLOW, bool ASMLOOP>
 __device__ __forceinline__ void composite_fwd_body(
     int W, int H, int gx, int tile, int wave, const PixelGeom p,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -265,44 +317,79 @@ __device__ __forceinline__ void composite_fwd_body(
         asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(lds_base));
         int last_even = -1, last_odd = -1;     // LDS address of the pair whose even / odd entry contributed last
         uint32_t best_key = 0;
-        // one (pixel, staged Gaussian) pair per lane
-        auto pair = [&](const int j, const int off, int &last_addr) {
-            const f32x4 g0 = *(lds_float4_ptr)(uintptr_t)(va + off);
-            const f32x4 g1 = *(lds_float4_ptr)(uintptr_t)(va + off + 1024);
-            // CR/forward.cu:368-387 as one flat predicate; q2 = -power log2(e)
-            const float q2 = q2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
-            const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(-q2));
-            const float wgt_all = alpha * T;
-            const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
-            const lanemask ok = live & LANES(__float_as_uint(q2) <= __float_as_uint(g1.z));
-            const lanemask stop = ok & LANES(test_T < 0.0001f);
-            live &= ~stop;
-            const lanemask add = ok & ~stop;
-            if (add == 0) return;
-            // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
-            const f32x4 g2 = *(lds_float4_ptr)(uintptr_t)(va + off + 2048);
-            const float wgt = select_f(add, wgt_all, 0.f);
-            const f32x2 ww = { wgt, wgt };
-            Crg = __builtin_elementwise_fma((f32x2){ g2.x, g2.y }, ww, Crg);
-            Dacc = __builtin_elementwise_fma((f32x2){ g2.z, g2.w }, ww, Dacc);
-            C2 = __builtin_fmaf(g1.w, wgt, C2);
-            if (FLOW) { const f32x4 g3 = *(lds_float4_ptr)(uintptr_t)(va + off + 3072); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
-            // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
-            uint32_t key;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
-            best_key = best_key > key ? best_key : key;
-            T -= wgt;                                          // the contributing lanes' new transmittance
-            last_addr = select_i(add, (int)va, last_addr);
-        };
-        {
-            int j = 0;
-            for (; j + 1 < cnt; j += 2, va += 32) {
-                if (live == 0) break;
-                pair(j, 0, last_even);
-                if (live == 0) break;
-                pair(j + 1, 16, last_odd);
+        if (ASMLOOP && !FLOW) {
+            // Hand-scheduled walk (round 3): the compiler's version of this loop spends as many instructions on lane-mask and loop
+            // bookkeeping as on arithmetic and waits twice per entry for LDS.  Here: the next entry's operands are requested while the
+            // current one is evaluated (two register sets trade places), the contributing lanes are selected through EXEC (no selects,
+            // no wait-state padding), an entry no live lane reaches leaves after 9 VALU, and a saturating lane (rare) is handled off
+            // the common path.  Same operations on the same operands in the same order as the C++ walk below: same bits.
+            if (cnt > 0) {
+                uint32_t jkey = 63u;
+                const uint32_t jend = 63u - (uint32_t)cnt;
+                lanemask ok_m, stop_m;
+                int last_addr = -1;
+                asm volatile(
+                    "s_waitcnt lgkmcnt(0)\n\t"                      // nothing of the compiler's in flight: the counts below are this block's own
+                    "ds_read_b128 v[40:43], %[va]\n\t"
+                    "ds_read_b128 v[44:47], %[va] offset:1024\n"
+                    "Lloop_%=:\n\t"
+                    EX4D_FWD_ENTRY("a", "v[40:43]", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[48:51]", "v[52:55]", "v[40:41]", "v[42:43]")
+                    "s_cbranch_scc0 Ldone_%=\n\t"
+                    EX4D_FWD_ENTRY("b", "v[48:51]", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[40:43]", "v[44:47]", "v[48:49]", "v[50:51]")
+                    "s_cbranch_scc1 Lloop_%=\n\t"
+                    "s_branch Ldone_%=\n"
+                    EX4D_FWD_RARE("a")
+                    EX4D_FWD_RARE("b")
+                    "Ldone_%=:\n\t"
+                    "s_mov_b64 exec, -1\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : [T] "+v"(T), [crg] "+v"(Crg), [dacc] "+v"(Dacc), [c2] "+v"(C2), [best] "+v"(best_key), [last] "+v"(last_addr),
+                      [va] "+v"(va), [live] "+s"(live), [jkey] "+s"(jkey), [ok] "=&s"(ok_m), [stop] "=&s"(stop_m)
+                    : [fx] "v"(p.fx), [fy] "v"(p.fy), [keep] "v"(keep_hi), [thr] "s"(0.0001f), [jend] "s"(jend)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                      "v60", "v61", "v62", "v63", "vcc", "scc", "memory");
+                last_even = last_addr;
             }
-            if (j < cnt && live != 0) pair(j, 0, last_even);          // odd count: the last entry (a break above leaves live == 0)
+        } else {
+            // one (pixel, staged Gaussian) pair per lane
+            auto pair = [&](const int j, const int off, int &last_addr) {
+                const f32x4 g0 = *(lds_float4_ptr)(uintptr_t)(va + off);
+                const f32x4 g1 = *(lds_float4_ptr)(uintptr_t)(va + off + 1024);
+                // CR/forward.cu:368-387 as one flat predicate; q2 = -power log2(e)
+                const float q2 = q2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
+                const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(-q2));
+                const float wgt_all = alpha * T;
+                const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
+                const lanemask ok = live & LANES(__float_as_uint(q2) <= __float_as_uint(g1.z));
+                const lanemask stop = ok & LANES(test_T < 0.0001f);
+                live &= ~stop;
+                const lanemask add = ok & ~stop;
+                if (add == 0) return;
+                // CR/forward.cu:389-422 for all lanes: lanes outside `add` accumulate a zero weight
+                const f32x4 g2 = *(lds_float4_ptr)(uintptr_t)(va + off + 2048);
+                const float wgt = select_f(add, wgt_all, 0.f);
+                const f32x2 ww = { wgt, wgt };
+                Crg = __builtin_elementwise_fma((f32x2){ g2.x, g2.y }, ww, Crg);
+                Dacc = __builtin_elementwise_fma((f32x2){ g2.z, g2.w }, ww, Dacc);
+                C2 = __builtin_fmaf(g1.w, wgt, C2);
+                if (FLOW) { const f32x4 g3 = *(lds_float4_ptr)(uintptr_t)(va + off + 3072); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
+                // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
+                uint32_t key;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
+                best_key = best_key > key ? best_key : key;
+                T -= wgt;                                          // the contributing lanes' new transmittance
+                last_addr = select_i(add, (int)va, last_addr);
+            };
+            {
+                int j = 0;
+                for (; j + 1 < cnt; j += 2, va += 32) {
+                    if (live == 0) break;
+                    pair(j, 0, last_even);
+                    if (live == 0) break;
+                    pair(j + 1, 16, last_odd);
+                }
+                if (j < cnt && live != 0) pair(j, 0, last_even);          // odd count: the last entry (a break above leaves live == 0)
+            }
         }
         const int je = last_even < 0 ? -1 : (int)(((uint32_t)last_even - lds_base) >> 4);
         const int jo = last_odd < 0 ? -1 : (int)(((uint32_t)last_odd - lds_base) >> 4) + 1;
@@ -336,7 +423,7 @@ __device__ __forceinline__ void composite_fwd_body(
 
 // FLOW is a launch-time choice (the frame flag travels with the instance count's read-back): the flow-free kernel needs 43 VGPRs, the
 // one with both paths behind a run-time branch needed 66
-template <bool FLOW>
+template <bool FLOW, bool ASMLOOP>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
     int W, int H, int gx, int num_tiles,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -351,7 +438,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     tile_of_block(num_tiles, tile, quad);
     if (tile >= num_tiles) return;
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
-    composite_fwd_body<FLOW>(W, H, gx, tile, quad, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc,
+    composite_fwd_body<FLOW, ASMLOOP>(W, H, gx, tile, quad, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc,
                              out_flow, out_idx, qlist, qcount, lds);
 }
 
@@ -752,6 +839,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 
 }  // namespace
 
+void ex4d_set_fwd_asm(int on) { g_fwd_asm.store(on); }
+int ex4d_get_fwd_asm() { return g_fwd_asm.load(); }
+
 hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long));
@@ -767,10 +857,12 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
     const int slots = 8 * ((T + 7) / 8);
-#define FWD_LAUNCH(FLOW) hipLaunchKernelGGL(composite_fwd_kernel<FLOW>, dim3(4 * slots), dim3(64), 0, stream, \
+#define FWD_LAUNCH(FLOW) hipLaunchKernelGGL((composite_fwd_kernel<FLOW, ASM>), dim3(4 * slots), dim3(64), 0, stream, \
         prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg, \
         prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, qlist, qcount)
-    if (has_flow) FWD_LAUNCH(true); else FWD_LAUNCH(false);
+    if (has_flow) { constexpr bool ASM = false; FWD_LAUNCH(true); }
+    else if (g_fwd_asm.load(std::memory_order_relaxed)) { constexpr bool ASM = true; FWD_LAUNCH(false); }
+    else { constexpr bool ASM = false; FWD_LAUNCH(false); }
 #undef FWD_LAUNCH
     return hipGetLastError();
 }

@@ -104,6 +104,8 @@ hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, con
     const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
 
+void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled entry walk (default) or the compiler's loop
+int ex4d_get_fwd_asm();
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
