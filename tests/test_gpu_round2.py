@@ -493,3 +493,35 @@ def test_sh_direction_sums_prepared_by_the_forward_and_second_backward(hip_lib):
         r = ref[n] if n != "means2D" else raw["dL_dmeans2D"]
         scale = max(1.0, float(r.abs().max()))
         assert float((a - r).abs().max()) <= 1e-5 * scale and float((b - r).abs().max()) <= 1e-5 * scale, n
+
+
+def test_hand_scheduled_forward_walk_is_bit_identical_to_the_compiled_one(hip_lib):
+    """The compositing forward's entry walk exists twice: hand-scheduled inline asm (default, frames without flow) and the compiler's
+    loop (`composite_fwd_asm` = 0; also what frames with flow run).  Same operations on the same operands in the same order: every
+    output and the per-pixel state must agree bit for bit -- on a shallow scene, a deep-overlap scene (saturating pixels: the
+    rare path) and an image whose size is not a multiple of the tile."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("composite_fwd_asm") == 1
+    from ex4dgs_amd.scene import CONFIGS
+    odd = CONFIGS["cfg3"]._replace(name="cfg3 at 333x217", width=333, height=217, focal=180.0)
+    for cfg, P in (("cfg2", 20_000), ("cfg5", 30_000), (odd, 9_000)):
+        ins, st = h.scene_inputs(cfg, P=P, dir_scale=0.0)
+        a = h.gpu_forward_raw(ins, st)
+        _C.set_option("composite_fwd_asm", 0)
+        try:
+            b = h.gpu_forward_raw(ins, st)
+        finally:
+            _C.set_option("composite_fwd_asm", 1)
+        for k in ("color", "depth", "acc", "flow", "idx", "final_T", "n_contrib", "qcount"):
+            assert torch.equal(a[k], b[k]), (cfg, k)
+        assert float(a["final_T"].min()) < 1e-3 or cfg != "cfg5"          # the deep scene does saturate pixels
+        cfg = cfg if isinstance(cfg, str) else cfg.name
+        # the compacted lists agree on their valid prefixes
+        T = a["qcount"].shape[0]
+        ranges = a["ranges"].cpu().numpy().astype(np.int64)
+        qa, qb, qc = a["qlist"].cpu().numpy(), b["qlist"].cpu().numpy(), a["qcount"].cpu().numpy()
+        for t in range(0, T, max(1, T // 97)):
+            r0, r1 = ranges[t]
+            for q in range(4):
+                s0 = 4 * r0 + q * (r1 - r0)
+                assert np.array_equal(qa[s0: s0 + qc[t, q]], qb[s0: s0 + qc[t, q]]), (cfg, t, q)
