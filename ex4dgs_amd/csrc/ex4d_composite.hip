@@ -529,6 +529,56 @@ __device__ __forceinline__ float row_scan_add_asm(float x)
     return x;
 }
 
+// The same two scans with the wait states of their DPP steps (a DPP read needs two wait states behind the VALU write of its source:
+// `s_nop 1`, an instruction slot that does nothing) filled by independent work of the step: the colour dot product c . dL_dpixel beside
+// the product scan, the dcc-weighted sums (and, with depth / flow gradients, the depth term) beside the sum scan.  Same operations on
+// the same operands as the plain versions -- only their place in the instruction stream differs.
+__device__ __forceinline__ float row_scan_mul_with_dot(float x, float &dot, float ax, float ay, float az, float bx, float by, float bz)
+{
+    asm("v_mul_f32 %[d], %[ax], %[bx]\n\t"
+        "v_fmac_f32 %[d], %[ay], %[by]\n\t"
+        "v_mul_f32_dpp %[x], %[x], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32 %[d], %[az], %[bz]\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %[x], %[x], %[x] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %[x], %[x], %[x] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %[x], %[x], %[x] row_shr:8 row_mask:0xf bank_mask:0xf"
+        : [x] "+v"(x), [d] "=&v"(dot) : [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [bx] "v"(bx), [by] "v"(by), [bz] "v"(bz));
+    return x;
+}
+// sum scan of e; beside it: (c78.x, c78.y) += (p.x, p.y) d,  c9 += p.z d      (d = the low half of dd)
+__device__ __forceinline__ float row_scan_add_with_sums(float e, f32x2 &c78, float &c9, f32x2 pxy, float pz, f32x2 dd, float d)
+{
+    asm("v_pk_fma_f32 %[c78], %[pxy], %[dd], %[c78] op_sel_hi:[1,0,1]\n\t"
+        "v_fmac_f32 %[c9], %[pz], %[d]\n\t"
+        "v_add_f32_dpp %[e], %[e], %[e] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %[e], %[e], %[e] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %[e], %[e], %[e] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %[e], %[e], %[e] row_shr:8 row_mask:0xf bank_mask:0xf"
+        : [e] "+v"(e), [c78] "+v"(c78), [c9] "+v"(c9) : [pxy] "v"(pxy), [pz] "v"(pz), [dd] "v"(dd), [d] "v"(d));
+    return e;
+}
+// ... and with depth / flow gradients also (c1011.x, c1011.y) += (f.x, f.y) d,  c12 += f.z d,  gdT = gd T,  v2 += alpha gdT
+__device__ __forceinline__ float row_scan_add_with_sums_extra(float e, f32x2 &c78, float &c9, f32x2 pxy, float pz, f32x2 dd, float d,
+                                                              f32x2 &c1011, float &c12, f32x2 fxy, float fz, float &gdT, float gd, float T, float &v2, float alpha)
+{
+    asm("v_pk_fma_f32 %[c78], %[pxy], %[dd], %[c78] op_sel_hi:[1,0,1]\n\t"
+        "v_fmac_f32 %[c9], %[pz], %[d]\n\t"
+        "v_add_f32_dpp %[e], %[e], %[e] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_pk_fma_f32 %[c1011], %[fxy], %[dd], %[c1011] op_sel_hi:[1,0,1]\n\t"
+        "v_fmac_f32 %[c12], %[fz], %[d]\n\t"
+        "v_add_f32_dpp %[e], %[e], %[e] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32 %[gdT], %[gd], %[T]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[e], %[e], %[e] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32 %[v2], %[alpha], %[gdT]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[e], %[e], %[e] row_shr:8 row_mask:0xf bank_mask:0xf"
+        : [e] "+v"(e), [c78] "+v"(c78), [c9] "+v"(c9), [c1011] "+v"(c1011), [c12] "+v"(c12), [gdT] "=&v"(gdT), [v2] "+v"(v2)
+        : [pxy] "v"(pxy), [pz] "v"(pz), [dd] "v"(dd), [d] "v"(d), [fxy] "v"(fxy), [fz] "v"(fz), [gd] "v"(gd), [T] "v"(T), [alpha] "v"(alpha));
+    return e;
+}
+
 // Every lane accumulates the 13 Gaussian-centred partial sums of its 16 pixels in registers (15 VALU per step), the four pixel-slot
 // lanes of a Gaussian are added in the epilogue.  STATS = true additionally counts into g_bwd_stats (developer variant 8).
 // EXTRA = false: no pixel of the quadrant has an upstream depth or flow gradient (training on the image alone) -- the depth term of
@@ -607,34 +657,32 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         const float alpha_m = fminf(0.99f, w * G_m);
         const float inv = __builtin_amdgcn_rcpf(1.f - alpha_m);
         // T_i = T_carry * prod_{j <= i} inv_j   (the carry is row-uniform: every lane of the row read it from LDS)
-        const float T = pb.z * row_scan_mul(inv);
+        // (the colour dot product c . dL_dpixel is evaluated in the wait states of the product scan)
+        float cgp;
+        const float T = pb.z * row_scan_mul_with_dot(inv, cgp, g2.x, g2.y, g2.z, pa.x, pa.y, pa.z);
         const float dcc = alpha_m * T;                                  // dchannel_dcolor
-        // c . dL_dpixel (explicit chain: the compiler's own packing of the three products costs two moves and a packed multiply)
-        const float cgp = __builtin_fmaf(g2.z, pa.z, __builtin_fmaf(g2.y, pa.y, g2.x * pa.x));
         const float e = dcc * cgp;
-        // the carry slot holds Q = bgT - E (E = sum of e over everything behind this batch): one subtraction gives bgT - E_inclusive
-        const float Q = pb.w - row_scan_add_asm(e);
+        f32x2 dd;
+        dd.x = dcc;                                                     // (only the low half is read: op_sel_hi broadcasts it)
+        // the carry slot holds Q = bgT - E (E = sum of e over everything behind this batch): one subtraction gives bgT - E_inclusive;
+        // the dcc-weighted sums (v7..v9, and v10..v12, gdT = dL_ddepth T, v2 with depth / flow gradients) fill the scan's wait states
+        float gdT = 0.f, Ssum;
+        if (EXTRA) Ssum = row_scan_add_with_sums_extra(e, C78, c9, (f32x2){ pa.x, pa.y }, pa.z, dd, dcc, C1011, c12, (f32x2){ pc.x, pc.y }, pc.z, gdT, pa.w, T, v2, alpha_m);
+        else Ssum = row_scan_add_with_sums(e, C78, c9, (f32x2){ pa.x, pa.y }, pa.z, dd, dcc);
+        const float Q = pb.w - Ssum;
         // dL_dalpha, CR/backward.cu:592-662:  ((final_depth - dep) gdepth T + (c - accum_rec) . dL_dpixel) T + bgT / (1 - alpha).
         // With e inv = (c . dL_dpixel) T (inv - 1) the colour and background terms collapse to inv ((c . dL_dpixel) T + bgT - E)
         // (E inclusive); the depth flag (0 or 1) is folded into per-Gaussian constants: (final_depth - dep) flag = final_depth flag - dep flag
         float dLa = (cgp * T + Q) * inv;
-        float gdT = 0.f;
-        if (EXTRA) {
-            gdT = pa.w * T;                                             // dL_ddepth T; the flag of the dL_dmean2D.z sum is applied per Gaussian
-            dLa += ((pb.x * flagf - depflag) * gdT) * T;
-        }
+        if (EXTRA) dLa += ((pb.x * flagf - depflag) * gdT) * T;         // gdT: dL_ddepth T; the flag of the dL_dmean2D.z sum is applied per Gaussian
         const float s6 = G_m * dLa;                                     // dL_dG G / w
-        const f32x2 s66 = { s6, s6 }, dd = { dcc, dcc };
+        const f32x2 s66 = { s6, s6 };
         if (use_gacc) {
             // dL_dacc *= T for every contributor (CR/backward.cu:650), then dL_dopacity += G (dL_dalpha + dL_dacc)
             const float ga = pc.w * row_scan_mul(select_f(ok, T, 1.f));
             M56.y = __builtin_fmaf(G_m, ga, M56.y);
             wG[16 * s] = ga;
         }
-        if (EXTRA) v2 = __builtin_fmaf(alpha_m, gdT, v2);
-        C78 = __builtin_elementwise_fma((f32x2){ pa.x, pa.y }, dd, C78);
-        c9 = __builtin_fmaf(pa.z, dcc, c9);
-        if (EXTRA) { C1011 = __builtin_elementwise_fma((f32x2){ pc.x, pc.y }, dd, C1011); c12 = __builtin_fmaf(pc.z, dcc, c12); }
         if (MOMENTS) {
             // dx takes one value on the even steps and one on the odd steps of a batch: the sums over s6 dx, s6 dx^2, s6 dx dy
             // follow from S = sum s6 and Y = sum s6 dy kept separately for the two step parities
