@@ -212,6 +212,8 @@ size_t ex4d_backward_scratch_acc_offset(int32_t P);
  *   "composite_bwd_variant"  4 = (Gaussian, pixel-slot) lanes with register accumulation (default), 8 = 4 + developer statistics
  *                            (ex4d_debug_bwd_stats).  Round 1's per-pixel kernel (0) and the matrix-core formulation of the sums (2)
  *                            were measured slower and are no longer part of the library.
+ *   "composite_fwd_asm"      1 (default) = the flow-free compositing forward walks its staged entries with the hand-scheduled
+ *                            inline-asm loop, 0 = with the compiler's loop (what frames with a non-zero dir3D always run); bit-identical.
  *   "binning_tile_ids"       1 = also write the sorted tile ids (Ex4dBinningLayout.tile_ids); 0 (default) = that region is scratch of
  *                            the tile sort -- nothing downstream reads the ids, the tile ranges carry the same information.  (Images with
  *                            <= 256 or > 65536 tiles, or more than 2^(32 - ceil(tile bits / 2)) Gaussians, take the key/value sort,
