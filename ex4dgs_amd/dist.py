@@ -232,27 +232,37 @@ class SliceGather:
         self.rank = dist.get_rank(group) if (dist.is_initialized() and not local_only) else 0
         self.all = torch.zeros((self.world,) + tuple(shape), dtype=torch.float32, device=device)
         self.first = torch.zeros(self.world, dtype=torch.int32, device=device)
+        self.first_local = torch.zeros(1, dtype=torch.int32, device=device)
         self.pending = []
+        self._keep = None
         self._native = _backend(group) == "nccl"
 
     def launch(self, window, first):
         self.wait()
-        self.all[self.rank].copy_(window)
         self._first_host = int(first)
-        if self.world > 1:
+        if self.world == 1:
+            self.all[0].copy_(window)
+            return self
+        if self._native:
+            # RCCL: the send buffers are the caller's window and a one-element tensor of their own -- never views of the receive
+            # buffers (no reliance on in-place all-gather semantics; this branch has not run on hardware yet, DESIGN.md section 6)
+            src = window if window.is_contiguous() else window.contiguous()
+            self.first_local.fill_(int(first))
+            self._keep = src
+            self.pending = [dist.all_gather_into_tensor(self.all, src, group=self.group, async_op=True),
+                            dist.all_gather_into_tensor(self.first, self.first_local, group=self.group, async_op=True)]
+        else:
+            self.all[self.rank].copy_(window)
             self.first[self.rank] = int(first)
-            if self._native:
-                self.pending = [dist.all_gather_into_tensor(self.all, self.all[self.rank], group=self.group, async_op=True),
-                                dist.all_gather_into_tensor(self.first, self.first[self.rank:self.rank + 1], group=self.group, async_op=True)]
-            else:
-                self.pending = [dist.all_gather([self.all[r] for r in range(self.world)], self.all[self.rank].clone(), group=self.group, async_op=True),
-                                dist.all_gather([self.first[r:r + 1] for r in range(self.world)], self.first[self.rank:self.rank + 1].clone(), group=self.group, async_op=True)]
+            self.pending = [dist.all_gather([self.all[r] for r in range(self.world)], self.all[self.rank].clone(), group=self.group, async_op=True),
+                            dist.all_gather([self.first[r:r + 1] for r in range(self.world)], self.first[self.rank:self.rank + 1].clone(), group=self.group, async_op=True)]
         return self
 
     def wait(self):
         for w in self.pending:
             w.wait()
         self.pending = []
+        self._keep = None
 
     def windows(self, count):
         """[(first keyframe, count, device pointer of the [Nd, count, C] block)] for all ranks (call after wait()).  With more than
