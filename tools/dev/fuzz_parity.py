@@ -1,5 +1,5 @@
 """Dev script: randomised parity sweep of the rasterizer forward + backward against the oracle (small scenes, many shapes).
-Usage: python tools/dev/fuzz_parity.py [n_cases] [seed]"""
+Usage: python tools/dev/fuzz_parity.py [n_cases] [seed] [dir_scale]      (dir_scale 0 = frames without flow: the hand-scheduled forward walk)"""
 import sys, os, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -9,6 +9,7 @@ from ex4dgs_amd import _C
 _C.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dir_scale = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1
 fails = 0
 for i in range(n):
     W = int(rng.integers(17, 700)); H = int(rng.integers(17, 500))
@@ -17,7 +18,7 @@ for i in range(n):
                       sigma_px_med=float(rng.uniform(0.3, 25.0)), sigma_px_logstd=float(rng.uniform(0.2, 1.2)),
                       cxr=float(rng.choice([0.0, 0.15])), cyr=float(rng.choice([0.0, -0.1])), z_lo=4.5, z_hi=float(rng.uniform(10, 120)))
     deg = int(rng.integers(0, 4)); t = int(rng.integers(0, 300))
-    kw = dict(sh_degree=deg, t=t, grad_acc_zero=bool(rng.integers(0, 2)), seed=int(rng.integers(1 << 20)))
+    kw = dict(sh_degree=deg, t=t, grad_acc_zero=bool(rng.integers(0, 2)), seed=int(rng.integers(1 << 20)), dir_scale=dir_scale)
     if rng.random() < 0.3:
         kw["kernel_size"] = float(rng.choice([0.0, 0.05, 0.3]))
     if rng.random() < 0.3:
