@@ -8,9 +8,13 @@ tests check the kernel itself).  Per 8x8 pixel quadrant it does what the kernel 
         Q_i    = Q_carry - sum_{j<=i} alpha_j T_j (c_j . dL_dpixel)        (Q = bgT - E: the background term folded into the carry)
         dL_dalpha (colour + background) = inv_i ((c_i . dL_dpixel) T_i + Q_i)
         gacc_i = gacc_carry * prod_{j<=i} T_j                              (dL_dacc compounding)
-  * the exponent with the forward's contraction power2 = fma(dx, fma(dx, a', b' dy), (c' dy) dy), pixel-row terms hoisted;
-  * the position moments accumulated per STEP PARITY (dx is constant over the even and over the odd steps of a batch):
-        S_e/o = sum sG,  Y_e/o = sum sG dy,  V = sum sG dy^2   ->   sum sG dx = dxe S_e + dxo S_o, etc.
+  * the exponent as q2 = -power log2(e) = fma(dx, fma(dx, -a', -b' dy), -(c' dy) dy) (the forward's contraction with every operand
+    negated), pixel-row terms hoisted; the reference's two skips (power > 0, alpha < 1/255) as ONE unsigned compare of bit patterns
+    bits(q2) <= bits(log2(255 w)) (round 3);
+  * the position moments accumulated per STEP PARITY and per pixel-slot lane (dx is constant over the even and over the odd steps of a
+    batch), over s6 = G dL_dalpha, the factor w of sG = w s6 applied ONCE per batch and lane (round 3):
+        S_e/o = sum s6,  Y_e/o = sum s6 dy,  V = sum s6 dy^2   ->   sum sG dx = w (dxe S_e + dxo S_o), etc.;
+    the conic mix of dL_dmean2D per lane, then the four pixel-slot lanes of a Gaussian added.
 
     python tests/scan_backward_replay.py [cfg] [P]
 """
@@ -104,10 +108,13 @@ def run(cfg="cfg1", P=None, grad_acc_zero=False):
                 dx = (gxm[:, None] - fx[None]).astype(f32); dy = (gym[:, None] - fy[None]).astype(f32)
                 fma = lambda a_, b_, c_: (a_.astype(np.float64) * b_.astype(np.float64) + c_.astype(np.float64)).astype(f32)   # one rounding
                 bdy = (bp[:, None] * dy).astype(f32); cdydy = ((cp[:, None] * dy).astype(f32) * dy).astype(f32)
-                power2 = fma(dx, fma(dx, np.broadcast_to(ap[:, None], dx.shape), bdy), cdydy)
-                G = np.exp2(power2).astype(f32)
+                q2 = fma(dx, fma(dx, np.broadcast_to(-ap[:, None], dx.shape), -bdy), -cdydy)          # = -power2, bit for bit
+                G = np.exp2(-q2).astype(f32)
                 alpha = np.minimum(f32(0.99), w[:, None] * G).astype(f32)
-                ok = (ks[:, None] < lastc[None]) & (power2 <= 0) & ~(alpha < f32(1.0 / 255.0))
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tauq = np.log2((f32(255.0) * w).astype(f32)).astype(f32)
+                # one unsigned compare: a negative q2 (power > 0) has its sign bit set and fails; q2 > tauq <=> w 2^-q2 < 1/255
+                ok = (ks[:, None] < lastc[None]) & (np.ascontiguousarray(q2).view(np.uint32) <= np.ascontiguousarray(tauq).view(np.uint32)[:, None])
                 alpha_m = np.where(ok, alpha, f32(0)); G_m = np.where(ok, G, f32(0))
                 inv = (f32(1) / (f32(1) - alpha_m)).astype(f32)
                 Tn = (Tc[None] * scan_mul(inv)).astype(f32)                     # row-uniform carry times the identity-seeded scan
@@ -122,25 +129,27 @@ def run(cfg="cfg1", P=None, grad_acc_zero=False):
                 dLa = (dLa + ((fd[None] * flag[:, None] - depflag[:, None]) * gdT) * Tn).astype(f32)
                 gaccn = (gaccc[None] * scan_mul(np.where(ok, Tn, f32(1)))).astype(f32)
                 s6 = (G_m * dLa).astype(f32)
-                sG = (w[:, None] * s6).astype(f32)
                 s6g = (G_m * gaccn).astype(f32)
                 Tc, Qc, gaccc = Tn[-1].copy(), Q[-1].copy(), gaccn[-1].copy()
                 # pixel p = 4 s + g: step parity = (p >> 2) & 1; dx is one value on the even steps and one on the odd steps (per pixel slot g)
                 par = ((np.arange(64) >> 2) & 1).astype(bool)
                 out = np.zeros((n, 13), f32)
-                v0 = np.zeros(n, f32); v1 = np.zeros(n, f32); v3 = np.zeros(n, f32); v4 = np.zeros(n, f32)
-                for g_ in range(4):
+                for g_ in range(4):                                              # one pixel-slot lane of every Gaussian
                     slot = (np.arange(64) & 3) == g_
+                    SY = {}
                     for odd in (False, True):
                         m = slot & (par == odd)
-                        S = sG[:, m].sum(1, dtype=f32); Y = (sG[:, m] * dy[:, m]).sum(1, dtype=f32)
-                        dxc = dx[:, m][:, 0]                                     # constant over these 8 pixels
-                        v0 += dxc * S; v1 += Y; v3 += (dxc * dxc) * S; v4 += dxc * Y
-                V = (sG * (dy * dy).astype(f32)).sum(1, dtype=f32)
-                out[:, 0] = (f32(2) * ap) * v0 + bp * v1
-                out[:, 1] = (f32(2) * cp) * v1 + bp * v0
+                        SY[odd] = (s6[:, m].sum(1, dtype=f32), (s6[:, m] * dy[:, m]).sum(1, dtype=f32), dx[:, m][:, 0])     # S, Y, the 8 pixels' dx
+                    (Se, Ye, dxe), (So, Yo, dxo) = SY[False], SY[True]
+                    V = (s6[:, slot] * (dy[:, slot] * dy[:, slot]).astype(f32)).sum(1, dtype=f32)
+                    m0 = ((dxe * Se + dxo * So).astype(f32) * w).astype(f32)
+                    m1 = ((Ye + Yo).astype(f32) * w).astype(f32)
+                    out[:, 3] += (((dxe * dxe) * Se + (dxo * dxo) * So).astype(f32) * w).astype(f32)
+                    out[:, 4] += ((dxe * Ye + dxo * Yo).astype(f32) * w).astype(f32)
+                    out[:, 5] += (w * V).astype(f32)
+                    out[:, 0] += ((f32(2) * ap) * m0 + bp * m1).astype(f32)
+                    out[:, 1] += ((f32(2) * cp) * m1 + bp * m0).astype(f32)
                 out[:, 2] = (alpha_m * gdT).sum(1, dtype=f32) * flag
-                out[:, 3] = v3; out[:, 4] = v4; out[:, 5] = V
                 out[:, 6] = (s6 + s6g).sum(1, dtype=f32)
                 out[:, 7:10] = (dcc @ gp.T).astype(f32)
                 out[:, 10:13] = (dcc @ gflow.T).astype(f32)
