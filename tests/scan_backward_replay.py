@@ -113,8 +113,10 @@ def run(cfg="cfg1", P=None, grad_acc_zero=False):
                 alpha = np.minimum(f32(0.99), w[:, None] * G).astype(f32)
                 with np.errstate(divide="ignore", invalid="ignore"):
                     tauq = np.log2((f32(255.0) * w).astype(f32)).astype(f32)
-                # one unsigned compare: a negative q2 (power > 0) has its sign bit set and fails; q2 > tauq <=> w 2^-q2 < 1/255
-                ok = (ks[:, None] < lastc[None]) & (np.ascontiguousarray(q2).view(np.uint32) <= np.ascontiguousarray(tauq).view(np.uint32)[:, None])
+                # one unsigned compare: a negative q2 (power > 0) has its sign bit set and fails; q2 > tauq <=> w 2^-q2 < 1/255.  Gaussians with
+                # w < 1/255 (tauq < 0) never reach the kernel: the forward's cull drops them before staging (ex4d_preprocess.hip: tau = -inf)
+                ok = ((ks[:, None] < lastc[None]) & (w[:, None] >= f32(1.0 / 255.0))
+                      & (np.ascontiguousarray(q2).view(np.uint32) <= np.ascontiguousarray(tauq).view(np.uint32)[:, None]))
                 alpha_m = np.where(ok, alpha, f32(0)); G_m = np.where(ok, G, f32(0))
                 inv = (f32(1) / (f32(1) - alpha_m)).astype(f32)
                 Tn = (Tc[None] * scan_mul(inv)).astype(f32)                     # row-uniform carry times the identity-seeded scan
