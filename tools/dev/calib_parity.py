@@ -15,7 +15,7 @@ from ex4dgs_amd import _C, build      # noqa: E402
 
 build.build()
 _C.load()
-variants = [int(v) for v in sys.argv[1:]] or [0, 2, 1]
+variants = [int(v) for v in sys.argv[1:]] or [4, 8]          # (the round-1 / round-2 variants 0 and 2 were removed in round 3)
 cases = [("cfg1", None, 0), ("cfg2", 20000, 0), ("cfg3", 12000, 137), ("cfg5", 6000, 0), ("cfg2", None, 0)]
 for cfg, P, t in cases:
     ins, st = h.scene_inputs(cfg, P=P, t=t)
