@@ -37,15 +37,26 @@ HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s
 PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
-def pmc_counters_current(pmc):
-    """The committed counter file is only quoted while every kernel source still has the hash it was collected from."""
+# which source files a stage's kernels are compiled from (plus the shared internal header)
+STAGE_SOURCES = {"composite_fwd": "ex4d_composite.hip", "composite_bwd": "ex4d_composite.hip", "preprocess_fwd": "ex4d_preprocess.hip",
+                 "preprocess_bwd": "ex4d_preprocess.hip", "depth_sort": "ex4d_binning.hip", "tile_sort": "ex4d_binning.hip",
+                 "scan_tiles": "ex4d_binning.hip", "duplicate": "ex4d_binning.hip"}
+
+
+def pmc_counters_current(pmc, stage=None):
+    """The committed counter file is only quoted for a kernel while the sources that kernel is compiled from (its .hip file and the
+    shared internal header) still have the hashes the counters were collected from; stage=None checks every source."""
     import hashlib
     want = pmc.get("source_sha16")
     if not want:
         return False
     d = os.path.join(ROOT, "ex4dgs_amd", "csrc")
-    have = {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))}
-    return have == want
+    files = [f for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))]
+    if stage is not None:
+        if stage not in STAGE_SOURCES:
+            return False
+        files = [STAGE_SOURCES[stage], "ex4d_internal.h"]
+    return all(want.get(f) == hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest()[:16] for f in files)
 
 
 def frame_inputs(model, t, device):
@@ -509,7 +520,7 @@ def main():
     try:   # HBM bytes per launch from the rocprofv3 --pmc passes of this command, collected separately and committed (tools/pmc.sh)
         with open(os.path.join(ROOT, PMC_FILE)) as fh:
             pmc = json.load(fh)
-        pmc_ok = pmc_counters_current(pmc)
+        pmc_ok = pmc_counters_current(pmc, dom)
         if pmc_ok and args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
             valu_busy = pmc["kernels"][dom].get("valu_busy_frac")
