@@ -7,8 +7,10 @@
  -> optimizer step: replicated fused RAdam or the sharded one      scene/c_gaussian_model.py:430-449, train.py:250
 
 One view (camera, timestamp) per rank per step: views shard round-robin (dist.shard_views), parameters are replicated.  The
-attribute backward and the gradient exchange of frame i run on a side stream / the communicator's stream while frame i+1 is
-rasterized on the main stream, so on xGMI the exchange hides behind the next frame as far as its length allows.
+attribute backward and the gradient exchange of frame i run on a side stream / the communicator's stream: the four feature gradients
+(3/4 of the bytes) go on the wire before the attribute backward starts.  Without an optimizer the whole exchange hides behind the
+rasterization of frame i+1; with one (the default of the multi-GPU bench) it has to finish before the optimizer step at the top of step
+i+1 and is exposed except for the part beside the attribute backward.
 No CPU fallback: everything here needs the HIP library and a ROCm device.
 """
 import math

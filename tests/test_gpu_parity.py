@@ -21,7 +21,7 @@ _ORACLE_FWD = {}       # (cfg, P, t, degree) -> oracle forward of the unmodified
 
 def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, subpixel=None, seed=3, max_fragile_frac=2e-3, noise_orders=8, dir_scale=0.1, **fwd_over):
     """dir_scale = 0: every dir3D is zero, the caller's case (gaussian_renderer/__init__.py:66-70 passes the zero gradient trap) and
-    the one bench.py times -- the forward kernel then takes its flow-free, row-table variant; any other value exercises the flow path."""
+    the one bench.py times -- the flow-free forward kernel with the hand-scheduled entry walk is launched; any other value exercises the kernel with flow."""
     from oracle import oracle
     ins, st = h.scene_inputs(cfg, P=P, t=t, sh_degree=sh_degree, dir_scale=dir_scale)
     st.update(fwd_over)

@@ -62,7 +62,7 @@ def test_cfg3_full_size_1M_against_the_oracle(hip_lib):
 
 def test_cfg3_full_size_1M_library_defaults(hip_lib_defaults):
     """BASELINE config 3 at full size on the library's DEFAULT options = exactly what bench.py times, against
-    the oracle (dir3D = 0 like the bench and like render(): the forward kernel's flow-free row-table variant)."""
+    the oracle (dir3D = 0 like the bench and like render(): the flow-free forward kernel with the hand-scheduled entry walk)."""
     from ex4dgs_amd import _C
     assert _C.get_option("geom_debug_arrays") == 0 and _C.get_option("binning_tile_ids") == 0 and _C.get_option("composite_bwd_variant") == 4
     o, g, ob, gb, rep = _fwd_bwd("cfg3", t=137, max_fragile_frac=1e-2, dir_scale=0.0)      # zero dir3D: the kernels bench.py times
