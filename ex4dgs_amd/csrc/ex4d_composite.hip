@@ -15,11 +15,10 @@
 //     kept so n_contrib keeps the reference's meaning);
 //   * the 64 lanes then walk the compacted list with wave-uniform LDS broadcasts, one flat predicate per
 //     pair (no nested divergent branches: SALU mask traffic costs as much issue bandwidth as VALU here);
-//   * backward: same traversal in reverse, starting at the quadrant's deepest contributor instead of the
-//     list end; the 13 per-Gaussian partials of the 64 pixels are summed through the LDS pipe (13 stores, four
-//     16-byte reads per lane, two quad DPP adds -- instead of 13 x 64 float atomics or a register butterfly whose
-//     v_permlane swaps are ~9 issue cycles each) and leave the wave as ONE 13-lane atomic instruction onto a
-//     64-byte accumulator row.
+//   * backward: lanes = (Gaussian, pixel slot) -- batches of 16 list entries x 4 pixels per step, the per-pixel recurrences as
+//     16-lane DPP prefix scans with carries, the 13 per-Gaussian partial sums accumulated over TIME in registers, and one
+//     64-byte-row atomic instruction per 4 Gaussians (see "Compositing backward" below); it streams the forward's per-quadrant
+//     compacted lists (BinState::qlist) back to front, starting at the quadrant's deepest contributor.
 // Tiles are assigned to workgroups XCD-aware: workgroup b runs on XCD b % 8, so each XCD gets a
 // contiguous band of the screen and neighbouring tiles (which share Gaussians) hit the same L2.
 // Arithmetic follows the reference's expressions; FMA contraction is allowed here (results are compared
@@ -180,11 +179,15 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 //     in the pair loop and the larger footprint made it SLOWER (0.165 ms with 64 staging slots, 0.153 with 32);
 //   * tile-cooperative culling (one gather and four culls per entry and tile, per-quadrant queues, two barriers per 256 entries):
 //     0.192 ms -- a fifth of the list is all a tile ever reads, and the barriers serialise its four latency chains into one.
-// What stayed: the dominant index as ONE integer max of (weight bits & ~63) | (63 - j) -- the 6 low mantissa bits (7.6e-6 relative) give
-// way to the chunk position, larger for earlier entries: equal weights keep the first one like the reference's strict `>`, and two
-// weights closer than that are a near-tie the parity contract excludes (oracle: idx_margin < 1e-4); T (1 - alpha) as one fma and
-// T -= weight instead of a select; the two skips of the reference as one unsigned compare (q2_rows above); the pair loop unrolled by two
-// by hand (immediate LDS offsets).  Per staged Gaussian and pixel: 13 VALU before the decision, 12 more when a pixel contributes.
+// What stayed: T (1 - alpha) as one fma and T -= weight instead of a select; the two skips of the reference as one unsigned compare
+// (q2_rows above); the pair loop unrolled by two by hand (immediate LDS offsets).  Per staged Gaussian and pixel: 13 VALU before the
+// decision, 12 more when a pixel contributes.
+// The dominant index (CR/forward.cu:411-415: strict `>` on the full-precision weight alpha T, i.e. the FIRST entry attaining the
+// maximum) is exact (round 4; rounds 1-3 compared weights quantised to 26 bits).  A contributing weight lies in [1e-4 / 255, 0.99], so
+// its sign and the three high exponent bits are constant: `bits << 4` keeps all 28 significant bits and leaves 4 bits for the position
+// inside a GROUP of 16 staged entries (15 - j, larger for earlier entries: equal weights keep the first one).  Inside a group the
+// running best is one v_lshl_or_b32 + v_max_u32 per contributing pair; at the end of every group the group's best is folded into the
+// pixel's running (key, location) with the strict compare `key > (best_key | 15)` -- 4 VALU per 16 entries.
 // Every chunk's survivors are appended to the quadrant's compacted list (BinState::qlist) -- all the backward reads of the tile list.
 std::atomic<int> g_fwd_asm{1};      // compositing forward: hand-scheduled walk (1, default) or the compiler's (0)
 
@@ -231,7 +234,7 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
     "v_pk_fma_f32 %[crg], " G2RG ", v[62:63], %[crg] op_sel_hi:[1,0,1]\n\t" \
     "v_pk_fma_f32 %[dacc], " G2DA ", v[62:63], %[dacc] op_sel_hi:[1,0,1]\n\t" \
     "v_fmac_f32 %[c2], " CBLUE ", v62\n\t" \
-    "v_bfi_b32 v61, %[keep], v62, %[jkey]\n\t"                   /* dominant index key: (weight bits & ~63) | (63 - j) */ \
+    "v_lshl_or_b32 v61, v62, 4, %[jkey]\n\t"                     /* dominant index key: (weight bits << 4) | (15 - j mod 16), exact */ \
     "v_sub_f32 %[T], %[T], v62\n\t" \
     "v_max_u32 %[best], %[best], v61\n\t" \
     "v_mov_b32 %[last], %[va]\n\t" \
@@ -246,7 +249,7 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
     "s_andn2_b64 %[ok], %[ok], %[stop]\n\t"                      /* the lanes that still add */ \
     "s_cbranch_scc1 Ladd" S "_%=\n\t" \
     "s_cmp_eq_u64 %[live], 0\n\t" \
-    "s_cbranch_scc1 Ldone_%=\n\t" \
+    "s_cbranch_scc1 Ldead_%=\n\t" \
     "s_branch Lskip" S "_%=\n"
 
 template <bool FLOW, bool ASMLOOP>
@@ -270,11 +273,14 @@ __device__ __forceinline__ void composite_fwd_body(
     int consumed = 0;
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
-    float T = 1.0f, C2 = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f, max_vis = 0.f;
+    float T = 1.0f, C2 = 0.f, F0 = 0.f, F1 = 0.f, F2 = 0.f;
     f32x2 Crg = { 0.f, 0.f }, Dacc = { 0.f, 0.f };           // (C0, C1), (sum of depth weight, sum of weights)
     uint32_t last_contributor = 0;
     int32_t best = -1;
-    const uint32_t keep_hi = 0xFFFFFFC0u;     // (in a VGPR: v_bfi_b32 takes one scalar operand, the chunk position)
+    // dominant index (CR/forward.cu:411-415), exact: the hand-scheduled walk keeps the pixel's largest weight as the integer key
+    // (bits << 4) | (15 - position in its group of 16), the C++ walk as the float itself; both orders are the reference's strict `>`
+    uint32_t dom_key = 0;
+    float max_vis = 0.f;
     // LDS byte address of this wave's staging area (the low half of the flat address of a __shared__ object IS its LDS address)
     const uint32_t lds_base = (uint32_t)(uintptr_t)&L.q0[0];
 
@@ -316,50 +322,75 @@ __device__ __forceinline__ void composite_fwd_body(
         uint32_t va;
         asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(lds_base));
         int last_even = -1, last_odd = -1;     // LDS address of the pair whose even / odd entry contributed last
-        uint32_t best_key = 0;
+        int dom_j = -1;                        // staged entry that became the pixel's dominant contributor in this chunk (none: -1)
         if (ASMLOOP && !FLOW) {
             // Hand-scheduled walk (round 3): the compiler's version of this loop spends as many instructions on lane-mask and loop
             // bookkeeping as on arithmetic and waits twice per entry for LDS.  Here: the next entry's operands are requested while the
             // current one is evaluated (two register sets trade places), the contributing lanes are selected through EXEC (no selects,
             // no wait-state padding), an entry no live lane reaches leaves after 9 VALU, and a saturating lane (rare) is handled off
             // the common path.  Same operations on the same operands in the same order as the C++ walk below: same bits.
+            // Round 4: the entries run in groups of 16 (jkey = 15 .. 0 is both the loop counter and the low bits of the dominant-index
+            // key); at the end of a group its best key is folded into (dom_key, dom_loc) with the reference's strict compare, the
+            // operand prefetch runs on across the group boundary (a full group ends on set b, the next one starts on set a).
             if (cnt > 0) {
-                uint32_t jkey = 63u;
-                const uint32_t jend = 63u - (uint32_t)cnt;
+                uint32_t jkey, jend, rem = (uint32_t)cnt;
                 lanemask ok_m, stop_m;
                 int last_addr = -1;
+                uint32_t best_key = 0, dom_loc = 0;
                 asm volatile(
                     "s_waitcnt lgkmcnt(0)\n\t"                      // nothing of the compiler's in flight: the counts below are this block's own
                     "ds_read_b128 v[40:43], %[va]\n\t"
                     "ds_read_b128 v[44:47], %[va] offset:1024\n"
+                    "Lgroup_%=:\n\t"
+                    "s_sub_i32 %[jend], 15, %[rem]\n\t"
+                    "s_max_i32 %[jend], %[jend], -1\n\t"            // the group's last key - 1: -1 for a full group
+                    "s_mov_b32 %[jkey], 15\n"
                     "Lloop_%=:\n\t"
                     EX4D_FWD_ENTRY("a", "v[40:43]", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[48:51]", "v[52:55]", "v[40:41]", "v[42:43]")
-                    "s_cbranch_scc0 Ldone_%=\n\t"
+                    "s_cbranch_scc0 Lgdone_%=\n\t"
                     EX4D_FWD_ENTRY("b", "v[48:51]", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[40:43]", "v[44:47]", "v[48:49]", "v[50:51]")
-                    "s_cbranch_scc1 Lloop_%=\n\t"
+                    "s_cbranch_scc1 Lloop_%=\n"
+                    "Lgdone_%=:\n\t"                                // fold the group's best into the pixel's: strict > on the 28 weight bits
+                    "v_or_b32 v60, 15, %[dkey]\n\t"
+                    "v_cmp_gt_u32_e64 %[ok], %[best], v60\n\t"
+                    "s_add_i32 %[rem], %[rem], -16\n\t"
+                    "s_nop 1\n\t"                                   // VALU-written SGPR pair read as a lane mask: 2 wait states
+                    "v_cndmask_b32_e64 %[dkey], %[dkey], %[best], %[ok]\n\t"
+                    "v_cndmask_b32_e64 %[dloc], %[dloc], %[va], %[ok]\n\t"      // (va: the address behind the group's last entry)
+                    "v_mov_b32 %[best], 0\n\t"
+                    "s_cmp_gt_i32 %[rem], 0\n\t"
+                    "s_cbranch_scc1 Lgroup_%=\n\t"
                     "s_branch Ldone_%=\n"
                     EX4D_FWD_RARE("a")
                     EX4D_FWD_RARE("b")
+                    "Ldead_%=:\n\t"                                 // no live lane left: fold what the group has, then leave
+                    "v_add_u32 %[va], 16, %[va]\n\t"
+                    "s_mov_b32 %[rem], 0\n\t"
+                    "s_branch Lgdone_%=\n"
                     "Ldone_%=:\n\t"
                     "s_mov_b64 exec, -1\n\t"
                     "s_waitcnt lgkmcnt(0)"
                     : [T] "+v"(T), [crg] "+v"(Crg), [dacc] "+v"(Dacc), [c2] "+v"(C2), [best] "+v"(best_key), [last] "+v"(last_addr),
-                      [va] "+v"(va), [live] "+s"(live), [jkey] "+s"(jkey), [ok] "=&s"(ok_m), [stop] "=&s"(stop_m)
-                    : [fx] "v"(p.fx), [fy] "v"(p.fy), [keep] "v"(keep_hi), [thr] "s"(0.0001f), [jend] "s"(jend)
+                      [dkey] "+v"(dom_key), [dloc] "+v"(dom_loc), [va] "+v"(va), [live] "+s"(live), [rem] "+s"(rem),
+                      [jkey] "=&s"(jkey), [jend] "=&s"(jend), [ok] "=&s"(ok_m), [stop] "=&s"(stop_m)
+                    : [fx] "v"(p.fx), [fy] "v"(p.fy), [thr] "s"(0.0001f)
                     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
                       "v60", "v61", "v62", "v63", "vcc", "scc", "memory");
                 last_even = last_addr;
+                // dom_loc = the address behind the last entry of the group that holds the new dominant contributor (0: none in this chunk)
+                if (dom_loc != 0u) dom_j = (int)((((dom_loc - 16u - lds_base) >> 4) & ~15u) + 15u - (dom_key & 15u));
             }
         } else {
             // one (pixel, staged Gaussian) pair per lane
-            auto pair = [&](const int j, const int off, int &last_addr) {
+            int dom_addr = -1;                 // LDS address of the entry that became the dominant contributor in this chunk
+            auto pair = [&](const int off, int &last_addr) {
                 const f32x4 g0 = *(lds_float4_ptr)(uintptr_t)(va + off);
                 const f32x4 g1 = *(lds_float4_ptr)(uintptr_t)(va + off + 1024);
                 // CR/forward.cu:368-387 as one flat predicate; q2 = -power log2(e)
                 const float q2 = q2_of(g0.x - p.fx, g0.y - p.fy, g0.z, g0.w, g1.x);
                 const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(-q2));
+                const float test_T = __builtin_fmaf(-T, alpha, T);   // T (1 - alpha), CR/forward.cu:383, as the asm walk's one fused multiply-add
                 const float wgt_all = alpha * T;
-                const float test_T = T - wgt_all;                 // T (1 - alpha), CR/forward.cu:383 (one fused multiply-add)
                 const lanemask ok = live & LANES(__float_as_uint(q2) <= __float_as_uint(g1.z));
                 const lanemask stop = ok & LANES(test_T < 0.0001f);
                 live &= ~stop;
@@ -373,10 +404,10 @@ __device__ __forceinline__ void composite_fwd_body(
                 Dacc = __builtin_elementwise_fma((f32x2){ g2.z, g2.w }, ww, Dacc);
                 C2 = __builtin_fmaf(g1.w, wgt, C2);
                 if (FLOW) { const f32x4 g3 = *(lds_float4_ptr)(uintptr_t)(va + off + 3072); F0 += g3.x * wgt; F1 += g3.y * wgt; F2 += g3.z * wgt; }
-                // dominant index (CR/forward.cu:411-415): max over (quantised weight, earlier entry first)
-                uint32_t key;
-                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(key) : "v"(keep_hi), "v"(wgt), "s"(63 - j));
-                best_key = best_key > key ? best_key : key;
+                // dominant index (CR/forward.cu:411-415): strict > on the weight (lanes outside `add` carry a zero weight: never larger)
+                const lanemask better = LANES(wgt > max_vis);
+                max_vis = fmaxf(max_vis, wgt);
+                dom_addr = select_i(better, (int)va + off, dom_addr);
                 T -= wgt;                                          // the contributing lanes' new transmittance
                 last_addr = select_i(add, (int)va, last_addr);
             };
@@ -384,21 +415,19 @@ __device__ __forceinline__ void composite_fwd_body(
                 int j = 0;
                 for (; j + 1 < cnt; j += 2, va += 32) {
                     if (live == 0) break;
-                    pair(j, 0, last_even);
+                    pair(0, last_even);
                     if (live == 0) break;
-                    pair(j + 1, 16, last_odd);
+                    pair(16, last_odd);
                 }
-                if (j < cnt && live != 0) pair(j, 0, last_even);          // odd count: the last entry (a break above leaves live == 0)
+                if (j < cnt && live != 0) pair(0, last_even);          // odd count: the last entry (a break above leaves live == 0)
             }
+            if (dom_addr >= 0) dom_j = (int)(((uint32_t)dom_addr - lds_base) >> 4);
         }
         const int je = last_even < 0 ? -1 : (int)(((uint32_t)last_even - lds_base) >> 4);
         const int jo = last_odd < 0 ? -1 : (int)(((uint32_t)last_odd - lds_base) >> 4) + 1;
         const int last_j = je > jo ? je : jo;
         if (last_j >= 0) last_contributor = L.it[last_j].y + 1;
-        if (best_key > 63u) {
-            const float wq = __uint_as_float(best_key & keep_hi);
-            if (wq > max_vis) { max_vis = wq; best = (int32_t)L.it[63 - (int)(best_key & 63u)].x; }
-        }
+        if (dom_j >= 0) best = (int32_t)L.it[dom_j].x;
         wave_lds_sync();
     }
     if (lane == 0) qcount[4 * tile + wave] = (uint32_t)consumed;

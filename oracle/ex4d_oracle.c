@@ -448,8 +448,10 @@ void ex4d_oracle_render_fwd(
      * weight alpha*T it would have had (alpha ~ 1/255 at the alpha threshold, <= min(0.99, opacity) at power ~ 0), a flipped
      * termination test (CR/forward.cu:383-387) frees or drops everything behind it, which carries at most the transmittance T
      * at that point.  |delta colour| <= flip_w * 2 max|c| (the flipped pair itself plus the rescaling of everything behind it). */
-    /* idx_margin (optional, test instrumentation): per pixel, the smallest relative difference of any "alpha*T > max_vis"
-     * comparison that decides the dominant index: an argmax over float weights swaps on 1-ulp differences when two weights tie */
+    /* idx_margin (optional, test instrumentation): per pixel, the relative gap (w1 - w2) / w1 between the largest blending weight
+     * alpha*T and the runner-up.  The dominant index is the FIRST entry attaining the maximum (strict `>` against the running
+     * maximum, CR/forward.cu:411-415), so it can only differ between two float evaluations of the weights (expf vs v_exp_f32,
+     * T (1 - alpha) vs T - alpha T) where that gap is within their rounding -- a band of ~1e-6, not the 1e-4 of the decisions. */
     (void)min_depth;
     const int gx = (W + BLOCK_X - 1) / BLOCK_X;
     for (int py = 0; py < H; py++)
@@ -466,7 +468,7 @@ void ex4d_oracle_render_fwd(
             float C[3] = { 0, 0, 0 };
             float Dm = 0.0f, acc = 0.0f, max_vis = 0.0f;
             float F[3] = { 0, 0, 0 };
-            float frag = 1.0f, imarg = 1.0f, flipw = 0.0f;
+            float frag = 1.0f, flipw = 0.0f, top1 = 0.0f, top2 = 0.0f;
             int done = 0;
             /* toDo is a signed int in the reference; r1 >= r0 always */
             for (uint32_t k = r0; k < r1 && !done; k++) {
@@ -502,8 +504,9 @@ void ex4d_oracle_render_fwd(
                 acc += alpha * T;
                 for (int ch = 0; ch < 3; ch++) F[ch] += dir3D[id * 3 + ch] * alpha * T;
                 if (idx_margin) {
-                    const float wv = alpha * T, big = fmaxf(wv, max_vis);
-                    if (big > 0.0f) { const float m = fabsf(wv - max_vis) / big; if (m < imarg) imarg = m; }
+                    const float wv = alpha * T;
+                    if (wv > top1) { top2 = top1; top1 = wv; }
+                    else if (wv > top2) top2 = wv;
                 }
                 if (alpha * T > max_vis) { max_vis = alpha * T; out_idx[pix_id] = (int32_t)id; }
                 T = test_T;
@@ -520,7 +523,7 @@ void ex4d_oracle_render_fwd(
             out_acc[pix_id] = acc;
             for (int ch = 0; ch < 3; ch++) out_flow[(size_t)ch * H * W + pix_id] = F[ch];
             if (fragile) fragile[pix_id] = frag;
-            if (idx_margin) idx_margin[pix_id] = imarg;
+            if (idx_margin) idx_margin[pix_id] = top1 > 0.0f ? (top1 - top2) / top1 : 1.0f;
             if (flip_w) flip_w[pix_id] = flipw;
         }
 }
@@ -544,8 +547,16 @@ void ex4d_oracle_render_bwd(
     float *dL_dmean2D /*[P,3]*/, float *dL_dconic2D /*[P,4]*/, float *dL_ddir /*[P,3]*/,
     float *dL_dopacity /*[P]*/, float *dL_dcolors /*[P,3]*/,
     double *sum13, double *abs13,
-    const uint32_t *pixel_order /* may be NULL: row-major */)
+    const uint32_t *pixel_order /* may be NULL: row-major */,
+    const float *dstate /* [3,H,W] |delta out_depth|, |delta out_acc|, |delta final_T| per pixel; may be NULL */,
+    double *state13 /* [P,13]; may be NULL */)
 {
+    /* dstate / state13 (optional, test instrumentation): the backward consumes the forward's per-pixel state (out_depth, out_acc,
+     * final_T).  Two forward evaluations differ in that state by rounding, and the backward AMPLIFIES the difference where a term is a
+     * small difference of large ones -- (final_depth - depth) dL_ddepth / acc at small acc, CR/backward.cu:535-541, :603-613.
+     * Given the per-pixel absolute differences of the two states, state13 accumulates the first-order bound
+     * sum_pixels |d term / d state| |delta state| per accumulator: what an END-TO-END comparison (own forward -> own backward on both
+     * sides) may differ by on top of the shared-state bound. */
     /* pixel_order (optional, test instrumentation): a permutation of the pixel ids.  The reference's threads (one per pixel) add
      * their terms with float atomicAdd (CR/backward.cu:613-679): the order in which the terms of different pixels reach one
      * accumulator is arbitrary and differs from run to run.  Replaying the pixel loop in several random orders measures the
@@ -587,6 +598,14 @@ void ex4d_oracle_render_bwd(
             }
             float dL_dacc = 0;
             if (acc > 0.0f) dL_dacc = dL_daccs[pix_id];
+            /* relative state differences of this pixel (first-order sensitivity bookkeeping, see above) */
+            double e_fd = 0.0, e_A = 0.0, e_T = 0.0, n_gacc = 0.0;
+            if (dstate && state13) {
+                e_fd = (double)dstate[pix_id];                                             /* absolute: enters as |delta final_depth| */
+                e_A = acc > 0.0f ? (double)dstate[(size_t)H * W + pix_id] / (double)acc : 0.0;
+                e_T = T_final > 0.0f ? (double)dstate[(size_t)2 * H * W + pix_id] / (double)T_final : 0.0;
+            }
+#define STATE(k, mag) do { if (dstate && state13) state13[13 * (size_t)global_id + (k)] += (mag); } while (0)
 
             float accum_rec[3] = { 0, 0, 0 };
             float dL_dpixel[3];
@@ -613,9 +632,12 @@ void ex4d_oracle_render_bwd(
                 float dL_dalpha = 0.0f;
 
                 const float dep = depths[global_id];
+                double s_alpha = 0.0;        /* bound on |delta dL_dalpha| (before the factor T below) */
                 if ((dep > min_depth) & (alpha * T > 0.0f)) {
                     ACC(&dL_dmean2D[3 * (size_t)global_id + 2], 2, dL_ddepth * dchannel_dcolor);
                     dL_dalpha += (final_depth - dep) * dL_ddepth * T;
+                    STATE(2, fabs((double)dL_ddepth * dchannel_dcolor) * (e_A + e_T));
+                    s_alpha += (e_fd + fabs((double)final_depth - dep) * (e_A + e_T)) * fabs((double)dL_ddepth) * T;
                 }
                 for (int ch = 0; ch < 3; ch++) {
                     const float c = colors[global_id * 3 + ch];
@@ -624,18 +646,24 @@ void ex4d_oracle_render_bwd(
                     const float dL_dchannel = dL_dpixel[ch];
                     dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
                     ACC(&dL_dcolors[global_id * 3 + ch], 7 + ch, dchannel_dcolor * dL_dchannel);
+                    STATE(7 + ch, fabs((double)dchannel_dcolor * dL_dchannel) * e_T);
                 }
                 ACC(&dL_ddir[global_id * 3 + 0], 10, dchannel_dcolor * dL_dflow[0]);
                 ACC(&dL_ddir[global_id * 3 + 1], 11, dchannel_dcolor * dL_dflow[1]);
                 ACC(&dL_ddir[global_id * 3 + 2], 12, dchannel_dcolor * dL_dflow[2]);
+                for (int ch = 0; ch < 3; ch++) STATE(10 + ch, fabs((double)dchannel_dcolor * dL_dflow[ch]) * (e_A + e_T));
 
+                /* every part of dL_dalpha carries one more factor T (relative difference e_T) from here on */
+                s_alpha = (s_alpha + fabs((double)dL_dalpha) * e_T) * T;
                 dL_dalpha *= T;
                 dL_dacc *= T;
+                n_gacc += 1.0;               /* dL_dacc = upstream x the product of n_gacc transmittances, each proportional to final_T */
                 last_alpha = alpha;
 
                 float bg_dot_dpixel = 0;
                 for (int i = 0; i < 3; i++) bg_dot_dpixel += bg_color[i] * dL_dpixel[i];
                 dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                s_alpha += fabs((double)(-T_final / (1.f - alpha)) * bg_dot_dpixel) * e_T;
 
                 const float dL_dG = con_o[3] * dL_dalpha;
                 const float gdx = G * dx;
@@ -652,7 +680,17 @@ void ex4d_oracle_render_bwd(
                 ACC(&dL_dconic2D[4 * (size_t)global_id + 3], 5, -0.5f * gdy * dy * dL_dG);
                 ACC(&dL_dopacity[global_id], 6, G * dL_dalpha);
                 ACC(&dL_dopacity[global_id], 6, G * dL_dacc);
+                if (dstate && state13) {
+                    const double s_G = fabs((double)con_o[3]) * s_alpha;          /* bound on |delta dL_dG| */
+                    STATE(0, s_G * (fabs((double)gdx * con_o[0]) + fabs((double)gdy * con_o[1])) * ddelx_dx);
+                    STATE(1, s_G * (fabs((double)gdy * con_o[2]) + fabs((double)gdx * con_o[1])) * ddely_dy);
+                    STATE(3, 0.5 * fabs((double)gdx * dx) * s_G);
+                    STATE(4, 0.5 * fabs((double)gdx * dy) * s_G);
+                    STATE(5, 0.5 * fabs((double)gdy * dy) * s_G);
+                    STATE(6, (double)G * s_alpha + fabs((double)G * dL_dacc) * n_gacc * e_T);
+                }
             }
+#undef STATE
         }
 #undef ACC
 #undef ACCM

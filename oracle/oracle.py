@@ -153,11 +153,14 @@ def forward(means3D, dir3D, opacities, *, shs=None, colors_precomp=None, scales=
     return out
 
 
-def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True, pixel_order=None, stage=True):
+def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True, pixel_order=None, stage=True, state_delta=None):
     """fwd = dict returned by forward().  Returns the nine tensors of
     RasterizeGaussiansBackwardCUDA (rasterize_points.cu:233) plus internals.
     pixel_order: optional permutation of the H*W pixel ids -- the order in which the pixels' terms reach the float32 accumulators
-    (the reference's atomicAdd order is arbitrary; see backward_noise).  stage=False stops after the compositing backward."""
+    (the reference's atomicAdd order is arbitrary; see backward_noise).  stage=False stops after the compositing backward.
+    state_delta: optional (|delta out_depth|, |delta out_acc|, |delta final_T|) per pixel, [H,W] each -- how far ANOTHER forward
+    evaluation's per-pixel state lies from fwd's; res['state13'] then holds the first-order bound on what that difference moves in
+    each of the 13 accumulators (the conditioning of the backward with respect to the forward state, e.g. dL_ddepth / acc)."""
     L = lib()
     P, W, H, M, D = fwd["P"], fwd["W"], fwd["H"], fwd["M"], fwd["D"]
     res = dict(
@@ -176,13 +179,19 @@ def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True, p
     colors = i["colors_precomp"] if i["colors_precomp"] is not None else fwd["rgb"]
     res["sum13"] = np.zeros((P, 13), np.float64) if want_sums else None
     res["abs13"] = np.zeros((P, 13), np.float64) if want_sums else None
+    dstate = None
+    res["state13"] = None
+    if state_delta is not None:
+        dstate = np.ascontiguousarray(np.stack([np.abs(_np(x, np.float32)).reshape(H, W) for x in state_delta]), dtype=np.float32)
+        res["state13"] = np.zeros((P, 13), np.float64)
     L.ex4d_oracle_render_bwd(
         C.c_int(W), C.c_int(H), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(i["sub"]), _p(i["bg"]),
         _p(fwd["means2D"]), _p(fwd["conic_opacity"]), _p(colors), _p(fwd["depths"]),
         _p(fwd["depth"]), _p(fwd["acc"]), C.c_float(i["min_depth"]), C.c_float(i["max_depth"]),
         _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(gc), _p(gd), _p(gf), _p(ga),
         _p(res["dL_dmeans2D"]), _p(res["dL_dconic"]), _p(res["dL_ddir"]), _p(res["dL_dopacity"]), _p(res["dL_dcolors"]),
-        _p(res["sum13"]), _p(res["abs13"]), _p(None if pixel_order is None else np.ascontiguousarray(pixel_order, dtype=np.uint32)))
+        _p(res["sum13"]), _p(res["abs13"]), _p(None if pixel_order is None else np.ascontiguousarray(pixel_order, dtype=np.uint32)),
+        _p(dstate), _p(res["state13"]))
     if stage:
         preprocess_backward(fwd, res)
     return res

@@ -137,6 +137,46 @@ def test_oracle_backward_quirk_terms_match_independent_closed_form():
     assert np.abs(b_all["sum13"][:, 6] - b_no_acc["sum13"][:, 6]).max() > 1e-3
 
 
+def test_oracle_state_sensitivity_bounds_a_perturbed_forward_state():
+    """oracle.backward(state_delta=...) -> state13: the first-order bound on what a difference in the forward's per-pixel state
+    (out_depth, out_acc, final_T) moves in each accumulator -- the modelled part of the END-TO-END gradient bar (the 1/acc
+    conditioning of dL_ddepth / acc, CR/backward.cu:535-541, :603-613).  Checked directly: run the backward on the state and on
+    randomly perturbed states (relative 3e-7 .. 3e-5, the size forward rounding has), the double-precision sums must move by at most
+    state13 (+ second order), and for the ill-conditioned depth channel the bound must not be slack by more than ~an order."""
+    from oracle import oracle
+    ins, st = _small_scene(P=300, size=64)
+    ins["opacities"] = ins["opacities"] * 0.012         # faint Gaussians: many pixels with acc ~ 0.01 .. 0.1
+    o = h.oracle_forward(ins, st)
+    H, W = st["image_height"], st["image_width"]
+    assert 0 < np.median(o["acc"][o["acc"] > 0]) < 0.3
+    g0 = torch.Generator().manual_seed(3)
+    solid = torch.from_numpy(o["fragile"] > 1e-4)
+    gc = torch.randn(3, H, W, generator=g0) * solid[None]
+    gd = torch.randn(1, H, W, generator=g0) * solid[None]
+    gf = torch.randn(3, H, W, generator=g0) * solid[None]
+    ga = torch.randn(1, H, W, generator=g0) * solid[None]
+    base = oracle.backward(o, gc, gd, gf, ga, stage=False)
+    rng = np.random.default_rng(0)
+    for rel in (3e-7, 3e-6, 3e-5):
+        pert = dict(o)
+        for k in ("depth", "acc", "final_T"):
+            pert[k] = (o[k].astype(np.float64) * (1.0 + rel * rng.uniform(-1, 1, o[k].shape))).astype(np.float32)
+        delta = [np.abs(pert[k].astype(np.float64) - o[k].astype(np.float64)).reshape(H, W) for k in ("depth", "acc", "final_T")]
+        b0 = oracle.backward(o, gc, gd, gf, ga, stage=False, state_delta=delta)
+        b1 = oracle.backward(pert, gc, gd, gf, ga, stage=False)
+        moved = np.abs(b1["sum13"] - base["sum13"])
+        bound = b0["state13"]
+        assert np.array_equal(b0["sum13"], base["sum13"])            # the instrumentation does not change the result
+        # first order + float32 evaluation noise of the two runs (a few ulp of the sum of |terms|) + second order
+        slack = 1.05 * bound + 8 * 2.0 ** -24 * base["abs13"] + 1e-9
+        assert (moved <= slack).all(), (rel, float((moved / slack).max()), np.unravel_index((moved / slack).argmax(), moved.shape))
+        # not vacuous: on the accumulators dL_dalpha feeds, the worst row moves by a sizeable share of its bound
+        live = bound[:, 1] > 0
+        assert live.sum() > 50 and (moved[live, 1] / bound[live, 1]).max() > 0.05, rel
+        # and the amplification is real: the y-gradient moves by far more than `rel` of its magnitude somewhere
+        assert (moved[:, 1] / (rel * (np.abs(base["sum13"][:, 1]) + 1e-12)))[live].max() > 3.0
+
+
 def test_oracle_sh_matches_reference_eval_sh_golden():
     """SH->RGB of the oracle (CR/forward.cu:20-71 restated) vs outputs of the reference's utils/sh_utils.eval_sh."""
     from oracle import oracle

@@ -55,10 +55,13 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     gb = h.gpu_backward_raw(ins, g, grads)
     rep.update(h.compare_backward(ob, gb, o, noise=noise, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} (oracle backward on the GPU forward's state)"))
     # end to end: oracle(forward -> backward) against GPU(forward -> backward), nothing shared but the inputs.  The oracle's own
-    # forward state differs from the GPU's by forward rounding (<= 1e-5, checked above), which dL_dalpha amplifies through
-    # (final_depth - depth) dL_ddepth / acc: bound 3e-5 instead of 1e-5
-    ob_e2e = oracle.backward(o, *grads)
-    h.compare_backward(ob_e2e, gb, o, atol=3e-5, k_eps=256.0, rel_tol=3e-5, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} END-TO-END")
+    # forward state differs from the GPU's by forward rounding (<= 1e-5, checked above), which the backward amplifies where a term is
+    # ill-conditioned in that state -- (final_depth - depth) dL_ddepth / acc at small acc.  Round 4: that amplification is MODELLED,
+    # not absorbed into a wider bar: the oracle's backward takes the measured per-pixel state differences and returns the first-order
+    # bound on what they move per accumulator (state13); the bars are the shared-state ones (1e-5, 64 half-ulps) + 2 x state13.
+    dstate = [np.abs(o[k].astype(np.float64) - h.to_np(g[k]).astype(np.float64)).astype(np.float32).reshape(H, W) for k in ("depth", "acc", "final_T")]
+    ob_e2e = oracle.backward(o, *grads, state_delta=dstate)
+    rep["e2e"] = h.compare_backward(ob_e2e, gb, o, extra13=2.0 * ob_e2e["state13"], tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} END-TO-END")
     # per-Gaussian backward stage in isolation: feed the GPU's own accumulators to the oracle's stage
     acc = h.acc16_in_reference_units(gb["acc16"], o["W"], o["H"], conic=o["conic_opacity"])
     res = {k: np.zeros_like(v) for k, v in ob.items() if isinstance(v, np.ndarray) and k.startswith("dL_")}
@@ -791,19 +794,15 @@ def test_edge_cases_of_the_fused_training_path(hip_lib):
 
 
 @pytest.mark.gpu
-def test_randomised_parity_sweep(hip_lib):
-    """16 random scenes (image sizes 17..700, 1..6000 Gaussians, footprints 0.3..25 px, SH degrees 0-3, static/dynamic,
-    off-centre projection, kernel sizes, scale modifiers, subpixel offsets) through the full forward + backward comparison.
-    tools/dev/fuzz_parity.py is the same sweep with more cases (800 random cases over four seeds pass)."""
-    import runpy
-    argv = sys.argv
-    try:
-        sys.argv = ["fuzz_parity.py", "16", "3"]
-        with pytest.raises(SystemExit) as e:
-            runpy.run_path(os.path.join(h.ROOT, "tools", "dev", "fuzz_parity.py"), run_name="__main__")
-        assert e.value.code == 0
-    finally:
-        sys.argv = argv
+@pytest.mark.parametrize("n,seed,dir_scale", [(16, 3, 0.1), (70, 7, 0.0)])
+def test_randomised_parity_sweep(hip_lib, n, seed, dir_scale):
+    """Random scenes (image sizes 17..700, 1..6000 Gaussians, footprints 0.3..25 px, SH degrees 0-3, static/dynamic, off-centre
+    projection, kernel sizes, scale modifiers, subpixel offsets) through the full forward + backward comparison, shared-state AND
+    end to end (tests/fuzz_sweep.py): 16 cases with flow, and the 70 FLOW-FREE cases of seed 7 -- the frames the hand-scheduled
+    forward walk serves; round 3 ran that sweep outside the suite and had one case above the un-modelled end-to-end bar."""
+    from tests import fuzz_sweep
+    fails = fuzz_sweep.run(n, seed, dir_scale)
+    assert not fails, "\n".join(fails)
 
 
 # ------------------------------------------------------------------ multi-process data path on the GPU (2 ranks share cuda:0)
