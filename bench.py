@@ -34,7 +34,9 @@ from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSetti
 from ex4dgs_amd.scene import CONFIGS, make_scene                                   # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+SIMDS, CLOCK_HZ = 1024, 2.4e9        # 256 CUs x 4 SIMDs; a SIMD issues one wave64 VALU instruction per 4 cycles (MI355X_MICROARCH.md)
+RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
 
 
 # which source files a stage's kernels are compiled from (plus the shared internal header)
@@ -52,7 +54,9 @@ def pmc_counters_current(pmc, stage=None):
         return False
     d = os.path.join(ROOT, "ex4dgs_amd", "csrc")
     files = [f for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h"))]
-    if stage is not None:
+    if stage == "frame":
+        files = list(RASTER_SOURCES)
+    elif stage is not None:
         if stage not in STAGE_SOURCES:
             return False
         files = [STAGE_SOURCES[stage], "ex4d_internal.h"]
@@ -516,7 +520,7 @@ def main():
     dom = max(agg, key=agg.get) if agg else None
     dom_bytes = stage_bytes["sort"] if dom in ("tile_sort", "depth_sort") else stage_bytes.get(dom)
     roof = None
-    traffic = valu_busy = None
+    traffic = valu_busy = valu_insts = frame_pmc = None
     try:   # HBM bytes per launch from the rocprofv3 --pmc passes of this command, collected separately and committed (tools/pmc.sh)
         with open(os.path.join(ROOT, PMC_FILE)) as fh:
             pmc = json.load(fh)
@@ -524,13 +528,31 @@ def main():
         if pmc_ok and args.config == "cfg3" and args.points is None and dom in pmc["kernels"]:
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
             valu_busy = pmc["kernels"][dom].get("valu_busy_frac")
+            valu_insts = pmc["kernels"][dom].get("SQ_INSTS_VALU")
+        if pmc.get("frame") and pmc_counters_current(pmc, "frame") and args.config == "cfg3" and args.points is None and not args.forward_only:
+            frame_pmc = pmc["frame"]
     except Exception:
         traffic, pmc_ok = None, False
     if dom is not None and dom_bytes:
         achieved = dom_bytes / (agg[dom] * 1e-3) / 1e9
         rast_ms = ms_per_step if not train_mode else kernel_ms
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        # What bounds the dominant kernel, from ITS counters: it is priced against HBM by the contract
+        # (`achieved` / `frac` below use the section-8(d) bytes of the reference's algorithm), but when its real HBM traffic is a small
+        # fraction of what the HBM could move in its duration and its SIMDs are busy issuing VALU instructions, the bound is the
+        # instruction issue: floor = wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
+        issue_floor_ms = None if not valu_insts else valu_insts * 4.0 / (SIMDS * CLOCK_HZ) * 1e3
+        frac_traffic_dom = None if traffic is None else traffic / (agg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        bound = "hbm"
+        if valu_busy is not None and frac_traffic_dom is not None and valu_busy > 0.6 and frac_traffic_dom < 0.4:
+            bound = "valu-issue"
+        roof = {"bound": bound, "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "frac_traffic": None if frac_traffic_dom is None else round(frac_traffic_dom, 4),
+                "valu_insts": valu_insts, "issue_floor_ms": None if issue_floor_ms is None else round(issue_floor_ms, 4),
+                "frac_of_issue_floor": None if issue_floor_ms is None else round(issue_floor_ms / agg[dom], 4),
+                "note": ("achieved / frac: SURVEY 8(d) algorithmic bytes of the REFERENCE's algorithm / this kernel's duration (the contract's index); "
+                         "traffic / frac_traffic: this kernel's real HBM bytes per launch from the counters and their share of the 8 TB/s peak; "
+                         "bound: what its own counters say limits it"),
                 "traffic_source": (PMC_FILE + " (separate rocprofv3 --pmc passes of this command, committed with the hashes of the kernel sources; not re-measured in this run)")
                                   if traffic is not None else (PMC_FILE + " is missing or was collected from other kernel sources (hash mismatch): no counter figure is quoted"),
                 "kernel_ms": round(agg[dom], 4), "algorithmic_bytes": int(dom_bytes),
@@ -539,7 +561,13 @@ def main():
                 "frame": {"A_fwd_bytes": int(A_fwd), "A_bwd_bytes": int(A_bwd), "A_bytes": int(A),
                           "achieved_GBps_walltime": round(A / (rast_ms * 1e-3) / 1e9, 1),
                           "frac_walltime": round(A / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                          "achieved_GBps_kernels": round(A / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None},
+                          "achieved_GBps_kernels": round(A / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None,
+                          # the frame's REAL HBM traffic: counter bytes of every launch of one forward + backward, summed
+                          "hbm_traffic_bytes_pmc": None if frame_pmc is None else frame_pmc["hbm_bytes_per_frame"],
+                          "frac_traffic": None if frame_pmc is None else round(frame_pmc["hbm_bytes_per_frame"] / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                          "launches_pmc": None if frame_pmc is None else frame_pmc["launches_per_frame"],
+                          "valu_insts_pmc": None if frame_pmc is None else frame_pmc["SQ_INSTS_VALU_per_frame"],
+                          "issue_floor_ms": None if frame_pmc is None else round(frame_pmc["SQ_INSTS_VALU_per_frame"] * 4.0 / (SIMDS * CLOCK_HZ) * 1e3, 4)},
                 "stage_ms": {k: round(v, 4) for k, v in agg.items()},
                 "pair_evals_per_s_upper": round((1 if args.forward_only else 2) * 256.0 * R / (rast_ms * 1e-3), 0)}
 

@@ -83,7 +83,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forward", "ex4d_backward",
            "ex4d_forward_split_sh", "ex4d_backward_split_sh",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
-           "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout", "ex4d_backward_scratch_acc_offset",
+           "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout",
            "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option", "ex4d_debug_bwd_stats")
 
 
@@ -103,7 +103,7 @@ def load():
     lib.ex4d_last_error.restype = C.c_char_p
     lib.ex4d_target_arch.restype = C.c_char_p
     lib.ex4d_abi_version.restype = C.c_int
-    for n in ("ex4d_backward_scratch_bytes", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes", "ex4d_backward_scratch_acc_offset"):
+    for n in ("ex4d_backward_scratch_bytes", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes"):
         getattr(lib, n).restype = C.c_size_t
     lib.ex4d_forward.restype = C.c_int
     lib.ex4d_backward.restype = C.c_int

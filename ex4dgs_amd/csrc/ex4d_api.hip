@@ -208,7 +208,6 @@ void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out) { carve_geom(nullptr, P, o
 void ex4d_binning_layout(int32_t R, int32_t W, int32_t H, Ex4dBinningLayout *out) { carve_binning(nullptr, (uint32_t)R, W, H, out, nullptr); }
 void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out) { carve_img(nullptr, W, H, out, nullptr); }
 size_t ex4d_backward_scratch_bytes(int32_t P) { return ex4d_align_up((size_t)P * 16 * sizeof(float)); }
-size_t ex4d_backward_scratch_acc_offset(int32_t P) { (void)P; return 0; }
 
 static int forward_impl(
     const Ex4dParams *prm, ShSplit split,
@@ -482,7 +481,6 @@ int ex4d_get_option(const char *name)
 {
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "composite_fwd_asm")) return ex4d_get_fwd_asm();
-    if (name && !strcmp(name, "acc_layout")) return 0;
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     return -1;

@@ -485,8 +485,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
 //     E_i    = E_carry + sum_{j<i} alpha_j T_j (c_j . dL_dpixel)                     (accum_rec in closed form:
 //              (c_i - accum_rec_i) . dL_dpixel T_i = (c_i . dL_dpixel) T_i - E_i / (1 - alpha_i))
 //     gacc_i = gacc_carry prod_{j<=i, contributing} T_j                              (dL_dacc *= T)
-// List compaction comes for free: the forward kernel leaves the survivors of its quadrant cull as one 64-bit mask per
-// (64-entry chunk, quadrant) and this kernel gathers the records of the survivors only.
+// List compaction comes for free: the forward kernel leaves, per (tile, quadrant), the compacted list of the entries that survived its
+// quadrant cull (BinState::qlist / qcount: Gaussian id + list position, in list order); this kernel streams it back to front and
+// gathers the records of the survivors only.
 //
 // Measured on MI355X, 1.0 M Gaussians / 7.5 M instances (profiles/r02_*): per-pixel kernel 0.458 ms, 2.32e8 VALU instructions;
 // this kernel 0.35 ms, 1.79e8 (86 % VALU-busy; 55 % of the lanes of a step hold a contributing pair, 96 % of the staged
@@ -944,7 +945,7 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
     return hipGetLastError();
 }
 
-// variant: 4 = (Gaussian, pixel-slot) lanes with register accumulation and the forward kernel's cull masks (default);
+// variant: 4 = (Gaussian, pixel-slot) lanes with register accumulation, streaming the forward kernel's per-quadrant compacted lists (default);
 //          8 = 4 + developer statistics (g_bwd_stats)
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,

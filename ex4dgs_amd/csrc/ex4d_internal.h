@@ -18,6 +18,7 @@ static inline size_t ex4d_align_up(size_t x) { return (x + (EX4D_ALIGN - 1)) & ~
 //   float4 #2: depth (p_view.z), r, g, b          (SH colour or colors_precomp)
 //   float4 #3: dir3D.x, dir3D.y, dir3D.z, w       (per-Gaussian "flow" channel, zeros if absent; w = opacity*coef)
 #define EX4D_RECORD_FLOATS 16
+#define EX4D_DSUMS_MARK 0x44535553u     // frame flag [3]: the forward stored the SH direction sums (Ex4dParams.prepare_backward)
 
 struct GeomState {
     float4 *records;          // [P][4]
@@ -32,7 +33,7 @@ struct GeomState {
     uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
-    uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0
+    uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0, [3] EX4D_DSUMS_MARK when sh_dsums was written
     uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
     float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on request (Ex4dParams.prepare_backward)
 };

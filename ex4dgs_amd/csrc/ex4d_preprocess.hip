@@ -627,6 +627,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     if (__ballot(visible && (in_d0 != 0.f || in_d1 != 0.f || in_d2 != 0.f)) != 0ull) {
         if (lane == 0) prefilter_violation[1] = 1u;
     }
+    if (sh_dsums && idx == 0) prefilter_violation[2] = EX4D_DSUMS_MARK;      // frame flag [3]: this frame's direction sums exist (checked by the backward)
     if (in_range) {
         radii[idx] = out_radius;
         if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D, float *__restrict__ dL_dsh,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drotations, float *__restrict__ dL_ddir, const ShSplit sp, const ShSplitGrad gsp,
-    const float *__restrict__ sh_dsums)
+    const float *__restrict__ sh_dsums, const uint32_t *__restrict__ frame_flags)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -695,6 +696,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
     const bool staged = (shs != nullptr || split) && (M == 16);
     float *lds_row_base = sh_lds + wave * SH_HALF_FLOATS;
+    // the prepare_backward contract (include/ex4d_rasterizer.h): the direction sums exist only when the FORWARD on these buffers ran
+    // with prepare_backward = 1 -- it leaves a mark in the frame flags.  A backward that asks for them on other buffers (raw C-ABI
+    // callers, replayed snapshots) must not return plausible numbers computed from uninitialised memory: its gradients come out NaN
+    const bool dsums_ok = !DSUMS || frame_flags[3] == EX4D_DSUMS_MARK;
     const int wave_first = blockIdx.x * 256 + wave * 64;
     const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
     // ---- all global loads are issued before anything waits for one of them (see preprocess_fwd_kernel): the wave's SH block, the
@@ -752,6 +757,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 const float *o = sh_dsums + 9 * (size_t)idx;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) { dRGBdx[ch] = o[ch]; dRGBdy[ch] = o[3 + ch]; dRGBdz[ch] = o[6 + ch]; }
+                if (!dsums_ok) { const float nan = __int_as_float(0x7fc00000); for (int ch = 0; ch < 3; ch++) dRGBdx[ch] = dRGBdy[ch] = dRGBdz[ch] = nan; }
             }
         } else if (staged && prefetched) {
 #pragma unroll
@@ -1036,9 +1042,9 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_ddir, split, gsplit
     const bool has_sh = shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr;
     if (prm.prepare_backward && has_sh)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PB_ARGS, (const float *)g.sh_dsums);
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PB_ARGS, (const float *)g.sh_dsums, (const uint32_t *)g.total);
     else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PB_ARGS, (const float *)nullptr);
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PB_ARGS, (const float *)nullptr, (const uint32_t *)g.total);
 #undef PB_ARGS
     return hipGetLastError();
 }

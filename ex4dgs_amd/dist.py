@@ -3,9 +3,15 @@ Gaussian parameters replicated), and the only collective is the sum all-reduce o
 for the training step (the reference itself is single-process: utils/general_utils.py:161).
 
 Backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests (world_size 2).
-Gradients are packed into a few large flat buckets (one all-reduce per bucket keeps every xGMI link busy
-with large messages instead of 5-15 small tensors) and reduced asynchronously so the exchange of frame
-i overlaps the rasterization of frame i+1.
+Large gradient tensors are reduced in place, small ones travel in one flat message (few, large collectives keep
+every xGMI link busy), asynchronously on the communicator's stream.  What that overlaps with depends on the step
+(DESIGN.md section 6): with an optimizer in the step (the default of the multi-GPU bench) the exchange of frame i
+must finish before the optimizer update at the top of step i+1, so only the part issued before the attribute
+backward runs beside compute; without one it hides behind the rasterization of frame i+1.
+
+`force=True` (or EX4D_FORCE_COLLECTIVES=1) makes the exchange classes issue their collectives even in a process group
+of ONE rank: the RCCL-native branches (reduce_scatter_tensor, all_gather_into_tensor, in-place all-gather) can then be
+executed and checked on a single-GPU box (tests/test_gpu_dist.py).
 """
 import os
 
@@ -28,6 +34,10 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _forced(force):
+    return bool(force) or os.environ.get("EX4D_FORCE_COLLECTIVES", "0") == "1"
 
 
 def shard_views(num_views, rank, world_size):
@@ -154,9 +164,10 @@ class ParamGradExchange:
     the CALLER'S STREAM on them (async_op work handles: no host synchronisation with NCCL/RCCL).  bytes_on_wire() reports the
     per-rank payload of one exchange."""
 
-    def __init__(self, shapes, device, mode="allreduce", group=None, small_bytes=1 << 20):
+    def __init__(self, shapes, device, mode="allreduce", group=None, small_bytes=1 << 20, force=False):
         assert mode in ("allreduce", "reduce_scatter")
         self.mode, self.group, self.device = mode, group, device
+        self.force = _forced(force) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.numels = [int(torch.Size(s).numel()) for s in shapes]
@@ -178,7 +189,7 @@ class ParamGradExchange:
         self._native_rs = _backend(group) == "nccl"
 
     def active(self):
-        return self.world > 1
+        return self.world > 1 or self.force
 
     def bytes_on_wire(self):
         """Payload bytes one rank contributes to one exchange (what a ring moves is 2 (W-1)/W of it for all-reduce, (W-1)/W for
@@ -224,10 +235,13 @@ class SliceGather:
     sum as the dense all-reduce.  (The union of W random timestamps covers most of the K keyframes, so a dense "union" tensor would
     save little; W small windows do.)"""
 
-    def __init__(self, shape, device, group=None, local_only=False):
-        """local_only: a single local window, no collective (exchange mode "none": nothing is summed over ranks)."""
+    def __init__(self, shape, device, group=None, local_only=False, force=False, native=None):
+        """local_only: a single local window, no collective (exchange mode "none": nothing is summed over ranks).
+        native: None = all_gather_into_tensor on RCCL, the list all-gather on gloo; False (or EX4D_SLICE_GATHER_LIST=1) = the list
+        all-gather on any backend (the validated fallback of ADVICE r03)."""
         self.group = group
         self.local_only = bool(local_only)
+        self.force = _forced(force) and dist.is_initialized() and not local_only
         self.world = dist.get_world_size(group) if (dist.is_initialized() and not local_only) else 1
         self.rank = dist.get_rank(group) if (dist.is_initialized() and not local_only) else 0
         self.all = torch.zeros((self.world,) + tuple(shape), dtype=torch.float32, device=device)
@@ -235,17 +249,19 @@ class SliceGather:
         self.first_local = torch.zeros(1, dtype=torch.int32, device=device)
         self.pending = []
         self._keep = None
-        self._native = _backend(group) == "nccl"
+        self._native = (_backend(group) == "nccl") if native is None else bool(native)
+        if os.environ.get("EX4D_SLICE_GATHER_LIST", "0") == "1":
+            self._native = False
 
     def launch(self, window, first):
         self.wait()
         self._first_host = int(first)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self.all[0].copy_(window)
             return self
         if self._native:
             # RCCL: the send buffers are the caller's window and a one-element tensor of their own -- never views of the receive
-            # buffers (no reliance on in-place all-gather semantics; this branch has not run on hardware yet)
+            # buffers (no reliance on in-place all-gather semantics).  Executed on hardware by tests/test_gpu_dist.py (one rank, forced)
             src = window if window.is_contiguous() else window.contiguous()
             self.first_local.fill_(int(first))
             self._keep = src
@@ -268,11 +284,13 @@ class SliceGather:
         """[(first keyframe, count, device pointer of the [Nd, count, C] block)] for all ranks (call after wait()).  With more than
         one rank the positions of the other ranks' windows exist on the DEVICE only (first_device_ptr(): the optimizer kernel reads
         them there -- no device -> host round trip in the step); the host values returned for them are placeholders."""
-        return [(self._first_host if r == self.rank else 0, int(count), self.all[r].data_ptr()) for r in range(self.world)]
+        return [(self._first_host if r == self.rank else None, int(count), self.all[r].data_ptr()) for r in range(self.world)]
 
     def first_device_ptr(self):
-        """Device int32[world] of the windows' first keyframes (None for one rank: the host value is exact)."""
-        return self.first.data_ptr() if self.world > 1 else None
+        """Device int32[world] of the windows' first keyframes (None when no collective ran: the host value is exact).  The host
+        positions windows() returns for OTHER ranks are None: a caller that does not hand this pointer to the optimizer kernel
+        fails loudly (optim.radam_step_sliced_raw) instead of applying remote windows at keyframe 0."""
+        return self.first.data_ptr() if (self.world > 1 or self.force) else None
 
     def bytes_on_wire(self):
         return 4 * self.all[0].numel()
@@ -290,14 +308,21 @@ class ShardedRAdam:
     params: list of contiguous float32 tensors (updated in place); lrs: per-tensor learning rates.
     step_fn(items, betas, eps, device): defaults to the fused HIP launch (optim.radam_step_raw); the CPU tests inject the oracle."""
 
-    def __init__(self, params, lrs, betas=(0.9, 0.999), eps=1e-8, group=None, step_fn=None, small_bytes=1 << 20):
+    def __init__(self, params, lrs, betas=(0.9, 0.999), eps=1e-8, group=None, step_fn=None, small_bytes=1 << 20, nan_to_num=None, force=False):
+        """nan_to_num: per-tensor flags -- the gradient of a flagged tensor is read through torch.nan_to_num like the replicated
+        paths do for _opacity_duration_var (train.py:244-247; ADVICE r03: without it one non-finite gradient poisons the sharded
+        parameter and its moments for good, and "bit-identical to the replicated update" stops holding)."""
         self.params = list(params)
         self.lrs = [float(x) for x in lrs]
+        self.nan_to_num = [0] * len(self.params) if nan_to_num is None else [int(bool(x)) for x in nan_to_num]
+        assert len(self.nan_to_num) == len(self.params)
         self.betas, self.eps, self.group = betas, eps, group
         self.device = self.params[0].device
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.exchange = ParamGradExchange([p.shape for p in self.params], self.device, mode="reduce_scatter", group=group, small_bytes=small_bytes)
+        self.force = _forced(force) and dist.is_initialized()
+        self.exchange = ParamGradExchange([p.shape for p in self.params], self.device, mode="reduce_scatter", group=group, small_bytes=small_bytes,
+                                          force=force)
         if step_fn is None:
             from .optim import radam_step_raw
             step_fn = radam_step_raw
@@ -333,11 +358,12 @@ class ShardedRAdam:
                 pv, gv = p.view(-1)[lo:hi], g.view(-1)[lo:hi]
                 items.append((pv.data_ptr() if pv.is_cuda else pv, gv.data_ptr() if gv.is_cuda else gv,
                               self.exp_avg[i].data_ptr() if pv.is_cuda else self.exp_avg[i],
-                              self.exp_avg_sq[i].data_ptr() if pv.is_cuda else self.exp_avg_sq[i], hi - lo, self.lrs[i], self.steps[i]))
+                              self.exp_avg_sq[i].data_ptr() if pv.is_cuda else self.exp_avg_sq[i], hi - lo, self.lrs[i], self.steps[i],
+                              self.nan_to_num[i]))
         self.step_fn(items, self.betas, self.eps, self.device)
         if self.device.type == "cuda":
             torch.autograd.graph.increment_version(self.params)        # written through raw pointers
-        if self.world > 1:
+        if self.world > 1 or self.force:
             works = []
             for p, sm in zip(self.params, self.exchange.small):
                 if sm:

@@ -73,7 +73,9 @@ def radam_step_sliced_raw(items, betas, eps, device):
             continue
         if len(windows) > MAX_WINDOWS:
             raise RuntimeError(f"at most {MAX_WINDOWS} gradient windows per tensor and step")
-        first = (C.c_int32 * 8)(*([w[0] for w in windows] + [0] * (8 - len(windows))))
+        if first_dev is None and any(w[0] is None for w in windows):
+            raise RuntimeError("radam_step_sliced_raw: a window without a host position needs first_dev (SliceGather.first_device_ptr())")
+        first = (C.c_int32 * 8)(*([(0 if w[0] is None else int(w[0])) for w in windows] + [0] * (8 - len(windows))))
         count = (C.c_int32 * 8)(*([w[1] for w in windows] + [0] * (8 - len(windows))))
         grad = (C.c_void_p * 8)(*([int(w[2]) for w in windows] + [None] * (8 - len(windows))))
         descs.append(Ex4dRadamSlicedTensor(int(p), int(m), int(v), int(rows), int(K), int(Cc), float(lr), int(step), len(windows), first, count, grad,

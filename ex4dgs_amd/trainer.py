@@ -49,11 +49,14 @@ class FrameTrainer:
     """model: scene.DynamicGaussians on a ROCm device.  exchange: "none" | "allreduce" | "sharded" (reduce-scatter + sharded RAdam +
     all-gather; implies optimizer).  optimizer: False | True (replicated fused RAdam when exchange != "sharded")."""
 
-    def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None, spatial_lr_scale=1.0):
+    def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None, spatial_lr_scale=1.0,
+                 force_collectives=False):
         """lrs: overrides of the reference table reference_lrs(spatial_lr_scale).
         sliced (default: on whenever a replicated optimizer runs): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from the
         attribute backward through the exchange (all-gather of the ranks' windows) into ex4d_radam_step_sliced -- no 196 MB zero fill,
-        no dense read, 16 MB per rank on the wire instead of 196."""
+        no dense read, 16 MB per rank on the wire instead of 196.
+        force_collectives: issue the exchange's collectives even in a process group of one rank (dist.py: the RCCL-native branches
+        run and are checked on a one-GPU box)."""
         assert exchange in ("none", "allreduce", "sharded")
         self.model = model
         self.names = list(attr.PARAM_ORDER)
@@ -62,7 +65,8 @@ class FrameTrainer:
         if self.device.type != "cuda":
             raise RuntimeError("FrameTrainer needs the model on a ROCm device (no CPU fallback)")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.mode = exchange if self.world > 1 or exchange == "sharded" else "none"
+        force = xdist._forced(force_collectives) and dist.is_initialized()
+        self.mode = exchange if (self.world > 1 or exchange == "sharded" or force) else "none"
         self.overlap = overlap
         self.side = torch.cuda.Stream(device=self.device) if overlap else None
         self.feature_idx = [self.names.index(n) for n in attr.FEATURE_NAMES]
@@ -88,19 +92,19 @@ class FrameTrainer:
             for i in self.kf_idx:
                 shape = (self.params[i].shape[0],) + attr.SLICED_SHAPES[self.names[i]]
                 self.pgrad[i] = torch.zeros(shape, dtype=torch.float32, device=self.device)
-                self.kf_gather.append(xdist.SliceGather(shape, self.device, group=group, local_only=(self.mode != "allreduce")))
+                self.kf_gather.append(xdist.SliceGather(shape, self.device, group=group, local_only=(self.mode != "allreduce"), force=force))
         # two exchanges: the four feature gradients (3/4 of the bytes) leave the rasterizer backward and are on the wire while the
         # attribute backward still runs; the other parameters follow it
         self.feat_pos = [i for i in self.feature_idx]
         self.rest_pos = [i for i in range(len(self.params)) if i not in self.kf_idx and i not in self.feature_idx]
         self.exchange_feat = None
         if self.mode == "sharded":
-            self.opt = xdist.ShardedRAdam(self.params, self.lrs, group=group)
+            self.opt = xdist.ShardedRAdam(self.params, self.lrs, group=group, nan_to_num=[n in NAN_TO_NUM for n in self.names], force=force)
             self.exchange = self.opt.exchange
         else:
             if self.mode == "allreduce":
-                self.exchange_feat = xdist.ParamGradExchange([self.params[i].shape for i in self.feat_pos], self.device, mode="allreduce", group=group)
-                self.exchange = xdist.ParamGradExchange([self.params[i].shape for i in self.rest_pos], self.device, mode="allreduce", group=group)
+                self.exchange_feat = xdist.ParamGradExchange([self.params[i].shape for i in self.feat_pos], self.device, mode="allreduce", group=group, force=force)
+                self.exchange = xdist.ParamGradExchange([self.params[i].shape for i in self.rest_pos], self.device, mode="allreduce", group=group, force=force)
             if optimizer:
                 self.m = [torch.zeros_like(p) for p in self.params]
                 self.v = [torch.zeros_like(p) for p in self.params]

@@ -47,7 +47,9 @@ typedef struct Ex4dParams {
     int32_t prepare_backward; /* forward: a backward will follow -- the per-Gaussian kernel also stores the d(colour)/d(direction) sums of the
                                  SH backward (36 B per visible Gaussian, inside the geometry buffer) while it has the SH rows in registers;
                                  pass the SAME value to the backward call that consumes this forward's buffers: it then does not read
-                                 the SH tensors at all (-155 MB of 535 at 1.0 M Gaussians).  0 = the backward reads them itself. */
+                                 the SH tensors at all (-155 MB of 535 at 1.0 M Gaussians).  0 = the backward reads them itself.
+                                 The forward marks the geometry buffer when it stored the sums; a backward that asks for them on a
+                                 buffer whose forward ran with 0 returns NaN gradients (never numbers computed from uninitialised memory). */
     int32_t reserved;
 } Ex4dParams;
 
@@ -203,10 +205,9 @@ typedef struct Ex4dImgLayout {
 void ex4d_geom_layout(int32_t P, Ex4dGeomLayout *out);
 void ex4d_binning_layout(int32_t num_rendered, int32_t W, int32_t H, Ex4dBinningLayout *out);
 void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
-/* offset of the packed per-Gaussian accumulator rows (float[P][16]) inside bwd_scratch -- for parity tests only.
+/* bwd_scratch holds the packed per-Gaussian accumulator rows float[P][16] at offset 0 (read by the parity tests).
  * Row: 0..2 dL_dmean2D.xyz (xy without the factors ln2 W/2, ln2 H/2), 3..5 dL_dconic.(x,y,w) (without -1/2), 6 dL_dopacity,
- *      7..9 dL_dcolor, 10..12 dL_ddir   (ex4d_get_option("acc_layout") == 0; a second layout existed in round 2) */
-size_t ex4d_backward_scratch_acc_offset(int32_t P);
+ *      7..9 dL_dcolor, 10..12 dL_ddir, 13..15 unused */
 
 /* Tuning knobs (process-wide; results are the same within float rounding whatever the setting):
  *   "composite_bwd_variant"  4 = (Gaussian, pixel-slot) lanes with register accumulation (default), 8 = 4 + developer statistics
@@ -221,7 +222,7 @@ size_t ex4d_backward_scratch_acc_offset(int32_t P);
  *   "geom_debug_arrays"      1 = also write Ex4dGeomLayout.cov3D and .tiles_touched; 0 (default) = those regions stay untouched: the
  *                            backward recomputes the covariance from scale / rotation (same function, same bits), the tile rect carries
  *                            the count.
- * ex4d_get_option additionally answers "acc_layout" (see above).  Returns EX4D_OK / the value, or an error / -1. */
+ * Returns EX4D_OK / the value, or an error / -1. */
 int ex4d_set_option(const char *name, int value);
 int ex4d_get_option(const char *name);
 /* developer counters of "composite_bwd_variant" 8 since the last reset: [0] batches, [1] valid Gaussians, [2] steps run,

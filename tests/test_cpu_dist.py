@@ -24,20 +24,27 @@ lrs = [1.6e-4, 2.5e-3, 1e-3, 5e-2, 5e-3, 1e-3]
 g0 = torch.Generator().manual_seed(7)
 init = [torch.randn(*s, generator=g0) for s in shapes]
 
+NAN_TENSOR = 4            # stands for _opacity_duration_var: its gradient goes through nan_to_num (train.py:244-247)
+
 def grads_of(r, step):
     g = torch.Generator().manual_seed(1000 * step + r)
     out = [torch.randn(*s, generator=g) * (0.1 + step) for s in shapes]
     out[3] = torch.zeros(*shapes[3])                 # an all-zero gradient (RAdam still moves the parameter by its momentum)
+    if step == 2 and r == 0:                         # one rank's frame produces non-finite gradients in both halves of the tensor
+        out[NAN_TENSOR][5] = float("nan"); out[NAN_TENSOR][3000] = float("inf"); out[NAN_TENSOR][4098] = float("-inf")
     return out
 
 def oracle_step(items, betas, eps, device):
-    for p, g, m, v, n, lr, step in items:            # tensors (CPU path of ShardedRAdam)
+    for p, g, m, v, n, lr, step, sanitize in items:  # tensors (CPU path of ShardedRAdam)
         pn, mn, vn = p.numpy(), m.numpy(), v.numpy()
-        optim_oracle.radam_step(pn, g.numpy().copy(), mn, vn, step, lr, betas[0], betas[1], eps)
+        gn = g.numpy().copy()
+        if sanitize:
+            gn = np.nan_to_num(gn)                   # numpy's defaults are torch.nan_to_num's: NaN -> 0, +-inf -> +-FLT_MAX
+        optim_oracle.radam_step(pn, gn, mn, vn, step, lr, betas[0], betas[1], eps)
 
 # --- sharded: every rank holds all parameters, updates only its element ranges
 params = [x.clone() for x in init]
-opt = xd.ShardedRAdam(params, lrs, step_fn=oracle_step, small_bytes=256)
+opt = xd.ShardedRAdam(params, lrs, step_fn=oracle_step, small_bytes=256, nan_to_num=[i == NAN_TENSOR for i in range(len(shapes))])
 assert opt.exchange.small == [False, False, False, True, False, True]
 K = 8
 for step in range(1, K + 1):
@@ -50,9 +57,13 @@ m = [torch.zeros_like(x) for x in init]; v = [torch.zeros_like(x) for x in init]
 for step in range(1, K + 1):
     ga, gb = grads_of(0, step), grads_of(1, step)
     for i in range(len(ref)):
-        optim_oracle.radam_step(ref[i].numpy(), (ga[i] + gb[i]).numpy(), m[i].numpy(), v[i].numpy(), step, lrs[i])
+        gsum = (ga[i] + gb[i]).numpy()
+        if i == NAN_TENSOR:
+            gsum = np.nan_to_num(gsum)               # the replicated path: nan_to_num on the summed gradient, then the dense step
+        optim_oracle.radam_step(ref[i].numpy(), gsum, m[i].numpy(), v[i].numpy(), step, lrs[i])
 for i, (a, b) in enumerate(zip(params, ref)):
     assert torch.equal(a, b), (i, float((a - b).abs().max()))          # bit-identical, including the un-sharded tails
+    assert bool(torch.isfinite(a).all()), i                             # the non-finite gradient of step 2 poisoned nothing
 # optimizer state is really sharded: about half of the replicated state per rank
 full = 8 * sum(x.numel() for x in init)
 assert opt.state_bytes() < 0.56 * full + 8 * (10 + 7) , (opt.state_bytes(), full)

@@ -1,5 +1,5 @@
-"""GPU tests of the multi-rank training path (run with `-m gpu` on an MI355X; a 1-GPU box is enough: the two ranks share the
-device and talk over gloo -- the collectives are the same calls that run over RCCL on a multi-GPU node)."""
+"""GPU tests of the multi-rank training path (run with `-m gpu` on an MI355X; a 1-GPU box is enough: two ranks share the device
+and talk over gloo, and the RCCL-native collectives run in a one-rank "nccl" group with the exchange forced)."""
 import json
 import os
 import subprocess
@@ -139,6 +139,109 @@ def test_two_ranks_exchange_and_sharded_optimizer(hip_lib, tmp_path):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o[-3000:]
+
+
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from ex4dgs_amd import _C, dist as xd
+from ex4dgs_amd.scene import make_scene
+from ex4dgs_amd.trainer import FrameTrainer, NAN_TO_NUM
+from ex4dgs_amd.optim import radam_step_raw
+from ex4dgs_amd.attributes import PARAM_ORDER
+
+torch.cuda.set_device(0); _C.load()
+dist.init_process_group(backend="nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+model, cam, bg = make_scene("cfg3", P=20000, device="cuda", fused=True)
+H, W = cam.image_height, cam.image_width
+w = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).cuda()
+up = lambda out: ([out["render"]], [w])
+stamps = [0, 100, 200, 299, 41, 88]
+solo = FrameTrainer(model, exchange="none")
+solo.step(cam, bg, stamps[0], up); solo.flush()
+g = [x.clone() for x in solo.grads().values()]
+shapes = [x.shape for x in g]
+
+# (1) ParamGradExchange, both modes, collectives FORCED in the one-rank group: reduce_scatter_tensor (in place, dist.py) / all_reduce
+#     over RCCL; the sum over one rank is the input, bit for bit, in the rank's range AND outside it (nothing else may be touched)
+for mode in ("reduce_scatter", "allreduce"):
+    ex = xd.ParamGradExchange(shapes, dev, mode=mode, force=True, small_bytes=1 << 14)
+    assert ex.active() and ex._native_rs and not all(ex.small)
+    g2 = [x.clone() for x in g]
+    ex.launch(g2); ex.wait(); torch.cuda.synchronize()
+    for name, a, b in zip(PARAM_ORDER, g, g2):
+        assert torch.equal(a, b), (mode, name)
+
+# (2) SliceGather, native all_gather_into_tensor from send buffers of its own
+win = torch.randn(model.num_dynamic, 4, 3, device=dev)
+sg = xd.SliceGather(win.shape, dev, force=True)
+assert sg._native and sg.force
+sg.launch(win, 7); sg.wait(); torch.cuda.synchronize()
+assert torch.equal(sg.all[0], win) and int(sg.first[0]) == 7 and sg.first_device_ptr() is not None
+assert sg.windows(4)[0][0] == 7
+
+# (3) ShardedRAdam over RCCL (reduce-scatter -> update of the own range -> in-place all_gather_into_tensor) == dense replicated update,
+#     bit for bit, over 4 steps of real rasterizer gradients; a NaN in the flagged tensor's gradient goes through nan_to_num on both sides
+lrs = [1e-3 * (1 + i) for i in range(15)]
+flags = [n in NAN_TO_NUM for n in PARAM_ORDER]
+A = [p.clone() for p in model.parameters()]
+mA = [torch.zeros_like(p) for p in A]; vA = [torch.zeros_like(p) for p in A]
+B = [p.clone() for p in model.parameters()]
+sh = xd.ShardedRAdam(B, lrs, small_bytes=1 << 14, nan_to_num=flags, force=True)
+assert sh._native and sh.force
+for k in range(1, 5):
+    solo.step(cam, bg, stamps[k], up); solo.flush()
+    gk = [x.clone() for x in solo.grads().values()]
+    if k == 2:
+        gk[flags.index(True)].view(-1)[3] = float("nan")
+    ga = [x.clone() for x in gk]
+    radam_step_raw([(p.data_ptr(), x.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, k, int(f)) for p, x, m, v, lr, f in zip(A, ga, mA, vA, lrs, flags)],
+                   (0.9, 0.999), 1e-8, dev)
+    sh.step(gk)
+    torch.cuda.synchronize()
+    for name, a, b in zip(PARAM_ORDER, A, B):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all()), (name, k)
+
+# (4) the trainer with its collectives forced == the trainer without an exchange (one rank: the sums are the rank's own gradients).
+#     Replicated optimizer + sliced keyframe gradients (all-reduce x2, SliceGather x2, positions read from the gathered device array)
+#     and the sharded optimizer; the two runs differ only by the order of the rasterizer's float atomics
+def run(exchange, force):
+    m, _, _ = make_scene("cfg3", P=20000, device="cuda", fused=True)
+    p0 = [p.clone() for p in m.parameters()]
+    tr = FrameTrainer(m, exchange=exchange, optimizer=True, lrs={n: 1e-4 for n in PARAM_ORDER}, force_collectives=force)
+    for k in range(4):
+        tr.step(cam, bg, stamps[k], up)
+    tr.flush(); torch.cuda.synchronize()
+    return tr, [p - q for p, q in zip(m.parameters(), p0)]
+ref_tr, ref = run("none", False)
+for exchange in ("allreduce", "sharded"):
+    tr, got = run(exchange, True)
+    assert tr.mode == exchange
+    if exchange == "allreduce":
+        assert tr.sliced and tr.exchange.active() and tr.exchange_feat.active() and all(gth.force and gth._native for gth in tr.kf_gather)
+    for name, a, b in zip(PARAM_ORDER, got, ref):
+        scale = float(b.abs().max())
+        assert scale > 0 or float(a.abs().max()) == 0, name
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-12, (exchange, name, float((a - b).abs().max()), scale)
+dist.barrier(); dist.destroy_process_group()
+print("OK rccl")
+"""
+
+
+def test_rccl_native_collectives_run_in_a_one_rank_group(hip_lib, tmp_path):
+    """The RCCL-native branches of ex4dgs_amd/dist.py -- reduce_scatter_tensor, all_gather_into_tensor from separate send buffers, the
+    in-place all-gather of the sharded optimizer -- executed on hardware in a process group of ONE rank with the collectives forced
+    (VERDICT r03 #7: until now they had never run anywhere; an 8-GPU job must not be their first execution)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32700 + (os.getpid() % 2000)), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), h.ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "OK rccl" in r.stdout, r.stdout[-4000:]
 
 
 @pytest.mark.parametrize("config", ["cfg3", "cfg4"])

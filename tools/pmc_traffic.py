@@ -72,7 +72,7 @@ def collect(fetch, write, stats, sq=None):
         if a is None or a in out:
             continue
         fk, wk = f.get(name, {}).get("FETCH_SIZE", 0.0), w.get(name, {}).get("WRITE_SIZE", 0.0)
-        us = next((v for k, v in st.items() if k[:50] == name[:50]), None)
+        us = next((v for k, v in st.items() if k[:len(name)] == name), None) or next((v for k, v in st.items() if k[:50] == name[:50]), None)
         row = {"kernel": name[:60], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
         if us:
             row["avg_us"] = us
@@ -85,9 +85,43 @@ def collect(fetch, write, stats, sq=None):
     return out
 
 
+RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
+
+
+def frame_totals(fetch, write, stats, sq):
+    """Everything ONE rasterizer frame (forward + backward) launches in the bench command, summed from the counter passes: every
+    kernel (and runtime fill / copy) whose launch count is a multiple of the frame count, launches per frame x per-launch
+    counters.  This is the frame's REAL HBM traffic and instruction count -- the figures a roofline of the frame is made of
+    (the section-8(d) 'algorithmic bytes' price the REFERENCE's algorithm, 6-pass 64-bit sort included)."""
+    f, w, st, s = parse_table(fetch), parse_table(write), parse_stats(stats), parse_table(sq)
+    calls = {}
+    for line in open(fetch).read().splitlines()[1:]:
+        m = re.match(r"^(.*?)\s+(\d+)((?:\s+[0-9.e+-]+)+)\s*$", line)
+        if m:
+            calls[m.group(1).strip()] = int(m.group(2))
+    n_fwd = next((n for k, n in calls.items() if "composite_fwd_kernel" in k), None)
+    if not n_fwd:
+        return None
+    rows, tot_b, tot_us, tot_valu, launches = [], 0.0, 0.0, 0.0, 0
+    for name, n in calls.items():
+        ours = "anonymous namespace" in name or "__amd_rocclr_fillBuffer" in name or "__amd_rocclr_copyBuffer" in name
+        per = int(round(n / n_fwd))
+        if not ours or per < 1 or alias(name) in ("radam", "l1_ssim_forward", "l1_ssim_backward", "l1_ssim_finish", "attributes_forward", "attributes_backward"):
+            continue
+        b = (2 * f.get(name, {}).get("FETCH_SIZE", 0.0) + w.get(name, {}).get("WRITE_SIZE", 0.0)) * 1024
+        us = next((v for k, v in st.items() if k[:len(name)] == name), None) or next((v for k, v in st.items() if k[:50] == name[:50]), 0.0)
+        valu = s.get(name, {}).get("SQ_INSTS_VALU", 0.0)
+        rows.append({"kernel": name[:60], "launches_per_frame": per, "hbm_bytes_per_launch": int(b), "avg_us": us, "SQ_INSTS_VALU": valu})
+        tot_b += per * b; tot_us += per * us; tot_valu += per * valu; launches += per
+    return {"launches_per_frame": launches, "hbm_bytes_per_frame": int(tot_b), "kernel_us_per_frame": round(tot_us, 2),
+            "SQ_INSTS_VALU_per_frame": tot_valu, "frac_of_8TBps_at_kernel_sum": round(tot_b / (tot_us * 1e-6) / 8e12, 3) if tot_us else None,
+            "rows": rows}
+
+
 def main():
     a = sys.argv[1:]
     kernels = collect(a[0], a[1], a[3], a[2])
+    frame = frame_totals(a[0], a[1], a[3], a[2])
     if len(a) >= 8:
         kernels.update({k: v for k, v in collect(a[5], a[6], a[7]).items() if k not in kernels})
     if len(a) >= 11:
@@ -96,7 +130,11 @@ def main():
                          "tools/dev/dev_iter_profile.py (fused training iteration at 1.0M); tools/dev/dev_knn_time.py",
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
                "source_sha16": kernel_source_hashes(),
+               "frame": frame,
                "kernels": kernels}, open(a[4], "w"), indent=1)
+    if frame:
+        print(f"frame: {frame['launches_per_frame']} launches, {frame['hbm_bytes_per_frame'] / 1e9:.3f} GB HBM traffic, {frame['kernel_us_per_frame']:.1f} us of kernels "
+              f"-> {frame['frac_of_8TBps_at_kernel_sum']} of 8 TB/s; {frame['SQ_INSTS_VALU_per_frame']:.4g} VALU wave-instructions")
     for k, v in kernels.items():
         print(f"{k:28s} {v.get('avg_us', 0):9.2f} us  {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  {v.get('hbm_GBps', 0):8.1f} GB/s  frac {v.get('frac_of_8TBps', 0):.3f}  valu_busy {v.get('valu_busy_frac', '')}")
 
