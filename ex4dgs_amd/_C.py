@@ -13,7 +13,8 @@ import os
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libex4d_hip.so")
+# EX4D_HIP_LIB: developer override (a variant build of the same sources, e.g. tools/dev/spill_probe.py); the product loads the in-tree library
+_LIB_PATH = os.environ.get("EX4D_HIP_LIB") or os.path.join(_CSRC, "libex4d_hip.so")
 _lib = None
 
 NUM_CHANNELS = 3   # cuda_rasterizer/config.h:15
@@ -84,7 +85,7 @@ EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forw
            "ex4d_forward_split_sh", "ex4d_backward_split_sh",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
            "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout",
-           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option", "ex4d_debug_bwd_stats")
+           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option", "ex4d_debug_bwd_stats", "ex4d_debug_bwd_stats16")
 
 
 def library_path():
@@ -403,11 +404,14 @@ def get_option(name):
     return int(load().ex4d_get_option(name.encode()))
 
 
-def bwd_stats(reset=True):
+def bwd_stats(reset=True, extended=False):
     """Developer counters of the compositing backward's variant 8 (ex4d_debug_bwd_stats): batches, valid Gaussians, steps run,
-    steps skipped, contributing (pixel, Gaussian) pairs, Gaussians with a contributing pair, 2 spare."""
-    buf = (C.c_ulonglong * 8)()
-    rc = load().ex4d_debug_bwd_stats(buf, int(bool(reset)))
+    steps skipped, contributing (pixel, Gaussian) pairs, Gaussians with a contributing pair, ... ; extended=True: the 16 counters of
+    ex4d_debug_bwd_stats16 (include/ex4d_rasterizer.h lists them)."""
+    n = 16 if extended else 8
+    buf = (C.c_ulonglong * n)()
+    fn = load().ex4d_debug_bwd_stats16 if extended else load().ex4d_debug_bwd_stats
+    rc = fn(buf, int(bool(reset)))
     if rc != 0:
         raise RuntimeError("ex4d_debug_bwd_stats failed")
     return [int(x) for x in buf]

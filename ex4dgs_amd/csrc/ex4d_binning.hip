@@ -28,12 +28,17 @@ __device__ __forceinline__ int to_int_sat(float f)
 
 // ---------------------------------------------------------------- radix sort (8-bit digits, stable)
 // pass structure: histogram -> row scan -> scatter.  hist layout: [bin][block] followed by [bin] totals.
-template <int ITEMS, int BINS>
+// COPIES > 1: lane L counts into copy L % COPIES of the block's histogram (rows padded by one word, so the copies of a bin sit in
+// different LDS banks).  The tile sort's first pass sees long runs of equal digits -- the instances of one Gaussian are neighbouring
+// tiles, their high digit is the same -- and 64 lanes adding to ONE LDS word serialise (round 3: 14.7 us for a 30 MB read, the LDS
+// atomics of 7.5 M instances at one per cycle and CU); with 8 copies a run of 64 equal digits costs 8 serial steps, not 64.
+template <int ITEMS, int BINS, int COPIES>
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift,
     uint32_t mask, uint32_t nblocks, uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t h[BINS];
-    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) h[b] = 0;
+    __shared__ uint32_t h_all[COPIES * (BINS + 1)];
+    uint32_t *h = h_all + (COPIES > 1 ? (threadIdx.x % COPIES) * (BINS + 1) : 0);
+    for (int b = threadIdx.x; b < COPIES * (BINS + 1); b += RS_THREADS) h_all[b] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
     // all loads in flight before the first LDS atomic (clamped index instead of a branch per load)
@@ -49,7 +54,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t
         if (i < n) atomicAdd(&h[(k[it] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) hist[(size_t)b * nblocks + blockIdx.x] = h[b];
+    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < COPIES; k++) c += h_all[k * (BINS + 1) + b];
+        hist[(size_t)b * nblocks + blockIdx.x] = c;
+    }
 }
 
 // one block per bin: exclusive scan of that bin's per-block counts; bin total to hist[RS_BINS*nblocks + bin].
@@ -520,13 +530,13 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         const int nbits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);
         const uint32_t mask = (1u << nbits) - 1u;
         if (small) {
-            hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
 #define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr)
             if (nbits == 9) RS_SMALL_SCATTER(9); else if (nbits == 8) RS_SMALL_SCATTER(8); else RS_SMALL_SCATTER(0);
 #undef RS_SMALL_SCATTER
         } else {
-            hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
             hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr);
         }
@@ -560,7 +570,7 @@ hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32
     const uint32_t nbA = rs_num_blocks(R), nbB = ts_max_blocks(R, tile_bits);
     uint32_t *histB = hist + (size_t)256 * (nbA + 1);
     const uint32_t *totals = hist + (size_t)256 * nbA;
-    hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist);
+    hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 8>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << high_bits), dim3(256), 0, stream, nbA, hist, 256u);
 #define TS_SCATTER_A(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 1, NB>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, vals, packed, (uint32_t *)nullptr, \
         R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, 0, (uint2 *)nullptr)

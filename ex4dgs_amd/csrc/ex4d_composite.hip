@@ -525,8 +525,11 @@ template <int R> __device__ __forceinline__ int ring_wrap(int i) { return i >= R
 #define DUMP_FLOATS 320          // per-wave scratch: junk target of the non-carry lanes (64 lanes + 15 steps x 16 floats), epilogue staging
 
 // developer statistics of the scan kernel (variant 8 only): [0] batches, [1] valid Gaussians, [2] steps run, [3] steps skipped,
-// [4] contributing (pixel, Gaussian) pairs, [5] Gaussians with at least one contributing pair in their batch
-__device__ unsigned long long g_bwd_stats[8];
+// [4] contributing (pixel, Gaussian) pairs, [5] Gaussians with at least one contributing pair in their batch,
+// [6] (pixel, Gaussian) pairs whose Gaussian lies in front of the pixel's last contributor (alive by list position, in range or not),
+// [7] Gaussians contributing in the TOP four rows of the quadrant only, [8] in the BOTTOM four rows only, [9] in both,
+// [10] steps run in the top half, [11] in the bottom half, [12] batches with no contributing pair in the top half, [13] ... bottom half
+__device__ unsigned long long g_bwd_stats[16];
 
 template <int RING> struct BwdLdsT {
     float4 ring[3][RING];        // [0] x y a' b'   [1] c' w depth id   [2] r g b list-position     (also: transposition scratch at setup)
@@ -653,7 +656,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
     float4 pa_n = L.pa[g], pb_n = L.pb[g], pc_n = make_float4(0.f, 0.f, 0.f, 0.f), pd_n = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rd_pc) pc_n = L.pc[g];
     if (!SEP) pd_n = L.pd[g];
-    unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0;
+    unsigned long long st_run = 0, st_skip = 0, st_pairs = 0, st_any = 0, st_alive = 0, st_top = 0, st_bot = 0, st_run_top = 0;
     const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
     float dyr = 0.f, bdy = 0.f, cdydy = 0.f;
     constexpr bool MOMENTS = SEP;     // see the accumulation below
@@ -680,7 +683,12 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         const float q2 = q2_rows(dx, ap, bdy, cdydy);
         const lanemask ok = NOLAST ? LANES(__float_as_uint(q2) <= tauq)
                                    : (LANES(orig < __float_as_uint(pb.y)) & LANES(__float_as_uint(q2) <= tauq));
-        if (STATS) { if (ok == 0) st_skip++; else st_run++; st_pairs += __popcll(ok); st_any |= ok; }
+        if (STATS) {
+            if (ok == 0) st_skip++; else { st_run++; if (s < 8) st_run_top++; }
+            st_pairs += __popcll(ok); st_any |= ok;
+            if (s < 8) st_top |= ok; else st_bot |= ok;
+            st_alive += __popcll(LANES(orig < __float_as_uint(pb.y)));
+        }
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         // G and alpha of the contributing lanes, exact zeros elsewhere (one select: w is finite, so w * 0 = 0)
         const float G_m = select_f(ok, __builtin_amdgcn_exp2f(-q2), 0.f);
@@ -733,6 +741,13 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         const unsigned long long any16 = (st_any | (st_any >> 16) | (st_any >> 32) | (st_any >> 48)) & 0xffffull;
         atomicAdd(&g_bwd_stats[0], 1ull); atomicAdd(&g_bwd_stats[1], (unsigned long long)nvalid); atomicAdd(&g_bwd_stats[2], st_run);
         atomicAdd(&g_bwd_stats[3], st_skip); atomicAdd(&g_bwd_stats[4], st_pairs); atomicAdd(&g_bwd_stats[5], (unsigned long long)__popcll(any16));
+        const unsigned long long top16 = (st_top | (st_top >> 16) | (st_top >> 32) | (st_top >> 48)) & 0xffffull;
+        const unsigned long long bot16 = (st_bot | (st_bot >> 16) | (st_bot >> 32) | (st_bot >> 48)) & 0xffffull;
+        atomicAdd(&g_bwd_stats[6], st_alive);
+        atomicAdd(&g_bwd_stats[7], (unsigned long long)__popcll(top16 & ~bot16)); atomicAdd(&g_bwd_stats[8], (unsigned long long)__popcll(bot16 & ~top16));
+        atomicAdd(&g_bwd_stats[9], (unsigned long long)__popcll(top16 & bot16));
+        atomicAdd(&g_bwd_stats[10], st_run_top); atomicAdd(&g_bwd_stats[11], st_run - st_run_top);
+        atomicAdd(&g_bwd_stats[12], top16 == 0 ? 1ull : 0ull); atomicAdd(&g_bwd_stats[13], bot16 == 0 ? 1ull : 0ull);
     }
     wave_lds_sync();
     float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
@@ -920,10 +935,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 void ex4d_set_fwd_asm(int on) { g_fwd_asm.store(on); }
 int ex4d_get_fwd_asm() { return g_fwd_asm.load(); }
 
-hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset)
+hipError_t ex4d_bwd_stats(unsigned long long *out, int count, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) { unsigned long long z[8] = { 0 }; e = hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)); }
+    if (count > 16) count = 16;
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_stats), count * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { unsigned long long z[16] = { 0 }; e = hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)); }
     return e;
 }
 

@@ -105,6 +105,8 @@ hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, con
     const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
 
+void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: bit 0 staggered wave priorities, bit 1 SH rows predicated on the frustum test
+int ex4d_get_preprocess_tune();
 void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled entry walk (default) or the compiler's loop
 int ex4d_get_fwd_asm();
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
@@ -119,4 +121,4 @@ hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges,
     int variant, hipStream_t stream);
 
 // developer statistics of the scan compositing backward (variant 8)
-hipError_t ex4d_bwd_stats(unsigned long long *out8, int reset);
+hipError_t ex4d_bwd_stats(unsigned long long *out, int count, int reset);

@@ -11,6 +11,7 @@
 // (CR/auxiliary.h:43, :284; CR/forward.cu:112-116) are kept.  One thread per Gaussian, 256-thread
 // blocks (4 wave64); the kernels are HBM-bound (SH read / SH-grad write of 192 B per Gaussian).
 #include "ex4d_internal.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -185,21 +186,23 @@ __device__ __forceinline__ void wave_sync_lds()
 // The forward kernel does that copy in two steps, so that the global loads are IN FLIGHT while its projection / covariance arithmetic
 // runs (a wave used to wait out three dependent memory round trips: means -> scale/rotation -> SH; now one):
 // issue = the 12 coalesced 16-byte loads into registers, commit = their transposition into half a padded LDS slice at a time.
+// need: bit L set <=> the Gaussian of lane L can be visible (it passed the frustum test); the 16-byte chunks of the other rows are not
+// requested (~19 % of them at BASELINE config 3: 36 MB per frame).  ~0 = every row.
 struct ShPrefetch { float4 v[13]; };
-__device__ __forceinline__ void wave_issue_sh(const float *__restrict__ shs_wave, ShPrefetch &pf, int nrows, int nvec, int lane)
+__device__ __forceinline__ void wave_issue_sh(const float *__restrict__ shs_wave, ShPrefetch &pf, int nrows, int nvec, int lane, uint64_t need)
 {
     const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
 #pragma unroll
     for (int it = 0; it < 12; it++) {
         const int q = it * 64 + lane;
         const int g = q / 12, v = q - 12 * g;
-        pf.v[it] = (g < nrows && v < nvec) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pf.v[it] = (g < nrows && v < nvec && ((need >> g) & 1ull)) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 // split layout: the wave's rows of ONE (dc, rest) tensor pair as two linear 16-byte-aligned spans (rest: 64 x 45 floats = 720 float4,
 // dc: 64 x 3 floats = 48 float4); returns false (nothing issued) for the one wave that straddles the static/dynamic boundary or for
 // misaligned tensors -- those lanes read their rows straight from memory
-__device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_first, int nrows, ShPrefetch &pf, int lane)
+__device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_first, int nrows, ShPrefetch &pf, int lane, uint64_t need)
 {
     const bool all_dynamic = wave_first >= sp.n_static, all_static = wave_first + nrows <= sp.n_static;
     if (nrows <= 0 || !(all_dynamic || all_static)) return false;
@@ -210,9 +213,15 @@ __device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_
 #pragma unroll
     for (int it = 0; it < 12; it++) {
         const int q = it * 64 + lane;
-        pf.v[it] = q < 720 ? reinterpret_cast<const float4 *>(rest)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r_lo = (4 * q) / 45, r_hi = (4 * q + 3) / 45;        // the at most two rows a 16-byte chunk of the rest span touches
+        const bool want = q < 720 && (((need >> (r_lo & 63)) | (need >> (r_hi & 63))) & 1ull);
+        pf.v[it] = want ? reinterpret_cast<const float4 *>(rest)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    pf.v[12] = lane < 48 ? reinterpret_cast<const float4 *>(dc)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int r_lo = (4 * lane) / 3, r_hi = (4 * lane + 3) / 3;
+        const bool want = lane < 48 && (((need >> (r_lo & 63)) | (need >> (r_hi & 63))) & 1ull);
+        pf.v[12] = want ? reinterpret_cast<const float4 *>(dc)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     return true;
 }
 
@@ -393,12 +402,24 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
-    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums)
+    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int tune)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in_range = idx < P;
+    // tune bit 0: staggered wave priorities.  Every wave of this kernel has the same three phases (load ~23 KB, ~1500 VALU instructions,
+    // store); the waves that share a SIMD start together and, with round-robin issue, stay in lock-step -- the CU alternates between
+    // "all waves wait for memory" and "all waves compete for the VALU" (measured: duration = memory time + VALU time, not their
+    // maximum).  Distinct priorities per wave slot let one wave at a time run its arithmetic through while the others' loads are in
+    // flight, so the phases of co-resident waves drift apart.  No workgroup barrier in this kernel: no priority inversion.
+    if (tune & 1) {
+        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;      // HW_REG_HW_ID.wave_id[1:0]
+        if (slot == 0) __builtin_amdgcn_s_setprio(0);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
     // the 2x16 camera floats are wave-uniform: they live in SGPRs / the scalar cache
     float vm[16], pm[16];
 #pragma unroll
@@ -414,9 +435,22 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
     ShPrefetch pf;
     bool prefetched = false;
+    // tune bit 1: the frustum test (CR/auxiliary.h in_frustum: 12 bytes of input) runs BEFORE the SH rows are requested, and the rows of
+    // the Gaussians it culls are not requested at all -- one more dependent memory round trip per wave against 36 MB less traffic
+    bool pre_ok = false;
+    float3 pre_p = make_float3(0.f, 0.f, 0.f), pre_view = make_float3(0.f, 0.f, 0.f);
+    float pre_nx = 0.f, pre_ny = 0.f;
+    uint64_t need = ~0ull;
+    if (tune & 2) {
+        if (in_range) {
+            pre_p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+            pre_ok = frustum_test(pre_p, vm, pm, min_depth, max_depth, pre_view, pre_nx, pre_ny);
+        }
+        need = __ballot(pre_ok);
+    }
     if (staged) {
-        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane);
-        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, (ncoef * 3 + 3) / 4, lane); prefetched = true; }
+        if (split) prefetched = wave_issue_sh_split(sp, wave_first, wave_rows, pf, lane, need);
+        else { wave_issue_sh(shs + (size_t)wave_first * 48, pf, wave_rows, (ncoef * 3 + 3) / 4, lane, need); prefetched = true; }
     }
     float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
     float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f, in_op = 0.f, in_d0 = 0.f, in_d1 = 0.f, in_d2 = 0.f;
@@ -445,9 +479,14 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     float3 p = make_float3(0.f, 0.f, 0.f), conic = make_float3(0.f, 0.f, 0.f);
     float pix_x = 0.f, pix_y = 0.f, depth = 0.f, coef = 0.f;
     if (in_range) do {
-        p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
         float3 p_view; float ndc_x, ndc_y;
-        if (!frustum_test(p, vm, pm, min_depth, max_depth, p_view, ndc_x, ndc_y)) {
+        bool in_view;
+        if (tune & 2) { p = pre_p; p_view = pre_view; ndc_x = pre_nx; ndc_y = pre_ny; in_view = pre_ok; }
+        else {
+            p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+            in_view = frustum_test(p, vm, pm, min_depth, max_depth, p_view, ndc_x, ndc_y);
+        }
+        if (!in_view) {
             if (prefiltered) atomicOr(prefilter_violation, 1u);
             break;
         }
@@ -1003,6 +1042,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 }  // namespace
 
+// "preprocess_tune" (ex4d_set_option): bit 0 = staggered wave priorities, bit 1 = SH rows of frustum-culled Gaussians not requested
+static std::atomic<int> g_preprocess_tune{0};
+void ex4d_set_preprocess_tune(int v) { g_preprocess_tune.store(v); }
+int ex4d_get_preprocess_tune() { return g_preprocess_tune.load(); }
+
 hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
@@ -1017,7 +1061,8 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
         radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split,
-        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr);
+        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr,
+        g_preprocess_tune.load(std::memory_order_relaxed));
     return hipGetLastError();
 }
 

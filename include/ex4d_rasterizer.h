@@ -228,6 +228,10 @@ int ex4d_get_option(const char *name);
 /* developer counters of "composite_bwd_variant" 8 since the last reset: [0] batches, [1] valid Gaussians, [2] steps run,
  * [3] steps skipped, [4] contributing (pixel, Gaussian) pairs, [5] Gaussians with a contributing pair, [6..7] spare */
 int ex4d_debug_bwd_stats(unsigned long long *out8, int reset);
+/* ... and the extended set: [6] pairs alive by list position, [7] / [8] / [9] Gaussians contributing in the top four rows of their
+ * quadrant only / the bottom four only / both, [10] / [11] steps run in the top / bottom half, [12] / [13] batches whose top / bottom
+ * half has no contributing pair, [14..15] spare */
+int ex4d_debug_bwd_stats16(unsigned long long *out16, int reset);
 
 /* Optional per-stage timing (hipEvents on the caller's stream, single host thread; used by bench.py).
  * ex4d_profile_read(which = 0 forward / 1 backward) waits for the last recorded call of that kind and

@@ -376,10 +376,18 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
         extra13 = np.asarray(extra13, dtype=np.float64)
         rep["extra13_max"] = [float(x) for x in extra13.max(0)]
         rep["extra13_rows_above_atol"] = int((extra13.max(1) > atol).sum())
+        base_tol = tol
         tol = tol + extra13
         ex = propagated_tolerance(fwd_o, extra13)
         extra_t = {k: float(np.asarray(ex[k]).max(initial=0.0)) for k in GRAD_NAMES if k in ex}
     err = np.abs(acc - ob["sum13"])
+    if extra13 is not None:
+        # how much of the modelled allowance is actually used: entries whose error exceeds the plain (shared-state) bar, and the
+        # worst error against the bar + HALF the allowance passed in (the caller passes 2 x the first-order bound)
+        rep["entries_above_plain_bar"] = int((err > base_tol).sum())
+        rep["rows_above_plain_bar"] = int((err > base_tol).any(1).sum())
+        rep["worst_ratio_at_half_allowance"] = float((err / (base_tol + 0.5 * extra13)).max())
+        rep["allowance_over_plain_bar_p50_p99"] = [float(x) for x in np.quantile((extra13 / base_tol).max(1), [0.5, 0.99])]
     rep["acc16_worst_ratio"] = float((err / tol).max())
     rep["acc16_max_abs"] = [float(x) for x in err.max(0)]
     assert (err <= tol).all(), f"accumulators out of tolerance: worst ratio {rep['acc16_worst_ratio']}, at {np.unravel_index((err / tol).argmax(), err.shape)}"
