@@ -137,8 +137,8 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_vals_b = c.take<uint32_t>(P);
     g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
-    g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-workgroup instance counts
-    g.block_totals = c.take<uint32_t>((P + 255) / 256);
+    g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-chunk instance counts
+    g.block_totals = c.take<uint32_t>((P + 63) / 64);        // instance count of every 64-Gaussian chunk
     g.sh_dsums = c.take<float>(9 * (size_t)P);
     l.total = c.off;
     if (lay) *lay = l;
@@ -274,7 +274,7 @@ static int forward_impl(
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
     // (g.total[0..63] and the per-workgroup counts are adjacent in the geometry buffer: one copy)
-    const size_t nblk = (size_t)(P + 255) / 256;
+    const size_t nblk = (size_t)(P + 63) / 64;
     const size_t rb_words = (size_t)(g.block_totals - g.total) + nblk;
     if (!g_readback.init(rb_words)) return fail(EX4D_ERR_HIP, "pinned read-back buffer allocation failed");
     HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -471,7 +471,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "composite_fwd_asm") && (value == 0 || value == 1)) { ex4d_set_fwd_asm(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "preprocess_tune") && value >= 0 && value <= 3) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
+    if (name && !strcmp(name, "preprocess_tune") && value >= 0 && value <= 7) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }

@@ -34,7 +34,7 @@ struct GeomState {
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
     uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0, [3] EX4D_DSUMS_MARK when sh_dsums was written
-    uint32_t *block_totals;                              // per-workgroup instance counts of preprocess_fwd (summed on the host)
+    uint32_t *block_totals;                              // instance counts of preprocess_fwd per chunk of 64 Gaussians (summed on the host)
     float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on request (Ex4dParams.prepare_backward)
 };
 struct BinState {

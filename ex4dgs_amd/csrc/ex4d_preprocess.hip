@@ -13,6 +13,7 @@
 #include "ex4d_internal.h"
 #include <atomic>
 #include <cstdlib>
+#include <cstdlib>
 
 namespace {
 
@@ -391,7 +392,8 @@ __device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float 
 #undef SHK
 }
 
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void preprocess_fwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
@@ -404,15 +406,16 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
     uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int tune)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool in_range = idx < P;
-    // tune bit 0: staggered wave priorities.  Every wave of this kernel has the same three phases (load ~23 KB, ~1500 VALU instructions,
-    // store); the waves that share a SIMD start together and, with round-robin issue, stay in lock-step -- the CU alternates between
-    // "all waves wait for memory" and "all waves compete for the VALU" (measured: duration = memory time + VALU time, not their
-    // maximum).  Distinct priorities per wave slot let one wave at a time run its arithmetic through while the others' loads are in
-    // flight, so the phases of co-resident waves drift apart.  No workgroup barrier in this kernel: no priority inversion.
+    __shared__ __attribute__((aligned(16))) float sh_lds[WAVES * SH_HALF_FLOATS];
+    const int lane = threadIdx.x & 63, wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
+    // Every WAVE is independent (no workgroup barrier, wave-private LDS slice, per-wave instance count) and handles chunk wc of 64
+    // Gaussians.  WAVES = 4 (rounds 1-3): workgroups of 256 threads; WAVES = 1 ("preprocess_tune" bit 2): one wave per workgroup, so
+    // that every wave retires -- and its successor starts loading -- on its own.
+    // tune bit 0: staggered wave priorities.  Every chunk has the same three phases (load ~23 KB, ~1500 VALU instructions, store); the
+    // waves that share a SIMD start together and, with round-robin issue, stay in lock-step -- all of them wait for memory, then all of
+    // them compete for the VALU: counters (profiles/r03_pmc_SQ_valu.txt) show a wave alive for 50 k cycles of which 23 k in s_waitcnt and
+    // 8 k issuing; the kernel's duration is memory time PLUS VALU time, not their maximum.  Distinct priorities per wave slot let one
+    // wave at a time run its arithmetic through while the others' loads are in flight.
     if (tune & 1) {
         const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;      // HW_REG_HW_ID.wave_id[1:0]
         if (slot == 0) __builtin_amdgcn_s_setprio(0);
@@ -420,6 +423,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         else if (slot == 2) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(3);
     }
+    const int wc = (int)blockIdx.x * WAVES + wave;
+    if (wc >= ((P + 63) >> 6)) return;
+    const int idx = wc * 64 + lane;
+    const bool in_range = idx < P;
     // the 2x16 camera floats are wave-uniform: they live in SGPRs / the scalar cache
     float vm[16], pm[16];
 #pragma unroll
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const int ncoef = (D + 1) * (D + 1);
     const bool split = sp.rest[0] != nullptr || sp.rest[1] != nullptr;        // implies M == 16, shs == nullptr (checked by the API)
     const bool staged = (shs != nullptr || split) && (M == 16);
-    const int wave_first = blockIdx.x * 256 + wave * 64;
+    const int wave_first = wc * 64;
     const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
     ShPrefetch pf;
     bool prefetched = false;
@@ -677,15 +684,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // number of tile instances (the reference's num_rendered = last element of the inclusive scan,
     // CR/rasterizer_impl.cu:295-299): it does not depend on the depth order, so it is summed here and read back by the
     // host WHILE the depth sort runs -- the blocking read-back no longer leaves the GPU idle.
-    // (one plain store per workgroup; the host adds the few thousand partial sums -- a single atomic counter would
+    // (one plain store per chunk of 64 Gaussians; the host adds the partial sums -- a single atomic counter would
     // serialise ~12 ns per arrival)
-    __shared__ uint32_t wave_totals[4];
     uint32_t wave_sum = out_tiles;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wave_sum += __shfl_xor(wave_sum, o, 64);
-    if (lane == 0) wave_totals[wave] = wave_sum;
-    __syncthreads();
-    if (threadIdx.x == 0) total_instances[blockIdx.x] = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
+    if (lane == 0) total_instances[wc] = wave_sum;        // one count per 64-Gaussian chunk
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -1042,8 +1046,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 }  // namespace
 
-// "preprocess_tune" (ex4d_set_option): bit 0 = staggered wave priorities, bit 1 = SH rows of frustum-culled Gaussians not requested
-static std::atomic<int> g_preprocess_tune{0};
+// "preprocess_tune" (ex4d_set_option): bit 0 = staggered wave priorities, bit 1 = SH rows of frustum-culled Gaussians not requested,
+// bit 2 = one wave per workgroup
+static int preprocess_tune_default() { const char *e = getenv("EX4D_PREPROCESS_TUNE"); return e ? (atoi(e) & 7) : 0; }    // developer override of the default
+static std::atomic<int> g_preprocess_tune{preprocess_tune_default()};
 void ex4d_set_preprocess_tune(int v) { g_preprocess_tune.store(v); }
 int ex4d_get_preprocess_tune() { return g_preprocess_tune.load(); }
 
@@ -1055,14 +1061,15 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
-    const int blocks = (prm.P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
-        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split,
-        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr,
-        g_preprocess_tune.load(std::memory_order_relaxed));
+    const int tune = g_preprocess_tune.load(std::memory_order_relaxed);
+#define PF_ARGS prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, \
+        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size, \
+        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation, \
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split, \
+        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr, tune
+    if (tune & 4) hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((prm.P + 63) / 64), dim3(64), 0, stream, PF_ARGS);
+    else hipLaunchKernelGGL(preprocess_fwd_kernel<4>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
+#undef PF_ARGS
     return hipGetLastError();
 }
 
