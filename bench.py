@@ -346,6 +346,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250_000)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo for debugging")
     ap.add_argument("--share-device", action="store_true", help="debug: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--async-frames", action="store_true", help="N = 1 rasterizer steps with the ASYNCHRONOUS forward (no instance-count read-back: Ex4dParams.instance_capacity)")
+    ap.add_argument("--graph", action="store_true", help="N = 1: forward + backward (asynchronous forward, raw C-ABI mirror calls) captured into ONE hipGraph and replayed per step")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     args = ap.parse_args()
 
@@ -416,9 +418,55 @@ def main():
             torch.autograd.backward([color, depth, flow, acc], [grads[0], grads[1], grads[2], grads[3]])
             return color
 
-        ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all)
+        mode_note = ""
+        if args.graph:
+            # forward + backward of frame 0 captured once (asynchronous forward: host-constant grids, no host wait), replayed per step
+            from ex4dgs_amd.diff_gaussian_rasterization_df import async_frames
+            xyz, shs, opa, scl, rot = [t.detach() for t in frames[0]]
+            zero_dir = torch.zeros(P, 3, device=dev)
+            fargs = (settings.bg, xyz, zero_dir, empty, opa, scl, rot, 1.0, empty, settings.viewmatrix, settings.projmatrix, settings.tanfovx,
+                     settings.tanfovy, 0.1, settings.subpixel_offset, H, W, shs, 3, settings.campos, False, settings.min_depth, settings.max_depth, False)
+            probe = _C.rasterize_gaussians(*fargs)
+            cap = int(1.25 * int(probe[0])) + 4096
+            del probe
+
+            def raw(cap):
+                f = _C.rasterize_gaussians(*fargs, prepare_backward=not args.forward_only, instance_capacity=cap, assume_no_flow=True)
+                if args.forward_only:
+                    return f, None
+                b = _C.rasterize_gaussians_backward(settings.bg, xyz, f[2], empty, scl, rot, f[6], f[7], settings.min_depth, settings.max_depth, 1.0, empty,
+                                                    settings.viewmatrix, settings.projmatrix, settings.tanfovx, settings.tanfovy, 0.1, settings.subpixel_offset,
+                                                    grads[0], grads[1], grads[2], grads[3], shs, 3, settings.campos, f[3], f[0], f[4], f[5], False,
+                                                    need_colors=False, need_cov3D=False, prepared=True)
+                return f, b
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                raw(cap)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gf, gb = raw(cap)
+
+            def step(i):
+                graph.replay()
+                return gf[1]
+            ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all)
+            assert gf[0].wait().valid, "the captured frame overflowed its capacity"
+            mode_note = f" replayed from one hipGraph (asynchronous forward, capacity {cap} for {gf[0].num_rendered} instances)"
+        else:
+            if args.async_frames:
+                from ex4dgs_amd.diff_gaussian_rasterization_df import async_frames
+                async_frames.enable(headroom=1.25, strict=False)
+            ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all)
+            if args.async_frames:
+                async_frames.drain()
+                assert async_frames.invalid_frames == 0, "an asynchronous frame overflowed inside the timed region"
+                mode_note = f" (asynchronous forward: no instance-count read-back, capacity {async_frames.capacity})"
+                async_frames.enabled = False
         parallelism = f"frame-sharded x{world}" + ("" if world == 1 else " (no collective)")
-        step_what = "GaussianRasterizer forward" + ("" if args.forward_only else " + backward") + " on a resident frame"
+        step_what = "GaussianRasterizer forward" + ("" if args.forward_only else " + backward") + " on a resident frame" + mode_note
     else:
         # ---------------- training-iteration core, one view per rank per step ----------------
         from ex4dgs_amd.trainer import FrameTrainer

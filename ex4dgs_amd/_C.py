@@ -24,7 +24,81 @@ class Ex4dParams(C.Structure):
     _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
                 ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("kernel_size", C.c_float), ("scale_modifier", C.c_float),
                 ("min_depth", C.c_float), ("max_depth", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
-                ("prepare_backward", C.c_int32), ("reserved", C.c_int32)]
+                ("prepare_backward", C.c_int32), ("instance_capacity", C.c_int32), ("assume_no_flow", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PendingFrame:
+    """`num_rendered` of an ASYNCHRONOUS forward (Ex4dParams.instance_capacity > 0): the capacity the binning buffer was sized for is
+    known now, the frame's status (instance count, overflow, flow flag) arrives in pinned host memory behind an event.  Stands in for
+    the reference's Python int: int(frame) waits for the event and returns the count (DGR/py:95-105 keeps it in ctx.num_rendered and
+    hands it back to the backward, which here only needs the capacity -- nobody waits unless somebody looks)."""
+    __slots__ = ("capacity", "assumed_no_flow", "_status", "_event", "_pool")
+
+    def __init__(self, capacity, assumed_no_flow, status, event, pool):
+        self.capacity, self.assumed_no_flow, self._status, self._event, self._pool = int(capacity), bool(assumed_no_flow), status, event, pool
+
+    def done(self):
+        return self._event is not None and self._event.query()
+
+    def wait(self):
+        if self._event is not None:
+            self._event.synchronize()
+        else:                                  # forward recorded into a graph: its status is valid after a replay has finished
+            torch.cuda.synchronize()
+        return self
+
+    def _word(self, i):
+        return int(self.wait()._status[i].item()) & 0xFFFFFFFF
+
+    @property
+    def num_rendered(self):
+        return self._word(0)
+
+    @property
+    def overflowed(self):
+        """The frame has more (Gaussian, tile) instances than the capacity: its tile lists were truncated, its outputs are invalid."""
+        return self.num_rendered > self.capacity
+
+    @property
+    def has_flow(self):
+        return self._word(2) != 0
+
+    @property
+    def prefilter_violation(self):
+        return self._word(1) != 0
+
+    @property
+    def valid(self):
+        return not self.overflowed and not (self.assumed_no_flow and self.has_flow)
+
+    def __int__(self):
+        return self.num_rendered
+
+    __index__ = __int__
+
+    def __repr__(self):
+        return f"PendingFrame(capacity={self.capacity}, " + (f"num_rendered={self.num_rendered})" if self.done() else "pending)")
+
+    def __del__(self):
+        try:
+            if self._pool is not None and self._event is not None and not self._status.is_cuda and self._event.query():
+                self._pool.append(self._status)          # the pinned status words go back to the pool once the copy has landed
+        except Exception:
+            pass
+
+
+_status_pool = []
+
+
+def _pinned_status():
+    """8 pinned int32 words for one frame's Ex4dFrameStatus (pooled: pinning host memory costs far more than a frame, and is not
+    allowed while a stream is capturing -- the pool is filled 16 buffers at a time outside capture)."""
+    if not _status_pool:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("no pinned status buffer left during graph capture: run one asynchronous forward before capturing")
+        block = torch.zeros(16, 8, dtype=torch.int32).pin_memory()
+        _status_pool.extend(block[i] for i in range(16))
+    return _status_pool.pop()
 
 
 class GeomLayout(C.Structure):
@@ -162,9 +236,10 @@ def _require_rocm(t, name):
         raise RuntimeError(f"{name} is on {t.device}: the ex4dgs_amd rasterizer only runs on a ROCm GPU (no CPU fallback)")
 
 
-def _params(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug, prepare_backward=False):
+def _params(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug, prepare_backward=False,
+            instance_capacity=0, assume_no_flow=False):
     return Ex4dParams(P, D, M, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, min_depth, max_depth, int(bool(prefiltered)), int(bool(debug)),
-                      int(bool(prepare_backward)), 0)
+                      int(bool(prepare_backward)), int(instance_capacity), int(bool(assume_no_flow)), 0)
 
 
 def _resizer(t):
@@ -177,11 +252,15 @@ def _resizer(t):
 
 def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width,
-                        sh, degree, campos, prefiltered, min_depth, max_depth, debug, prepare_backward=False):
+                        sh, degree, campos, prefiltered, min_depth, max_depth, debug, prepare_backward=False,
+                        instance_capacity=0, assume_no_flow=False):
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-133): 24 positional arguments ->
     (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idx).
     prepare_backward (keyword, not in the reference): a backward will follow -- the forward also leaves the SH direction sums the
-    backward needs (include/ex4d_rasterizer.h: Ex4dParams.prepare_backward); hand `prepared=True` to the backward on these buffers."""
+    backward needs (include/ex4d_rasterizer.h: Ex4dParams.prepare_backward); hand `prepared=True` to the backward on these buffers.
+    instance_capacity > 0 (keyword, not in the reference): ASYNCHRONOUS forward -- no instance-count read-back, the host does not wait,
+    every launch has a host-constant grid; num_rendered comes back as a PendingFrame (capacity now, count / overflow on demand).
+    assume_no_flow: with it, launch the flow-free compositing kernel (the caller's dir3D is all zeros; PendingFrame.has_flow checks)."""
     lib = load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -224,9 +303,17 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos), ("subpixel_offset", subpixel_offset)):
         kt, ptr[name] = _dev_f32(t, name, dev)
         keep.append(kt)
-    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug, prepare_backward)
+    prm = _params(P, int(degree), M, W, H, tan_fovx, tan_fovy, kernel_size, scale_modifier, min_depth, max_depth, prefiltered, debug, prepare_backward,
+                  instance_capacity, assume_no_flow)
     cbs = [_resizer(geomBuffer), _resizer(binningBuffer), _resizer(imgBuffer)]
     num_rendered = C.c_int32(0)
+    count_ref = C.byref(num_rendered)
+    status = None
+    if instance_capacity > 0:
+        # Ex4dFrameStatus: pinned host memory behind an event; for a call recorded into a graph, device memory (it is read with an
+        # ordinary copy after a replay -- a pinned destination of a captured copy was observed to be clobbered between replays)
+        status = torch.zeros(8, dtype=torch.int32, device=dev) if torch.cuda.is_current_stream_capturing() else _pinned_status()
+        count_ref = C.cast(status.data_ptr(), C.POINTER(C.c_int32))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream().cuda_stream
         if split is not None:
@@ -239,15 +326,22 @@ def rasterize_gaussians(background, means3D, dir3D, colors, opacity, scales, rot
                 ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
                 ptr["subpixel_offset"], cbs[0], None, cbs[1], None, cbs[2], None,
                 out_color.data_ptr(), radii.data_ptr(), out_depth.data_ptr(), out_acc.data_ptr(), out_flow.data_ptr(), out_idx.data_ptr(),
-                C.c_void_p(stream), C.byref(num_rendered))
+                C.c_void_p(stream), count_ref)
         else:
             code = lib.ex4d_forward(
                 C.byref(prm), ptr["background"], ptr["means3D"], ptr["dir3D"], ptr["sh"], ptr["colors"], ptr["opacity"],
                 ptr["scales"], ptr["rotations"], ptr["cov3D_precomp"], ptr["viewmatrix"], ptr["projmatrix"], ptr["campos"],
                 ptr["subpixel_offset"], cbs[0], None, cbs[1], None, cbs[2], None,
                 out_color.data_ptr(), radii.data_ptr(), out_depth.data_ptr(), out_acc.data_ptr(), out_flow.data_ptr(), out_idx.data_ptr(),
-                C.c_void_p(stream), C.byref(num_rendered))
+                C.c_void_p(stream), count_ref)
+        ev = None
+        if status is not None and code == 0 and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
     _check(code)
+    if status is not None:
+        return (PendingFrame(instance_capacity, assume_no_flow, status, ev, _status_pool), out_color, radii, geomBuffer, binningBuffer, imgBuffer,
+                out_depth, out_acc, out_flow, out_idx)
     return (int(num_rendered.value), out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth, out_acc, out_flow, out_idx)
 
 
@@ -263,6 +357,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     _require_rocm(means3D, "means3D")
     dev = means3D.device
     P = means3D.size(0)
+    if isinstance(R, PendingFrame):
+        R = R.capacity            # asynchronous forward: the buffers are laid out for the capacity, the kernels read the actual ranges
     H, W = acc_depth.size(1), acc_depth.size(2)      # forward output [1,H,W]; any upstream gradient may be absent (empty = zeros)
     f32 = dict(dtype=torch.float32, device=dev)
     split = sh if isinstance(sh, SplitSH) else None
@@ -375,6 +471,9 @@ def geom_views(geomBuffer, P):
 
 
 def binning_views(binningBuffer, R, W, H):
+    """R: the count the buffer was laid out for (the instance count, or the capacity of an asynchronous forward)."""
+    if isinstance(R, PendingFrame):
+        R = R.capacity
     lay = BinningLayout()
     load().ex4d_binning_layout(R, W, H, C.byref(lay))
     b = binningBuffer

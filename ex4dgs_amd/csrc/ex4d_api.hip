@@ -198,7 +198,7 @@ ImgState carve_img(void *buf, int W, int H, Ex4dImgLayout *lay, size_t *total)
 extern "C" {
 
 const char *ex4d_last_error(void) { return g_err; }
-int ex4d_abi_version(void) { return 3; }
+int ex4d_abi_version(void) { return 4; }
 const char *ex4d_target_arch(void) { return "gfx950"; }
 
 size_t ex4d_geom_bytes(int32_t P) { size_t t; carve_geom(nullptr, P, nullptr, &t); return t; }
@@ -237,6 +237,11 @@ static int forward_impl(
     if (!out_color || !radii || !out_depth || !out_acc || !out_flow || !out_idx) return fail(EX4D_ERR_ARG, "null output");
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     const int T = gx * gy;
+    // asynchronous forward (Ex4dParams.instance_capacity): no read-back, no host wait, host-constant grids; `num_rendered` is an
+    // Ex4dFrameStatus in pinned host memory that an asynchronous copy fills
+    const bool async = prm->instance_capacity > 0;
+    if (prm->instance_capacity < 0) return fail(EX4D_ERR_ARG, "instance_capacity must be >= 0");
+    if (async && prm->debug) return fail(EX4D_ERR_ARG, "debug (synchronise after every stage) and instance_capacity > 0 (asynchronous forward) exclude each other");
 
     void *geom_buf = geom_alloc(geom_user, ex4d_geom_bytes(P));
     if (!geom_buf) return fail(EX4D_ERR_ALLOC, "geometry buffer allocation failed");
@@ -263,7 +268,7 @@ static int forward_impl(
     uint32_t *keys1 = start_in_b ? g.sort_keys_a : g.sort_keys_b, *vals1 = start_in_b ? g.depth_order : g.sort_vals_b;
 
     g_prof.begin(0, stream);
-    HIP_TRY(hipMemsetAsync(g.total, 0, 4 * sizeof(uint32_t), stream));
+    HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));        // the frame flags / Ex4dFrameStatus words
     // 1. per-Gaussian preprocess
     GeomState gw = g;          // cov3D[P,6] / tiles_touched[P] are written on request only: nothing downstream reads them
     if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
@@ -273,31 +278,44 @@ static int forward_impl(
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
-    // (g.total[0..63] and the per-workgroup counts are adjacent in the geometry buffer: one copy)
+    // (g.total[0..63] and the per-chunk counts are adjacent in the geometry buffer: one copy)
     const size_t nblk = (size_t)(P + 63) / 64;
     const size_t rb_words = (size_t)(g.block_totals - g.total) + nblk;
-    if (!g_readback.init(rb_words)) return fail(EX4D_ERR_HIP, "pinned read-back buffer allocation failed");
-    HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(g_readback.ev, stream));
+    if (!async) {
+        if (!g_readback.init(rb_words)) return fail(EX4D_ERR_HIP, "pinned read-back buffer allocation failed");
+        HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(g_readback.ev, stream));
+    }
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
     bool in_first = true;
     STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream), prm, stream);
     if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
     MARK(0, "depth_sort");
-    // 3. instance offsets in depth order + total
-    STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, stream), prm, stream);
+    // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)
+    STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
     MARK(0, "scan_tiles");
-    // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
-    HIP_TRY(hipEventSynchronize(g_readback.ev));
-    uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
-    for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
-    const uint32_t host_total[2] = { instance_sum, g_readback.host[1] };
-    const bool has_flow = g_readback.host[2] != 0u;      // frame flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
-    if (prm->prefiltered && host_total[1])
-        return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    const uint32_t R = host_total[0];
-    if (R > 0x7FFFFFFFu) return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances");
-    *num_rendered = (int32_t)R;
+    uint32_t R = 0;                      // instance count (synchronous) or capacity (asynchronous): sizes the binning buffer and the grids
+    const uint32_t *n_dev = nullptr;     // asynchronous: the kernels read the actual count here
+    bool has_flow;
+    if (async) {
+        static_assert(sizeof(Ex4dFrameStatus) == 8 * sizeof(uint32_t), "Ex4dFrameStatus mirrors the first eight frame-flag words");
+        // (hipMemcpyDefault: the status may live in pinned host memory or -- e.g. for calls recorded into a graph -- in device memory)
+        HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
+        R = (uint32_t)prm->instance_capacity;
+        n_dev = g.total;
+        has_flow = prm->assume_no_flow == 0;
+    } else {
+        // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
+        HIP_TRY(hipEventSynchronize(g_readback.ev));
+        uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
+        for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
+        has_flow = g_readback.host[2] != 0u;      // frame flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
+        if (prm->prefiltered && g_readback.host[1])
+            return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        R = instance_sum;
+        if (R > 0x7FFFFFFFu) return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances");
+        *num_rendered = (int32_t)R;
+    }
 
     void *bin_buf = binning_alloc(binning_user, ex4d_binning_bytes((int32_t)R, W, H));
     if (!bin_buf) return fail(EX4D_ERR_ALLOC, "binning buffer allocation failed");
@@ -312,21 +330,21 @@ static int forward_impl(
     if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
         // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
-        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, b.tile_ids, b.vals_tmp, stream), prm, stream);
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, b.tile_ids, b.vals_tmp, R, stream), prm, stream);
         MARK(0, "duplicate");
         STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
-                                 R, tile_bits(T), b.sort_hist, im.ranges, stream), prm, stream);
+                                 R, tile_bits(T), b.sort_hist, im.ranges, stream, n_dev), prm, stream);
         MARK(0, "tile_sort");
         MARK(0, "tile_ranges");
     } else {
         if (R > 0) {
-            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, k0, v0, stream), prm, stream);
+            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, k0, v0, R, stream), prm, stream);
             MARK(0, "duplicate");
             bool res_a = true;
-            STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream), prm, stream);
+            STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream, n_dev), prm, stream);
         }
         MARK(0, "tile_sort");
-        STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream), prm, stream);
+        STAGE(ex4d_launch_tile_ranges(R, T, b.tile_ids, im.ranges, stream, n_dev), prm, stream);
         MARK(0, "tile_ranges");
     }
     // 8. compositing
@@ -364,7 +382,7 @@ static int backward_impl(
 
     const int variant = g_bwd_variant.load(std::memory_order_relaxed);
     g_prof.begin(1, stream);
-    HIP_TRY(hipMemsetAsync(acc16, 0, (size_t)P * 16 * sizeof(float), stream));
+    HIP_TRY(ex4d_launch_zero(acc16, (size_t)P * 16 * sizeof(float), stream));
     MARK(1, "zero_accumulators");
     // colours (SH or precomputed, rasterizer_impl.cu:426) already sit in the records
     if (num_rendered > 0)

@@ -34,24 +34,29 @@ __device__ __forceinline__ int to_int_sat(float f)
 // atomics of 7.5 M instances at one per cycle and CU); with 8 copies a run of 64 equal digits costs 8 serial steps, not 64.
 template <int ITEMS, int BINS, int COPIES>
 __global__ __launch_bounds__(RS_THREADS) void rs_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift,
-    uint32_t mask, uint32_t nblocks, uint32_t *__restrict__ hist)
+    uint32_t mask, uint32_t nblocks, uint32_t *__restrict__ hist, const uint32_t *__restrict__ n_dev)
 {
+    // n_dev (asynchronous forward, Ex4dParams.instance_capacity): the item count lives in device memory, `n` is the capacity the grid
+    // was sized for; workgroups behind the last item write an all-zero column
+    if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }
     __shared__ uint32_t h_all[COPIES * (BINS + 1)];
     uint32_t *h = h_all + (COPIES > 1 ? (threadIdx.x % COPIES) * (BINS + 1) : 0);
     for (int b = threadIdx.x; b < COPIES * (BINS + 1); b += RS_THREADS) h_all[b] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
-    // all loads in flight before the first LDS atomic (clamped index instead of a branch per load)
-    uint32_t k[ITEMS];
+    if (base < n) {              // (uniform)
+        // all loads in flight before the first LDS atomic (clamped index instead of a branch per load)
+        uint32_t k[ITEMS];
 #pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t i = base + it * RS_THREADS + threadIdx.x;
-        k[it] = keys[i < n ? i : n - 1];
-    }
+        for (int it = 0; it < ITEMS; it++) {
+            const uint32_t i = base + it * RS_THREADS + threadIdx.x;
+            k[it] = keys[i < n ? i : n - 1];
+        }
 #pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t i = base + it * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(k[it] >> shift) & mask], 1u);
+        for (int it = 0; it < ITEMS; it++) {
+            const uint32_t i = base + it * RS_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[(k[it] >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < BINS; b += RS_THREADS) {
@@ -159,8 +164,10 @@ template <int ITEMS, int BINS, int MODE, int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
-    int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges)
+    int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges, const uint32_t *__restrict__ n_dev)
 {
+    if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }      // (see rs_histogram_kernel)
+    if (MODE != 2 && blockIdx.x * (uint32_t)(RS_THREADS * ITEMS) >= n) return;      // behind the last item (uniform: the whole workgroup)
     __shared__ uint32_t wave_cnt[4][BINS];        // per-wave digit counts -> exclusive block-local offsets
     __shared__ uint32_t local_start[BINS];        // first block-local slot of each digit
     __shared__ uint32_t global_base[BINS];        // global position of this block's first item of each digit
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t
 // ---------------------------------------------------------------- scan of tiles_touched in depth order
 __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint2 *__restrict__ rects,
     const uint32_t *__restrict__ order, uint2 *__restrict__ sorted_rects, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums,
-    int T, uint2 *__restrict__ ranges)
+    int T, uint2 *__restrict__ ranges, uint32_t *__restrict__ frame_total)
 {
     // every kernel launch costs ~5 us of ramp and tail on this part: the zero-fill of the tile ranges (cudaMemset at
     // CR/rasterizer_impl.cu:328) rides along here instead of being its own launch
@@ -392,7 +399,12 @@ __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint
         const int i = block_first + it * 256 + threadIdx.x;
         if (i < P) out[i] = cnt[it * 256 + threadIdx.x];
     }
-    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + x;
+    if (threadIdx.x == 255) {
+        block_sums[blockIdx.x] = woff + x;
+        // the frame's instance count in device memory (cleared with the frame flags): what the kernels behind this one read when the
+        // forward runs asynchronously (a few hundred fire-and-forget atomics spread over the kernel's duration)
+        atomicAdd(frame_total, woff + x);
+    }
 }
 
 // ---------------------------------------------------------------- duplication
@@ -426,8 +438,10 @@ struct DupRec { uint32_t off, gid, xy, w, magic; };
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
     const uint2 *__restrict__ sorted_rects,
-    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals)
+    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals, uint32_t cap)
 {
+    // cap: capacity of the output arrays -- the instance count itself (synchronous forward) or Ex4dParams.instance_capacity (an
+    // instance count above it truncates the stream: the caller sees that in the frame status and re-runs the frame)
     __shared__ DupRec s_rec[4][64];
     __shared__ uint32_t s_mark[4][64];
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
         uint32_t owner = wave_inclusive_max_u32(s_mark[wave][lane]);
         owner = owner > carry ? owner : carry;
         carry = (uint32_t)__builtin_amdgcn_readlane((int)owner, 63);
-        if (t < end) {                       // owner >= 1 here: slot `start` belongs to the first Gaussian with instances
+        if (t < end && t < cap) {            // owner >= 1 here: slot `start` belongs to the first Gaussian with instances
             const DupRec r = s_rec[wave][owner - 1u];
             const uint32_t local = t - r.off;
             uint32_t row = (r.w == 1u) ? local : __umulhi(local, r.magic);           // magic wraps to 0 for w == 1
@@ -490,9 +504,21 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
     }
 }
 
-// ---------------------------------------------------------------- tile ranges
-__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint32_t *__restrict__ tile_ids, uint2 *__restrict__ ranges)
+// ---------------------------------------------------------------- zero fill
+// The library clears its frame flags and the backward's accumulator rows with a kernel of its own instead of hipMemsetAsync: a memset
+// NODE of a captured graph was observed (ROCm 7.2, round 4: tools/dev/dbg_graph.py) to clear its target on the first replay only --
+// from the second replay on the frame-flag words held stale pointers-like values and the instance count came out as garbage + R.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *__restrict__ p, size_t n16)
 {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+
+// ---------------------------------------------------------------- tile ranges
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint32_t *__restrict__ tile_ids, uint2 *__restrict__ ranges,
+    const uint32_t *__restrict__ n_dev)
+{
+    if (n_dev) { const uint32_t nd = *n_dev; R = nd < R ? nd : R; }
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
     const uint32_t cur = tile_ids[i];
@@ -517,7 +543,7 @@ size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)512 * rs_blocks_for(n)
 int ex4d_radix_passes(uint32_t n, int end_bit) { const int mb = rs_max_bits_for(n); return (end_bit + mb - 1) / mb; }
 
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream)
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev)
 {
     *result_in_a = true;
     if (n == 0) return hipSuccess;
@@ -530,15 +556,15 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         const int nbits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);
         const uint32_t mask = (1u << nbits) - 1u;
         if (small) {
-            hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist, n_dev);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
-#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr)
+#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr, n_dev)
             if (nbits == 9) RS_SMALL_SCATTER(9); else if (nbits == 8) RS_SMALL_SCATTER(8); else RS_SMALL_SCATTER(0);
 #undef RS_SMALL_SCATTER
         } else {
-            hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist, n_dev);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr);
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr, n_dev);
         }
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
@@ -563,49 +589,60 @@ size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits) { return (size_t)256
 // keys / vals: the instances in depth order (from the duplication); packed: R words of scratch; point_list: the result; tile_ids_out:
 // optional (nullptr = not materialised); ranges must be zero (tiles without instances are never written)
 hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
-    uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream)
+    uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev)
 {
     if (R == 0) return hipSuccess;
     const int low_bits = (tile_bits + 1) / 2, high_bits = tile_bits - low_bits;
     const uint32_t nbA = rs_num_blocks(R), nbB = ts_max_blocks(R, tile_bits);
     uint32_t *histB = hist + (size_t)256 * (nbA + 1);
     const uint32_t *totals = hist + (size_t)256 * nbA;
-    hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 8>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist);
+    hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 8>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, R, low_bits, (1u << high_bits) - 1u, nbA, hist, n_dev);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << high_bits), dim3(256), 0, stream, nbA, hist, 256u);
 #define TS_SCATTER_A(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 1, NB>), dim3(nbA), dim3(RS_THREADS), 0, stream, keys, vals, packed, (uint32_t *)nullptr, \
-        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, 0, (uint2 *)nullptr)
+        R, low_bits, high_bits, nbA, hist, low_bits, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, n_dev)
     if (high_bits == 6) TS_SCATTER_A(6); else if (high_bits == 7) TS_SCATTER_A(7); else if (high_bits == 8) TS_SCATTER_A(8); else TS_SCATTER_A(0);
 #undef TS_SCATTER_A
     hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, totals, 1 << high_bits, 32 - low_bits, nbB, histB);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, histB, 256u);
 #define TS_SCATTER_B(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2, NB>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list, \
-        R, 32 - low_bits, low_bits, nbB, histB, low_bits, totals, 1 << high_bits, ranges)
+        R, 32 - low_bits, low_bits, nbB, histB, low_bits, totals, 1 << high_bits, ranges, (const uint32_t *)nullptr)
     if (low_bits == 7) TS_SCATTER_B(7); else if (low_bits == 8) TS_SCATTER_B(8); else TS_SCATTER_B(0);
 #undef TS_SCATTER_B
     return hipGetLastError();
 }
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
-    uint32_t *block_sums, int T, uint2 *ranges, hipStream_t stream)
+    uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream)
 {
     const int nb = (P + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, rects, order, sorted_rects, sorted_offsets, block_sums, T, ranges);
+    hipLaunchKernelGGL(scan_tiles_local_kernel, dim3(nb), dim3(256), 0, stream, P, rects, order, sorted_rects, sorted_offsets, block_sums, T, ranges, frame_total);
     return hipGetLastError();
 }
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream)
+    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        sorted_rects, tile_keys, vals);
+        sorted_rects, tile_keys, vals, cap);
     return hipGetLastError();
 }
 
-hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream)
+hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream)
+{
+    // ptr and bytes are multiples of 16 (256-byte aligned regions of the scratch buffers)
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    size_t blocks = (n16 + 1023) / 1024;                 // 4 stores of 16 bytes per thread
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint4 *)ptr, n16);
+    return hipGetLastError();
+}
+
+hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev)
 {
     (void)T;      // the ranges were zeroed by the scan kernel
     if (R > 0)
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, tile_ids, ranges);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, tile_ids, ranges, n_dev);
     return hipGetLastError();
 }

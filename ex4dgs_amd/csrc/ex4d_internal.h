@@ -33,7 +33,7 @@ struct GeomState {
     uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
-    uint32_t *total;                                     // frame flags: [0] unused, [1] prefilter violation, [2] some visible Gaussian has dir3D != 0, [3] EX4D_DSUMS_MARK when sh_dsums was written
+    uint32_t *total;                                     // frame flags (Ex4dFrameStatus): [0] instance count (summed by the tile scan), [1] prefilter violation, [2] some visible Gaussian has dir3D != 0, [3] EX4D_DSUMS_MARK when sh_dsums was written
     uint32_t *block_totals;                              // instance counts of preprocess_fwd per chunk of 64 Gaussians (summed on the host)
     float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on request (Ex4dParams.prepare_backward)
 };
@@ -88,8 +88,9 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
 
 // stable LSD radix sort of (key,value) uint32 pairs over key bits [0, end_bit); result lands in
 // (keys_out, vals_out) which must be one of the two ping-pong pairs; returns which through *result_in_a.
+// n_dev (optional): the item count in device memory, n then is the capacity the grids are sized for (asynchronous forward)
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream);
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev = nullptr);
 size_t ex4d_radix_hist_words(uint32_t n);
 int ex4d_radix_passes(uint32_t n, int end_bit);      // number of passes ex4d_radix_sort_pairs will run (decides where the result lands)
 
@@ -97,13 +98,14 @@ int ex4d_radix_passes(uint32_t n, int end_bit);      // number of passes ex4d_ra
 bool ex4d_tile_sort_msd_applies(int P, int tile_bits);
 size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits);
 hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
-    uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream);
+    uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
-    uint32_t *block_sums, int T, uint2 *ranges, hipStream_t stream);
+    uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, hipStream_t stream);
-hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream);
+    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream);
+hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // bytes and ptr multiples of 16
+hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 
 void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: bit 0 staggered wave priorities, bit 1 SH rows predicated on the frustum test
 int ex4d_get_preprocess_tune();

@@ -70,6 +70,13 @@ struct Ex4dTrainer {
           *g_rotations = nullptr, *g_dir = nullptr;
     void *bwd_scratch = nullptr;
     Arena geom, binning, img;
+    // asynchronous rasterizer forward (ex4d_trainer_set_async): capacity of the binning buffer in tile instances (0 = not known yet: the
+    // next frame runs synchronously and seeds it), the frame status in pinned host memory, the event behind the forward
+    bool async = false;
+    uint32_t capacity = 0;
+    Ex4dFrameStatus *status = nullptr;
+    hipEvent_t status_ev = nullptr;
+    int64_t replays = 0;
     void *owned[96] = {};
     int n_owned = 0;
 
@@ -99,6 +106,8 @@ void ex4d_trainer_destroy(Ex4dTrainer *t)
     if (t->geom.ptr) (void)hipFree(t->geom.ptr);
     if (t->binning.ptr) (void)hipFree(t->binning.ptr);
     if (t->img.ptr) (void)hipFree(t->img.ptr);
+    if (t->status) (void)hipHostFree(t->status);
+    if (t->status_ev) (void)hipEventDestroy(t->status_ev);
     delete t;
 }
 
@@ -198,35 +207,62 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
     Ex4dParams prm;
     prm.P = t->P; prm.D = c.sh_degree; prm.M = 16; prm.W = c.W; prm.H = c.H; prm.tanfovx = c.tanfovx; prm.tanfovy = c.tanfovy;
     prm.kernel_size = c.kernel_size; prm.scale_modifier = 1.0f; prm.min_depth = c.min_depth; prm.max_depth = c.max_depth;
-    prm.prefiltered = 0; prm.debug = 0; prm.prepare_backward = 1; prm.reserved = 0;
+    prm.prefiltered = 0; prm.debug = 0; prm.prepare_backward = 1; prm.instance_capacity = 0; prm.assume_no_flow = 0; prm.reserved = 0;
     Ex4dSplitSH sh;
     sh.dc[0] = p[5]; sh.rest[0] = p[6]; sh.dc[1] = p[13]; sh.rest[1] = p[14]; sh.n_static = c.Ns;
-    int32_t R = 0;
-    int rc = ex4d_forward_split_sh(&prm, background, t->means3D, nullptr, &sh, t->opacities, t->scales, t->rotations, nullptr,
-                                   viewmatrix, projmatrix, campos, nullptr, arena_alloc, &t->geom, arena_alloc, &t->binning, arena_alloc, &t->img,
-                                   t->color, t->radii, t->depth, t->acc, t->flow, t->idx, stream, &R);
-    if (rc) return tfail(rc, "rasterizer forward: %s", ex4d_last_error());
-    if (num_rendered) *num_rendered = R;
-
-    if (ex4d_l1_ssim_forward(3, c.H, c.W, t->color, gt_image, c.lambda_dssim, c.window, t->loss, nullptr, nullptr, t->dmaps, t->loss_scratch, stream))
-        return tfail(EX4D_ERR_HIP, "loss forward: %s", ex4d_loss_last_error());
-    if (ex4d_l1_ssim_backward(3, c.H, c.W, t->color, gt_image, c.lambda_dssim, c.window, t->dmaps, t->grad_loss, t->grad_img, stream))
-        return tfail(EX4D_ERR_HIP, "loss backward: %s", ex4d_loss_last_error());
-
     Ex4dSplitSHGrad gsh;
     gsh.dc[0] = t->grad[5]; gsh.rest[0] = t->grad[6]; gsh.dc[1] = t->grad[13]; gsh.rest[1] = t->grad[14]; gsh.n_static = c.Ns;
-    rc = ex4d_backward_split_sh(&prm, R, background, t->means3D, t->radii, &sh, t->scales, t->rotations, nullptr, viewmatrix, projmatrix, campos,
-                                nullptr, t->depth, t->acc, t->geom.ptr, t->binning.ptr, t->img.ptr, t->grad_img, nullptr, nullptr, nullptr,
-                                t->g_means2D, nullptr, t->g_opacity, t->g_means3D, nullptr, &gsh, t->g_scales, t->g_rotations, t->g_dir,
-                                t->bwd_scratch, stream);
-    if (rc) return tfail(rc, "rasterizer backward: %s", ex4d_last_error());
-
     float *const *g = t->grad;
-    if (ex4d_attributes_backward_sliced(&a, p[3], p[4], p[8], p[9], p[10], p[11], p[12],
-                                        t->g_means3D, t->g_rotations, t->g_opacity, t->g_scales, nullptr,
-                                        g[0], g[1], g[2], g[3], g[4], nullptr, nullptr, g[7], g[8], g[9], g[10], g[11], g[12], nullptr, nullptr,
-                                        t->slices, stream))
-        return tfail(EX4D_ERR_HIP, "attributes backward: %s", ex4d_attributes_last_error());
+    // Asynchronous mode: the forward does not wait for the instance count (the reference's one host synchronisation per frame,
+    // rasterizer_impl.cu:298-299); the frame's status is looked at once, right before the optimizer step -- by then every kernel of the
+    // frame is enqueued, the GPU has work for the rest of the iteration, and the status copy (it sits behind the tile scan, early in the
+    // frame) has usually landed.  A frame whose instance count exceeded the capacity is simply run again with a larger one before anything
+    // is applied: the parameters see exactly the gradients of the synchronous path.
+    for (int attempt = 0; ; attempt++) {
+        const bool async_frame = t->async && t->capacity > 0;
+        prm.instance_capacity = async_frame ? (int32_t)t->capacity : 0;
+        prm.assume_no_flow = async_frame ? 1 : 0;            // (dir3D is NULL: no Gaussian carries a flow vector)
+        int32_t R = 0;
+        int rc = ex4d_forward_split_sh(&prm, background, t->means3D, nullptr, &sh, t->opacities, t->scales, t->rotations, nullptr,
+                                       viewmatrix, projmatrix, campos, nullptr, arena_alloc, &t->geom, arena_alloc, &t->binning, arena_alloc, &t->img,
+                                       t->color, t->radii, t->depth, t->acc, t->flow, t->idx, stream,
+                                       async_frame ? reinterpret_cast<int32_t *>(t->status) : &R);
+        if (rc) return tfail(rc, "rasterizer forward: %s", ex4d_last_error());
+        if (async_frame) {
+            if (hipEventRecord(t->status_ev, (hipStream_t)stream) != hipSuccess) return tfail(EX4D_ERR_HIP, "event record failed");
+            R = (int32_t)t->capacity;                        // the backward lays the buffers out for the capacity
+        }
+
+        if (ex4d_l1_ssim_forward(3, c.H, c.W, t->color, gt_image, c.lambda_dssim, c.window, t->loss, nullptr, nullptr, t->dmaps, t->loss_scratch, stream))
+            return tfail(EX4D_ERR_HIP, "loss forward: %s", ex4d_loss_last_error());
+        if (ex4d_l1_ssim_backward(3, c.H, c.W, t->color, gt_image, c.lambda_dssim, c.window, t->dmaps, t->grad_loss, t->grad_img, stream))
+            return tfail(EX4D_ERR_HIP, "loss backward: %s", ex4d_loss_last_error());
+
+        rc = ex4d_backward_split_sh(&prm, R, background, t->means3D, t->radii, &sh, t->scales, t->rotations, nullptr, viewmatrix, projmatrix, campos,
+                                    nullptr, t->depth, t->acc, t->geom.ptr, t->binning.ptr, t->img.ptr, t->grad_img, nullptr, nullptr, nullptr,
+                                    t->g_means2D, nullptr, t->g_opacity, t->g_means3D, nullptr, &gsh, t->g_scales, t->g_rotations, t->g_dir,
+                                    t->bwd_scratch, stream);
+        if (rc) return tfail(rc, "rasterizer backward: %s", ex4d_last_error());
+
+        if (ex4d_attributes_backward_sliced(&a, p[3], p[4], p[8], p[9], p[10], p[11], p[12],
+                                            t->g_means3D, t->g_rotations, t->g_opacity, t->g_scales, nullptr,
+                                            g[0], g[1], g[2], g[3], g[4], nullptr, nullptr, g[7], g[8], g[9], g[10], g[11], g[12], nullptr, nullptr,
+                                            t->slices, stream))
+            return tfail(EX4D_ERR_HIP, "attributes backward: %s", ex4d_attributes_last_error());
+
+        uint32_t count = (uint32_t)R;
+        if (async_frame) {
+            if (hipEventSynchronize(t->status_ev) != hipSuccess) return tfail(EX4D_ERR_HIP, "event wait failed");
+            count = t->status->num_rendered;
+        }
+        if (num_rendered) *num_rendered = (int32_t)count;
+        const uint32_t want = count + count / 4 + 4096;      // 25 % headroom over the largest frame seen
+        const bool overflow = async_frame && count > t->capacity;
+        if (t->async && want > t->capacity) t->capacity = want < 0x7FFFFFFFu ? want : 0x7FFFFFFFu;
+        if (!overflow) break;
+        if (attempt >= 2) return tfail(EX4D_ERR_HIP, "internal: the frame overflowed its instance capacity three times");
+        t->replays++;
+    }
 
     if (c.optimizer) {
         t->step += 1;
@@ -253,6 +289,20 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
     }
     return EX4D_OK;
 }
+
+int ex4d_trainer_set_async(Ex4dTrainer *t, int32_t on)
+{
+    t_err[0] = 0;
+    if (!t) return tfail(EX4D_ERR_ARG, "null argument");
+    if (on && !t->status) {
+        if (hipHostMalloc((void **)&t->status, sizeof(Ex4dFrameStatus), hipHostMallocDefault) != hipSuccess) { t->status = nullptr; return tfail(EX4D_ERR_HIP, "pinned status allocation failed"); }
+        if (hipEventCreateWithFlags(&t->status_ev, hipEventDisableTiming) != hipSuccess) { t->status_ev = nullptr; return tfail(EX4D_ERR_HIP, "event creation failed"); }
+    }
+    t->async = on != 0;
+    return EX4D_OK;
+}
+
+int64_t ex4d_trainer_replays(const Ex4dTrainer *t) { return t ? t->replays : 0; }
 
 int ex4d_trainer_set_lr(Ex4dTrainer *t, const double *lr15)
 {

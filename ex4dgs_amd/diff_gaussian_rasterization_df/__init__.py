@@ -42,6 +42,80 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+class AsyncFrames:
+    """Opt-in policy of the autograd surface for the ASYNCHRONOUS forward (include/ex4d_rasterizer.h: Ex4dParams.instance_capacity).
+
+    The reference blocks the host once per frame to read the instance count back (rasterizer_impl.cu:298-299) and so does this
+    package by default.  `async_frames.enable()` removes that wait: the binning buffer is sized for
+    `headroom x the largest instance count seen so far` (the first frame runs synchronously and seeds it), `ctx.num_rendered`
+    becomes a `_C.PendingFrame` (an int on demand) and the status of a frame is looked at when it costs nothing -- at the start
+    of the NEXT forward, by which time its copy has long landed.  A frame whose instance count exceeded the capacity had its tile
+    lists truncated: its outputs and gradients are invalid.  That cannot be repaired behind the caller's back (the image was
+    already consumed), so it is reported: `strict` (default) raises at the next forward, otherwise `invalid_frames` counts and the
+    capacity grows.  Callers that own the whole iteration (trainer.FrameTrainer, the compiled NativeTrainer) check the status
+    before their optimizer step and RE-RUN the frame instead -- exact results, no wait on the critical path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.headroom = 1.25
+        self.strict = True
+        self.capacity = 0
+        self.no_flow = False            # launch the flow-free kernel (learned from the frames' has_flow flag)
+        self.pending = []
+        self.invalid_frames = 0
+        self.frames = 0
+
+    def enable(self, headroom=1.25, capacity=0, strict=True):
+        self.enabled, self.headroom, self.strict, self.capacity = True, float(headroom), bool(strict), int(capacity)
+        self.pending, self.no_flow, self.invalid_frames, self.frames = [], False, 0, 0
+        return self
+
+    def disable(self):
+        self.drain()
+        self.enabled = False
+
+    def observe(self, num_rendered):
+        need = int(self.headroom * int(num_rendered)) + 4096
+        if need > self.capacity:
+            self.capacity = min(need, 0x7FFFFFFF)
+
+    def _settle(self, fr):
+        self.observe(fr.num_rendered)
+        self.no_flow = not fr.has_flow
+        if not fr.valid:
+            self.invalid_frames += 1
+            if self.strict:
+                raise RuntimeError(f"asynchronous rasterizer frame invalid: {fr.num_rendered} tile instances exceed the capacity {fr.capacity}"
+                                   if fr.overflowed else "asynchronous rasterizer frame invalid: dir3D was not zero although the flow-free kernel ran")
+
+    def poll(self):
+        """Settle every frame whose status has arrived (never blocks)."""
+        while self.pending and self.pending[0].done():
+            self._settle(self.pending.pop(0))
+
+    def drain(self):
+        """Settle every outstanding frame (waits for the stream)."""
+        while self.pending:
+            self._settle(self.pending.pop(0).wait())
+
+    def next_call(self):
+        """(instance_capacity, assume_no_flow) for the next forward; capacity 0 = run synchronously (nothing known yet)."""
+        if not self.enabled:
+            return 0, False
+        self.poll()
+        return self.capacity, self.no_flow
+
+    def record(self, num_rendered):
+        self.frames += 1
+        if isinstance(num_rendered, _C.PendingFrame):
+            self.pending.append(num_rendered)
+        elif self.enabled:
+            self.observe(num_rendered)
+
+
+async_frames = AsyncFrames()
+
+
 def _snapshot(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
@@ -73,11 +147,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         # a backward will follow iff some input wants a gradient: the forward then also leaves the SH direction sums of the SH
         # backward in its geometry buffer (it has the SH rows in registers anyway), and the backward does not read the SH tensors
         ctx.prepared = any(ctx.needs_input_grad)
-        native_fwd = lambda *a: _C.rasterize_gaussians(*a, prepare_backward=ctx.prepared)
+        capacity, no_flow = (0, False) if s.debug else async_frames.next_call()      # (debug synchronises after every stage)
+        native_fwd = lambda *a: _C.rasterize_gaussians(*a, prepare_backward=ctx.prepared, instance_capacity=capacity, assume_no_flow=no_flow)
         (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idxs) = _call_native(
             native_fwd, args, s.debug, "snapshot_fw.dump", "forward")
+        async_frames.record(num_rendered)
         ctx.raster_settings = s
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = num_rendered          # an int, or a _C.PendingFrame (asynchronous forward): the backward needs its capacity only
         # outputs that take no part in the loss arrive in backward as None instead of freshly filled zero tensors
         # (the native backward treats a null upstream gradient as zeros)
         ctx.set_materialize_grads(False)

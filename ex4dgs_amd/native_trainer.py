@@ -19,7 +19,7 @@ from .trainer import reference_lrs
 
 EXPORTS = ("ex4d_trainer_last_error", "ex4d_trainer_create", "ex4d_trainer_destroy", "ex4d_trainer_step", "ex4d_trainer_output",
            "ex4d_trainer_grad", "ex4d_trainer_read", "ex4d_trainer_bytes", "ex4d_trainer_time_scalars", "ex4d_trainer_set_lr",
-           "ex4d_trainer_set_sh_degree")
+           "ex4d_trainer_set_sh_degree", "ex4d_trainer_set_async", "ex4d_trainer_replays")
 
 
 class Ex4dTrainerConfig(C.Structure):
@@ -52,6 +52,10 @@ def _lib():
         lib.ex4d_trainer_set_lr.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.ex4d_trainer_set_sh_degree.restype = C.c_int
         lib.ex4d_trainer_set_sh_degree.argtypes = [C.c_void_p, C.c_int32]
+        lib.ex4d_trainer_set_async.restype = C.c_int
+        lib.ex4d_trainer_set_async.argtypes = [C.c_void_p, C.c_int32]
+        lib.ex4d_trainer_replays.restype = C.c_int64
+        lib.ex4d_trainer_replays.argtypes = [C.c_void_p]
         lib.ex4d_trainer_bytes.restype = C.c_size_t
         lib.ex4d_trainer_bytes.argtypes = [C.c_void_p]
         lib._trainer_ready = True
@@ -132,6 +136,15 @@ class NativeTrainer:
             raise RuntimeError(_lib().ex4d_trainer_last_error().decode())
         self.cfg.sh_degree = int(degree)
         self.model.active_sh_degree = int(degree)
+
+    def set_async(self, on=True):
+        """Asynchronous rasterizer forward (no instance-count read-back in the middle of the frame; include/ex4d_trainer.h):
+        same parameters as the synchronous path -- a frame that overflows its capacity is re-run before the optimizer step."""
+        if _lib().ex4d_trainer_set_async(self.handle, int(bool(on))):
+            raise RuntimeError(_lib().ex4d_trainer_last_error().decode())
+
+    def replays(self):
+        return int(_lib().ex4d_trainer_replays(self.handle))
 
     def output(self, what):
         """Copies of the trainer's outputs of the last step: 'loss', 'render', 'radii', 'viewspace_grad', 'depth', 'acc'."""

@@ -50,8 +50,30 @@ typedef struct Ex4dParams {
                                  the SH tensors at all (-155 MB of 535 at 1.0 M Gaussians).  0 = the backward reads them itself.
                                  The forward marks the geometry buffer when it stored the sums; a backward that asks for them on a
                                  buffer whose forward ran with 0 returns NaN gradients (never numbers computed from uninitialised memory). */
+    int32_t instance_capacity;/* 0 (default): the reference's behaviour -- the forward reads the instance count back (one blocking 4-byte D2H,
+                                 rasterizer_impl.cu:298-299) and sizes the binning buffer exactly.
+                                 > 0: ASYNCHRONOUS forward.  The binning buffer is sized for this many (Gaussian, tile) instances, every kernel
+                                 behind the tile scan reads the actual count from device memory, NOTHING blocks the host and every launch
+                                 has a host-constant grid (the call sequence can be captured into a hipGraph).  `num_rendered` must then
+                                 point to PINNED HOST memory (or device memory) of Ex4dFrameStatus size, filled by an asynchronous copy on
+                                 `stream`; the caller looks at it after synchronising with the stream (or an event recorded behind the call).  An instance count
+                                 above the capacity truncates the tile lists: status.num_rendered > capacity tells, the frame's outputs
+                                 are then invalid and the caller re-runs it with a larger capacity.  The matching backward takes
+                                 num_rendered = this capacity (it sizes the same buffer layout; the kernels read the actual ranges). */
+    int32_t assume_no_flow;   /* asynchronous forward only: 1 = the caller asserts that every dir3D of the frame is zero (the training loop's
+                                 gradient trap, gaussian_renderer/__init__.py:66-70) and the flow-free compositing kernel is launched;
+                                 status.has_flow != 0 reports a violated assertion (flow output invalid).  0 = the kernel with flow.
+                                 (The synchronous forward picks the kernel from the frame flag it reads back.) */
     int32_t reserved;
 } Ex4dParams;
+
+/* What an ASYNCHRONOUS forward (Ex4dParams.instance_capacity > 0) leaves in the caller's pinned host memory */
+typedef struct Ex4dFrameStatus {
+    uint32_t num_rendered;        /* (Gaussian, tile) instances of the frame; > capacity: lists truncated, frame invalid */
+    uint32_t prefilter_violation; /* != 0: prefiltered was set and a Gaussian was culled (the synchronous call returns EX4D_ERR_PREFILTERED) */
+    uint32_t has_flow;            /* != 0: some visible Gaussian carries a non-zero dir3D */
+    uint32_t reserved[5];
+} Ex4dFrameStatus;
 
 /* Scratch allocation callback: must return a device pointer to at least `bytes` bytes, 256-byte aligned,
  * that stays valid until the matching backward has run (the reference resizes a torch byte tensor). */
@@ -79,6 +101,9 @@ const char *ex4d_target_arch(void);
  * (no pre-initialisation needed; out_idx = -1 where nothing contributed).
  * *num_rendered receives the number of (Gaussian, tile) instances (host int, one blocking 4-byte D2H
  * exactly like rasterizer_impl.cu:298-299).  P == 0 is handled by the caller (rasterize_points.cu:90).
+ * With Ex4dParams.instance_capacity > 0 the call is asynchronous and `num_rendered` is an Ex4dFrameStatus in pinned host
+ * memory (see Ex4dParams); such a call enqueues only kernels, memsets and one device-to-host copy, so it may run under
+ * hipStreamBeginCapture (with the per-stage profiler off and allocation callbacks that are legal during capture).
  */
 int ex4d_forward(
     const Ex4dParams *prm,

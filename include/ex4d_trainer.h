@@ -75,6 +75,12 @@ int ex4d_trainer_step(Ex4dTrainer *t, double timestamp, const float *viewmatrix,
  * (c_gaussian_model.py:451-470) and oneupSHdegree (train.py:113-114) of the reference change them during training. */
 int ex4d_trainer_set_lr(Ex4dTrainer *t, const double *lr15);
 int ex4d_trainer_set_sh_degree(Ex4dTrainer *t, int32_t degree);
+/* on != 0: the rasterizer forward runs ASYNCHRONOUSLY (ex4d_rasterizer.h: Ex4dParams.instance_capacity) -- no instance-count read-back
+ * in the middle of the frame; the binning arena is sized for 1.25 x the largest instance count seen (the first frame runs synchronously
+ * and seeds it), the frame's status is looked at once, right before the optimizer step, and a frame that overflowed its capacity is run
+ * again before anything is applied: same parameters as the synchronous path.  ex4d_trainer_replays counts such re-runs. */
+int ex4d_trainer_set_async(Ex4dTrainer *t, int32_t on);
+int64_t ex4d_trainer_replays(const Ex4dTrainer *t);
 
 /* Device pointers into the trainer's workspace, valid until the next step / destroy:
  * what = 0 loss [1], 1 render [3,H,W], 2 radii int32 [P], 3 dL_dmeans2D [P,3] (viewspace gradient, densification statistics),

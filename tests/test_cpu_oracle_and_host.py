@@ -315,7 +315,7 @@ def test_wrapper_marshalling_matches_reference_golden(monkeypatch):
     rec = {}
 
     def fwd(*args, **extension):      # prepare_backward: keyword-only extension, the positional arguments are the reference's
-        assert set(extension) <= {"prepare_backward"}
+        assert set(extension) <= {"prepare_backward", "instance_capacity", "assume_no_flow"} and not extension.get("instance_capacity")
         rec["fwd"] = args
         P, H, W = args[1].shape[0], args[15], args[16]
         z = torch.zeros
@@ -626,14 +626,14 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     for name in declared:
         assert hasattr(handle, name), name
     l = _C.load()
-    assert l.ex4d_abi_version() == 3 and l.ex4d_target_arch() == b"gfx950"
+    assert l.ex4d_abi_version() == 4 and l.ex4d_target_arch() == b"gfx950"
     # size / layout queries are pure host code
     P = 1000
     lay = _C.GeomLayout(); l.ex4d_geom_layout(P, ctypes.byref(lay))
     assert lay.total == l.ex4d_geom_bytes(P) and lay.cov3D >= 64 * P and lay.cov3D % 256 == 0 and lay.records == 0
     assert l.ex4d_binning_bytes(0, 64, 64) > 0 and l.ex4d_img_bytes(1352, 1014) >= 1352 * 1014 * 8 + 5440 * 8
     assert l.ex4d_backward_scratch_bytes(P) >= P * 64
-    assert ctypes.sizeof(_C.Ex4dParams) == 15 * 4
+    assert ctypes.sizeof(_C.Ex4dParams) == 17 * 4
     # the kernels are gfx950 code objects
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={lib}"], capture_output=True, text=True)
     if out.returncode == 0 and out.stdout.strip():

@@ -1,0 +1,208 @@
+"""GPU tests of round 4's asynchronous forward (Ex4dParams.instance_capacity): no instance-count read-back, host-constant grids,
+the frame status in pinned host memory behind an event; overflow detection and recovery; hipGraph capture and replay."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_forward(ins, st, device="cuda", settings=None, **kw):
+    from ex4dgs_amd import _C
+    s = h.gpu_settings(st, device) if settings is None else settings      # (building them copies host tensors: not inside a capture)
+    e = torch.Tensor([])
+    d = lambda k: ins[k].to(device) if ins.get(k) is not None else e
+    return s, _C.rasterize_gaussians(s.bg, d("means3D"), d("dir3D"), d("colors_precomp"), d("opacities"), d("scales"), d("rotations"),
+                                     s.scale_modifier, d("cov3D_precomp"), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size,
+                                     s.subpixel_offset, s.image_height, s.image_width, d("shs"), s.sh_degree, s.campos, s.prefiltered,
+                                     s.min_depth, s.max_depth, s.debug, **kw)
+
+
+def _raw_backward(ins, s, fwd, grads, device="cuda", **kw):
+    from ex4dgs_amd import _C
+    e = torch.Tensor([])
+    d = lambda k: ins[k].to(device) if ins.get(k) is not None else e
+    R, color, radii, geom, binning, img, depth, acc, flow, idx = fwd
+    gc, gd, gf, ga = grads
+    return _C.rasterize_gaussians_backward(
+        s.bg, d("means3D"), radii, d("colors_precomp"), d("scales"), d("rotations"), depth, acc, s.min_depth, s.max_depth, s.scale_modifier,
+        d("cov3D_precomp"), s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.kernel_size, s.subpixel_offset, gc, gd, gf, ga, d("shs"),
+        s.sh_degree, s.campos, geom, R, binning, img, s.debug, **kw)
+
+
+@pytest.mark.parametrize("cfg,P,dir_scale", [("cfg2", 20000, 0.1), ("cfg3", 12000, 0.0), ("cfg1", None, 0.1)])
+def test_asynchronous_forward_equals_the_synchronous_one(hip_lib, cfg, P, dir_scale):
+    """Same frame through the reference-style forward (blocking instance-count read-back, exact buffer) and through the asynchronous
+    one (capacity-sized buffer, count read from device memory by every kernel behind the scan): every output bit-equal, the sorted
+    point list and the tile ranges equal, the status word equal to the synchronous count; the backward on the capacity-sized buffers
+    returns the same gradients (to the order of the float atomics).  cfg1 (256x256: 256 tiles) takes the key/value tile sort."""
+    from ex4dgs_amd import _C
+    ins, st = h.scene_inputs(cfg, P=P, dir_scale=dir_scale)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    s, sync = _raw_forward(ins, st)
+    R = sync[0]
+    assert isinstance(R, int) and R > 0
+    for cap, no_flow in ((R, False), (R + 12345, dir_scale == 0.0), (4 * R, False)):
+        s2, asy = _raw_forward(ins, st, instance_capacity=cap, assume_no_flow=no_flow)
+        fr = asy[0]
+        assert isinstance(fr, _C.PendingFrame) and fr.capacity == cap
+        assert int(fr) == R and not fr.overflowed and fr.valid and fr.has_flow == (dir_scale != 0.0)
+        for name, a, b in zip(("color", "radii", "depth", "acc", "flow", "idx"), (sync[1], sync[2], sync[6], sync[7], sync[8], sync[9]),
+                              (asy[1], asy[2], asy[6], asy[7], asy[8], asy[9])):
+            assert torch.equal(a, b), name
+        H, W = st["image_height"], st["image_width"]
+        va, vb = _C.binning_views(sync[4], R, W, H), _C.binning_views(asy[4], fr, W, H)
+        assert torch.equal(va["point_list"][:R], vb["point_list"][:R])
+        assert torch.equal(_C.img_views(sync[5], W, H)["ranges"], _C.img_views(asy[5], W, H)["ranges"])
+        grads = [x.cuda() for x in h.upstream_grads(sync[7].cpu(), H, W, seed=4)]
+        ga = _raw_backward(ins, s, sync, grads)
+        gb = _raw_backward(ins, s2, asy, grads)
+        for name, a, b in zip(h.GRAD_NAMES, (ga[0], ga[1], ga[2], ga[8], ga[3], ga[4], ga[5], ga[6], ga[7]), (gb[0], gb[1], gb[2], gb[8], gb[3], gb[4], gb[5], gb[6], gb[7])):
+            if a.numel():
+                tol = 2e-5 * float(a.abs().max()) + 1e-12
+                assert float((a - b).abs().max()) <= tol, (name, cap)
+
+
+def test_overflow_is_reported_and_the_autograd_surface_recovers(hip_lib):
+    """An instance count above the capacity: nothing is written out of bounds, the status says so (num_rendered > capacity), the
+    policy object of the autograd surface raises at the next forward (strict) or counts and regrows (non-strict), and the frame
+    rendered again with the regrown capacity equals the synchronous frame."""
+    from ex4dgs_amd import _C
+    from ex4dgs_amd.diff_gaussian_rasterization_df import async_frames, rasterize_gaussians
+    ins, st = h.scene_inputs("cfg2", P=20000, dir_scale=0.0)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    s, sync = _raw_forward(ins, st)
+    R = sync[0]
+    guard = torch.full((1 << 20,), 7, dtype=torch.uint8, device="cuda")          # neighbours in the caching allocator stay untouched
+    s2, asy = _raw_forward(ins, st, instance_capacity=R // 3)
+    fr = asy[0]
+    assert fr.num_rendered == R and fr.overflowed and not fr.valid
+    assert bool((guard == 7).all()) and bool(torch.isfinite(asy[1]).all())
+    grads = [x.cuda() for x in h.upstream_grads(sync[7].cpu(), st["image_height"], st["image_width"], seed=4)]
+    gb = _raw_backward(ins, s2, asy, grads)                                     # truncated lists: finite garbage, no fault
+    assert all(bool(torch.isfinite(g).all()) for g in gb if g.numel())
+    e = torch.Tensor([])
+    call = lambda: rasterize_gaussians(ins["means3D"], torch.zeros_like(ins["means3D"]), ins["dir3D"], ins["shs"], e, ins["opacities"],
+                                       ins["scales"], ins["rotations"], e, s)
+    try:
+        async_frames.enable(headroom=1.25, capacity=R // 3, strict=True)
+        out1 = call()                                                           # runs truncated ...
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="exceed the capacity"):
+            call()                                                              # ... and is reported here
+        assert async_frames.capacity >= int(1.25 * R)
+        async_frames.enable(headroom=1.25, capacity=R // 3, strict=False)
+        call(); torch.cuda.synchronize()
+        out2 = call()                                                           # regrown: this one is whole
+        async_frames.drain()
+        assert async_frames.invalid_frames == 1 and async_frames.no_flow
+        assert torch.equal(out2[0], sync[1]) and torch.equal(out2[5], sync[9])
+        out3 = call()                                                           # now with the flow-free kernel (learned from the status)
+        async_frames.drain()
+        assert torch.equal(out3[0], sync[1]) and async_frames.invalid_frames == 1
+    finally:
+        async_frames.enabled = False
+        async_frames.pending = []
+
+
+def test_wrong_no_flow_assertion_is_reported(hip_lib):
+    ins, st = h.scene_inputs("cfg1", dir_scale=0.1)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    s, sync = _raw_forward(ins, st)
+    s2, asy = _raw_forward(ins, st, instance_capacity=sync[0] + 10, assume_no_flow=True)
+    assert asy[0].has_flow and not asy[0].valid and not asy[0].overflowed
+    assert torch.equal(asy[1], sync[1]) and float(asy[8].abs().max()) == 0.0     # colour is right, the flow image was not composited
+
+
+def test_forward_and_backward_replay_from_a_hip_graph(hip_lib):
+    """The asynchronous call sequence has host-constant grids and no host wait: forward + backward are captured into ONE graph
+    (torch.cuda.graph = hipStreamBeginCapture underneath), replayed on new input values, and match the eager calls."""
+    from ex4dgs_amd import _C
+    ins, st = h.scene_inputs("cfg2", P=20000, dir_scale=0.0)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    s, sync = _raw_forward(ins, st)
+    R = sync[0]
+    H, W = st["image_height"], st["image_width"]
+    grads = [x.cuda() for x in h.upstream_grads(sync[7].cpu(), H, W, seed=4)]
+    cap = int(1.5 * R)
+    static = {k: v.clone() for k, v in ins.items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up on the capture stream (allocator, lazy module loading)
+        _, f = _raw_forward(static, st, settings=s, instance_capacity=cap, assume_no_flow=True)
+        _raw_backward(static, s, f, grads)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s3, fwd = _raw_forward(static, st, settings=s, instance_capacity=cap, assume_no_flow=True)
+        bwd = _raw_backward(static, s3, fwd, grads)
+    for shift in (0.0, 0.05):
+        moved = ins["means3D"] + shift * torch.tensor([1.0, 0.0, 0.0], device="cuda")
+        static["means3D"].copy_(moved)
+        g.replay()
+        torch.cuda.synchronize()
+        eager_in = dict(ins, means3D=moved)
+        s4, ref = _raw_forward(eager_in, st)
+        assert fwd[0].wait().num_rendered == ref[0] and fwd[0].valid
+        assert torch.equal(fwd[1], ref[1]) and torch.equal(fwd[9], ref[9]) and torch.equal(fwd[2], ref[2])
+        gref = _raw_backward(eager_in, s4, ref, grads)
+        for a, b in zip(bwd, gref):
+            if a.numel():
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+
+
+def test_compiled_host_path_asynchronous_mode_is_exact_and_replays_overflowing_frames(hip_lib):
+    """include/ex4d_trainer.h with ex4d_trainer_set_async: no instance-count read-back inside the frame, the status is checked once
+    before the optimizer step.  Two copies of one model, synchronous vs asynchronous, over views whose instance counts differ by much
+    more than the 25 % headroom (a wide and a narrow field of view): the asynchronous trainer must re-run the frames that overflow
+    (replays > 0) and end with the same parameters (to the order of the rasterizer's float atomics)."""
+    from ex4dgs_amd.native_trainer import NativeTrainer
+    from ex4dgs_amd.scene import make_scene
+    ma, cam, bg = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    mb, _, _ = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    cam = cam.to("cuda"); bg = bg.cuda()
+    gt = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(11)).cuda()
+    lrs = {n: 1e-4 for n in ma.PARAM_NAMES}
+    p0 = {n: getattr(ma, n).clone() for n in ma.PARAM_NAMES}
+    na = NativeTrainer(ma, cam, optimizer=True, lrs=lrs)
+    nb = NativeTrainer(mb, cam, optimizer=True, lrs=lrs)
+    nb.set_async(True)
+    counts_a, counts_b = [], []
+    for t in (0, 137, 41, 299, 7, 138, 40, 139, 200, 201):
+        na.step(cam, bg, t, gt); counts_a.append(na.num_rendered)
+        nb.step(cam, bg, t, gt); counts_b.append(nb.num_rendered)
+    torch.cuda.synchronize()
+    assert counts_a == counts_b and min(counts_a) > 0
+    for n in ma.PARAM_NAMES:
+        a, b = getattr(ma, n), getattr(mb, n)
+        moved = float((a - p0[n]).abs().max())
+        ulp = 2.0 ** -23 * float(a.abs().max())
+        assert moved > 0 and float((a - b).abs().max()) <= 1e-3 * moved + 2 * ulp, (n, float((a - b).abs().max()), moved)
+    assert float(na.output("loss")) == pytest.approx(float(nb.output("loss")), abs=1e-6)
+    na.close(); nb.close()
+    # forced overflow: a trainer whose capacity was seeded by a frame with few instances (tiny Gaussians), then the real scene
+    mc, _, _ = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    md, _, _ = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    nc = NativeTrainer(mc, cam, optimizer=True, lrs=lrs)
+    nd = NativeTrainer(md, cam, optimizer=True, lrs=lrs)
+    nd.set_async(True)
+    with torch.no_grad():
+        for m in (mc, md):                                # exp(-3): footprints 20x smaller -> far fewer tile instances
+            m._scaling -= 3.0; m._scaling_motion -= 3.0
+    nc.step(cam, bg, 0, gt); nd.step(cam, bg, 0, gt)      # (synchronous seed frame of nd)
+    small = nd.num_rendered
+    with torch.no_grad():
+        for m in (mc, md):
+            m._scaling += 3.0; m._scaling_motion += 3.0
+    for t in (5, 137, 250):
+        nc.step(cam, bg, t, gt); nd.step(cam, bg, t, gt)
+        assert nc.num_rendered == nd.num_rendered
+    torch.cuda.synchronize()
+    assert nd.num_rendered > 1.5 * small and nd.replays() >= 1, (small, nd.num_rendered, nd.replays())
+    for n in mc.PARAM_NAMES:
+        a, b = getattr(mc, n), getattr(md, n)
+        assert float((a - b).abs().max()) <= 1e-3 * float((a - p0[n]).abs().max()) + 4 * 2.0 ** -23 * float(a.abs().max()) + 1e-12, n
+    nc.close(); nd.close()

@@ -12,10 +12,15 @@ model, cam, bg = make_scene("cfg3", P=P, device="cuda", fused=True)
 cam = cam.to("cuda"); bg = bg.cuda()
 gt = torch.rand(3, cfg.height, cfg.width, device="cuda")
 nt = NativeTrainer(model, cam, optimizer=True, lrs={n: 1e-7 for n in model.PARAM_NAMES}, near=cfg.min_depth, far=cfg.max_depth)
+mode = "synchronous forward"
+if len(sys.argv) > 3 and sys.argv[3] == "async":
+    nt.set_async(True); mode = "asynchronous forward"
 for i in range(8):
     nt.step(cam, bg, (0, 137, 299)[i % 3], gt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(steps):
     nt.step(cam, bg, (0, 137, 299)[i % 3], gt)
+t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
-print(f"native trainer P={P}: {1e3 * (time.perf_counter() - t0) / steps:.4f} ms/iteration over {steps} iterations (+8 warm-up), R={nt.num_rendered}")
+print(f"native trainer P={P} ({mode}): {1e3 * (time.perf_counter() - t0) / steps:.4f} ms/iteration over {steps} iterations (+8 warm-up), "
+      f"host time inside step() {1e3 * t_host / steps:.4f} ms/iteration, R={nt.num_rendered}, replays={nt.replays()}")
