@@ -107,7 +107,7 @@ hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, con
 hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // bytes and ptr multiples of 16
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 
-void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: bit 0 staggered wave priorities, bit 1 SH rows predicated on the frustum test
+void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: 1 (default) = SH rows of frustum-culled Gaussians are not requested
 int ex4d_get_preprocess_tune();
 void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled entry walk (default) or the compiler's loop
 int ex4d_get_fwd_asm();

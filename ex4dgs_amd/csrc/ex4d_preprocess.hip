@@ -392,8 +392,7 @@ __device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float 
 #undef SHK
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void preprocess_fwd_kernel(
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int D, int M,
     const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
@@ -404,26 +403,17 @@ __global__ __launch_bounds__(64 * WAVES) void preprocess_fwd_kernel(
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
-    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int tune)
+    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int sh_predicate)
 {
-    __shared__ __attribute__((aligned(16))) float sh_lds[WAVES * SH_HALF_FLOATS];
-    const int lane = threadIdx.x & 63, wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
-    // Every WAVE is independent (no workgroup barrier, wave-private LDS slice, per-wave instance count) and handles chunk wc of 64
-    // Gaussians.  WAVES = 4 (rounds 1-3): workgroups of 256 threads; WAVES = 1 ("preprocess_tune" bit 2): one wave per workgroup, so
-    // that every wave retires -- and its successor starts loading -- on its own.
-    // tune bit 0: staggered wave priorities.  Every chunk has the same three phases (load ~23 KB, ~1500 VALU instructions, store); the
-    // waves that share a SIMD start together and, with round-robin issue, stay in lock-step -- all of them wait for memory, then all of
-    // them compete for the VALU: counters (profiles/r03_pmc_SQ_valu.txt) show a wave alive for 50 k cycles of which 23 k in s_waitcnt and
-    // 8 k issuing; the kernel's duration is memory time PLUS VALU time, not their maximum.  Distinct priorities per wave slot let one
-    // wave at a time run its arithmetic through while the others' loads are in flight.
-    if (tune & 1) {
-        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;      // HW_REG_HW_ID.wave_id[1:0]
-        if (slot == 0) __builtin_amdgcn_s_setprio(0);
-        else if (slot == 1) __builtin_amdgcn_s_setprio(1);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(3);
-    }
-    const int wc = (int)blockIdx.x * WAVES + wave;
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Every wave is independent (no workgroup barrier, wave-private LDS slice, per-wave instance count): chunk wc of 64 Gaussians.
+    // Round 4, measured and dropped (profiles/r04b_experiments.txt, r04c_experiments.txt): distinct s_setprio levels per wave slot and
+    // one-wave workgroups, meant to pull the load / arithmetic / store phases of co-resident waves apart -- no effect (+-2 %).  What the
+    // kernel's time is made of (tools/dev/pre_probe.py, 1.0 M Gaussians): 49 us with precomputed colours (no SH path at all), +24 us for
+    // the SH staging and evaluation at degree 0 (16 of 192 bytes of SH read per Gaussian), +10 us for the other 176 bytes at degree 3,
+    // +10 us for the direction sums left for the backward (which saves 31 us there): it does not follow its bytes.
+    const int wc = (int)blockIdx.x * 4 + wave;
     if (wc >= ((P + 63) >> 6)) return;
     const int idx = wc * 64 + lane;
     const bool in_range = idx < P;
@@ -442,13 +432,14 @@ __global__ __launch_bounds__(64 * WAVES) void preprocess_fwd_kernel(
     const int wave_rows = (P - wave_first) < 64 ? (P - wave_first) : 64;
     ShPrefetch pf;
     bool prefetched = false;
-    // tune bit 1: the frustum test (CR/auxiliary.h in_frustum: 12 bytes of input) runs BEFORE the SH rows are requested, and the rows of
-    // the Gaussians it culls are not requested at all -- one more dependent memory round trip per wave against 36 MB less traffic
+    // sh_predicate (default; option "preprocess_sh_predicate"): the frustum test (CR/auxiliary.h in_frustum: 12 bytes of input) runs
+    // BEFORE the SH rows are requested, and the rows of the Gaussians it culls are not requested at all -- one more dependent memory
+    // round trip per wave against 36 MB less traffic at BASELINE config 3 (19 % of the Gaussians); measured -1.6 us of 92.
     bool pre_ok = false;
     float3 pre_p = make_float3(0.f, 0.f, 0.f), pre_view = make_float3(0.f, 0.f, 0.f);
     float pre_nx = 0.f, pre_ny = 0.f;
     uint64_t need = ~0ull;
-    if (tune & 2) {
+    if (sh_predicate) {
         if (in_range) {
             pre_p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
             pre_ok = frustum_test(pre_p, vm, pm, min_depth, max_depth, pre_view, pre_nx, pre_ny);
@@ -488,7 +479,7 @@ __global__ __launch_bounds__(64 * WAVES) void preprocess_fwd_kernel(
     if (in_range) do {
         float3 p_view; float ndc_x, ndc_y;
         bool in_view;
-        if (tune & 2) { p = pre_p; p_view = pre_view; ndc_x = pre_nx; ndc_y = pre_ny; in_view = pre_ok; }
+        if (sh_predicate) { p = pre_p; p_view = pre_view; ndc_x = pre_nx; ndc_y = pre_ny; in_view = pre_ok; }
         else {
             p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
             in_view = frustum_test(p, vm, pm, min_depth, max_depth, p_view, ndc_x, ndc_y);
@@ -1046,11 +1037,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 }  // namespace
 
-// "preprocess_tune" (ex4d_set_option): bit 0 = staggered wave priorities, bit 1 = SH rows of frustum-culled Gaussians not requested,
-// bit 2 = one wave per workgroup
-static int preprocess_tune_default() { const char *e = getenv("EX4D_PREPROCESS_TUNE"); return e ? (atoi(e) & 7) : 0; }    // developer override of the default
-static std::atomic<int> g_preprocess_tune{preprocess_tune_default()};
-void ex4d_set_preprocess_tune(int v) { g_preprocess_tune.store(v); }
+// "preprocess_sh_predicate" (ex4d_set_option): the SH rows of frustum-culled Gaussians are not requested (default 1)
+static int preprocess_option_default() { const char *e = getenv("EX4D_PREPROCESS_SH_PREDICATE"); return e ? (atoi(e) != 0) : 1; }    // developer override
+static std::atomic<int> g_preprocess_tune{preprocess_option_default()};
+void ex4d_set_preprocess_tune(int v) { g_preprocess_tune.store(v != 0); }
 int ex4d_get_preprocess_tune() { return g_preprocess_tune.load(); }
 
 hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3D, const float *dir3D, const float *scales,
@@ -1061,15 +1051,13 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
-    const int tune = g_preprocess_tune.load(std::memory_order_relaxed);
-#define PF_ARGS prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, \
-        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size, \
-        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation, \
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split, \
-        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr, tune
-    if (tune & 4) hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((prm.P + 63) / 64), dim3(64), 0, stream, PF_ARGS);
-    else hipLaunchKernelGGL(preprocess_fwd_kernel<4>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
-#undef PF_ARGS
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
+        prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
+        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split,
+        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr,
+        g_preprocess_tune.load(std::memory_order_relaxed));
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 """Dev script (GPU box): wall time per iteration of the compiled host path (include/ex4d_trainer.h) at a given size.  Run under
-`rocprofv3 --kernel-trace --stats` the kernel time total / iterations is the kernel sum it is compared with (tools/prof_r02.sh)."""
+`rocprofv3 --kernel-trace --stats` the kernel time total / iterations is the kernel sum it is compared with (tools/prof_round.sh)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel HBM traffic and roofline fractions from separate rocprofv3 --pmc passes (tools/prof_r02.sh):
+"""Per-kernel HBM traffic and roofline fractions from separate rocprofv3 --pmc passes (tools/prof_round.sh):
 
     pmc_traffic.py FETCH.txt WRITE.txt SQ_valu.txt kernel_stats.txt out.json [iter_FETCH iter_WRITE iter_stats knn_FETCH knn_WRITE knn_stats]
 
@@ -126,7 +126,7 @@ def main():
         kernels.update({k: v for k, v in collect(a[5], a[6], a[7]).items() if k not in kernels})
     if len(a) >= 11:
         kernels.update({k: v for k, v in collect(a[8], a[9], a[10]).items() if k not in kernels})
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, tools/prof_r02.sh): bench.py cfg3 1.0M Gaussians; "
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, tools/prof_round.sh): bench.py cfg3 1.0M Gaussians; "
                          "tools/dev/dev_iter_profile.py (fused training iteration at 1.0M); tools/dev/dev_knn_time.py",
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
                "source_sha16": kernel_source_hashes(),

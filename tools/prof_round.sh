@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/prof_r03.sh <tag>
+# usage (GPU box, repo root): tools/prof_round.sh <tag>     (e.g. r04)
 # Every measurement artefact of the round in one go -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/):
 #   kernel-trace stats of the default bench command; separate --pmc passes (FETCH_SIZE, WRITE_SIZE, two SQ groups) of the same command;
 #   kernel-trace stats + FETCH/WRITE passes of the fused training iteration (attributes, loss, RAdam kernels) and of distCUDA2
