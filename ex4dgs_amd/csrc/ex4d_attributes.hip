@@ -297,9 +297,10 @@ static int attributes_backward_impl(const Ex4dAttrParams *a, int sliced,
     if (a->Nd > 0) {
         if (a->k < 1 || a->k + 2 >= a->K) { snprintf(g_attr_err, sizeof(g_attr_err), "keyframe index out of range"); return EX4D_ERR_ARG; }
         // dense gradients of the keyframe tensors: only 4 (xyz) / 2 (rotation) of the K slices are non-zero
-        if (!sliced && (hipMemsetAsync(g_xyz_motion, 0, (size_t)a->Nd * a->K * 3 * sizeof(float), stream) != hipSuccess ||
-            hipMemsetAsync(g_rotation_motion, 0, (size_t)a->Nd * a->K * 4 * sizeof(float), stream) != hipSuccess)) {
-            snprintf(g_attr_err, sizeof(g_attr_err), "memset failed"); return EX4D_ERR_HIP;
+        if (!sliced && ((((uintptr_t)g_xyz_motion | (uintptr_t)g_rotation_motion) & 15) != 0 ||
+            ex4d_launch_zero(g_xyz_motion, (size_t)a->Nd * a->K * 3 * sizeof(float), stream) != hipSuccess ||
+            ex4d_launch_zero(g_rotation_motion, (size_t)a->Nd * a->K * 4 * sizeof(float), stream) != hipSuccess)) {
+            snprintf(g_attr_err, sizeof(g_attr_err), "clearing the dense keyframe gradients failed (they must be 16-byte aligned)"); return EX4D_ERR_HIP;
         }
     }
     hipLaunchKernelGGL(attributes_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, *a, opacity, scaling, rotation_motion, opacity_motion,

@@ -508,10 +508,11 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
 // The library clears its frame flags and the backward's accumulator rows with a kernel of its own instead of hipMemsetAsync: a memset
 // NODE of a captured graph was observed (ROCm 7.2, round 4: tools/dev/dbg_graph.py) to clear its target on the first replay only --
 // from the second replay on the frame-flag words held stale pointers-like values and the instance count came out as garbage + R.
-__global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *__restrict__ p, size_t n16)
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *__restrict__ p, size_t n16, uint32_t tail_words)
 {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < tail_words) reinterpret_cast<uint32_t *>(p + n16)[threadIdx.x] = 0u;       // < 4 words behind the last 16 bytes
 }
 
 // ---------------------------------------------------------------- tile ranges
@@ -630,12 +631,14 @@ hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, con
 
 hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream)
 {
-    // ptr and bytes are multiples of 16 (256-byte aligned regions of the scratch buffers)
+    // ptr: 16-byte aligned; bytes: a multiple of 4
     const size_t n16 = bytes / 16;
-    if (n16 == 0) return hipSuccess;
+    const uint32_t tail_words = (uint32_t)((bytes % 16) / 4);
+    if (bytes == 0) return hipSuccess;
     size_t blocks = (n16 + 1023) / 1024;                 // 4 stores of 16 bytes per thread
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint4 *)ptr, n16);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint4 *)ptr, n16, tail_words);
     return hipGetLastError();
 }
 

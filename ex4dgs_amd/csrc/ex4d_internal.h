@@ -104,7 +104,7 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *ord
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream);
-hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // bytes and ptr multiples of 16
+hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // ptr 16-byte aligned, bytes a multiple of 4 (a kernel, not hipMemsetAsync: ex4d_binning.hip)
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 
 void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: 1 (default) = SH rows of frustum-culled Gaussians are not requested

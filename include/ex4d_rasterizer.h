@@ -245,8 +245,8 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *                            <= 256 or > 65536 tiles, or more than 2^(32 - ceil(tile bits / 2)) Gaussians, take the key/value sort,
  *                            which always writes them.)
  *   "preprocess_sh_predicate" 1 (default) = the per-Gaussian forward kernel runs its frustum test before it requests the SH rows and
- *                            does not request the rows of culled Gaussians (-36 MB per frame at 1.0 M Gaussians); 0 = all loads
- *                            up front (rounds 2-3).  Same results.
+ *                            does not request the rows of frustum-culled Gaussians (pays in views whose frustum culls; the synthetic
+ *                            BASELINE scenes lose their invisible Gaussians after the projection); 0 = all loads up front.  Same results.
  *   "geom_debug_arrays"      1 = also write Ex4dGeomLayout.cov3D and .tiles_touched; 0 (default) = those regions stay untouched: the
  *                            backward recomputes the covariance from scale / rotation (same function, same bits), the tile rect carries
  *                            the count.

@@ -853,3 +853,53 @@ def test_compiled_trainer_rejects_bad_configurations_without_touching_a_device()
     h, msg = create()                      # sizes fine, but the parameter pointers are NULL
     assert not h and "NULL" in msg
     assert lib.ex4d_trainer_bytes(None) == 0 and lib.ex4d_trainer_output(None, 0) is None
+
+
+def test_async_frames_policy_capacity_growth_and_reporting():
+    """Host logic of the asynchronous forward's opt-in policy (diff_gaussian_rasterization_df.async_frames), no device involved: the
+    first frame runs synchronously and seeds the capacity, later frames get headroom x the largest count seen, a frame above its
+    capacity is reported at the next forward (strict) or counted while the capacity grows, and the flow-free kernel is chosen from the
+    previous frame's flow flag."""
+    from ex4dgs_amd import _C
+    from ex4dgs_amd.diff_gaussian_rasterization_df import AsyncFrames
+
+    class Fake(_C.PendingFrame):
+        def __init__(self, capacity, count, flow=False, assumed_no_flow=False, ready=True):
+            self.capacity, self.assumed_no_flow, self._count, self._flow, self._ready = capacity, assumed_no_flow, count, flow, ready
+            self._status = self._event = self._pool = None
+
+        def done(self):
+            return self._ready
+
+        def wait(self):
+            self._ready = True
+            return self
+
+        num_rendered = property(lambda self: self._count)
+        has_flow = property(lambda self: self._flow)
+        prefilter_violation = property(lambda self: False)
+
+    pol = AsyncFrames()
+    assert pol.next_call() == (0, False)                       # disabled: synchronous, reference behaviour
+    pol.enable(headroom=1.25)
+    assert pol.next_call() == (0, False)                       # nothing known yet: the first frame runs synchronously ...
+    pol.record(1000)                                           # ... and seeds the capacity
+    cap, no_flow = pol.next_call()
+    assert cap == int(1.25 * 1000) + 4096 and not no_flow
+    pol.record(Fake(cap, 1200, flow=False))
+    cap2, no_flow = pol.next_call()                            # settled: it fitted (the capacity follows the largest count seen); no flow -> flow-free kernel next
+    assert cap2 == int(1.25 * 1200) + 4096 and no_flow and pol.invalid_frames == 0
+    pol.record(Fake(cap2, 9000, ready=False))                  # its status has not arrived yet: not looked at, nothing blocks
+    assert pol.next_call()[0] == cap2 and len(pol.pending) == 1
+    pol.pending[0]._ready = True
+    with pytest.raises(RuntimeError, match="exceed the capacity"):
+        pol.next_call()                                        # strict: the truncated frame is reported at the next forward
+    assert pol.capacity == int(1.25 * 9000) + 4096 and pol.invalid_frames == 1
+    pol.enable(headroom=1.5, capacity=100, strict=False)
+    pol.record(Fake(100, 5000))
+    assert pol.next_call()[0] == int(1.5 * 5000) + 4096 and pol.invalid_frames == 1      # counted, regrown, no exception
+    pol.record(Fake(pol.capacity, 10, flow=True, assumed_no_flow=True))
+    pol.drain()
+    assert pol.invalid_frames == 2 and not pol.no_flow         # a violated no-flow assumption invalidates the frame as well
+    pol.disable()
+    assert pol.next_call() == (0, False)
