@@ -9,6 +9,7 @@ import os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "ex4dgs_amd", "csrc")
+SIZES = (100_000, 65_536, 40_000, 131_072)
 
 
 def build_variant(dst, patch):
@@ -40,7 +41,7 @@ def worker(out):
     from ex4dgs_amd import _C
     _C.load()
     res = {}
-    for P in (100_000, 99_968):                 # 100 000 = 390 blocks + 160 threads (a 32-row wave, an empty wave); 99 968 = whole waves only
+    for P in SIZES:                              # 100 000 = 390 blocks + 160 threads (a 32-row wave, an empty wave); 65 536 = 256 blocks: one per CU
         ins, st = h.scene_inputs("cfg2", P=P)
         g = h.gpu_forward_raw(ins, st)
         grads = [x.cuda() for x in h.upstream_grads(g["acc"].cpu(), st["image_height"], st["image_width"], seed=3)]
@@ -67,7 +68,7 @@ def main():
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "run", out], env=e)
         outs[name] = np.load(out)
     a, v = outs["default"], outs["variant"]
-    for P in (100_000, 99_968):
+    for P in SIZES:
         radii = a[f"{P}/radii"]
         # the per-Gaussian stage is deterministic given its accumulators: compare on rows whose accumulator rows are bit-equal
         same_acc = (a[f"{P}/0/acc16"].view(np.uint32) == v[f"{P}/0/acc16"].view(np.uint32)).all(1)
