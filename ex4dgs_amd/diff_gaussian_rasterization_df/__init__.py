@@ -52,8 +52,9 @@ class AsyncFrames:
     of the NEXT forward, by which time its copy has long landed.  A frame whose instance count exceeded the capacity had its tile
     lists truncated: its outputs and gradients are invalid.  That cannot be repaired behind the caller's back (the image was
     already consumed), so it is reported: `strict` (default) raises at the next forward, otherwise `invalid_frames` counts and the
-    capacity grows.  Callers that own the whole iteration (trainer.FrameTrainer, the compiled NativeTrainer) check the status
-    before their optimizer step and RE-RUN the frame instead -- exact results, no wait on the critical path."""
+    capacity grows.  Callers that own the whole iteration -- trainer.FrameTrainer(async_forward=True), under a policy object of its
+    own (`use_policy`), and the compiled NativeTrainer.set_async -- check the status before their optimizer step and RE-RUN the frame
+    instead: exact results, and the wait sits where every kernel of the frame is already enqueued."""
 
     def __init__(self):
         self.enabled = False
@@ -113,7 +114,28 @@ class AsyncFrames:
             self.observe(num_rendered)
 
 
-async_frames = AsyncFrames()
+async_frames = AsyncFrames()          # the process-wide policy (disabled until somebody calls async_frames.enable())
+_policy_stack = []
+
+
+class use_policy:
+    """`with use_policy(p): ...` -- forwards issued inside run under the AsyncFrames object `p` instead of the process-wide one
+    (a trainer that re-runs overflowing frames itself keeps its own policy and leaves everybody else synchronous)."""
+
+    def __init__(self, policy):
+        self.policy = policy
+
+    def __enter__(self):
+        _policy_stack.append(self.policy)
+        return self.policy
+
+    def __exit__(self, *exc):
+        _policy_stack.pop()
+        return False
+
+
+def current_policy():
+    return _policy_stack[-1] if _policy_stack else async_frames
 
 
 def _snapshot(args):
@@ -147,11 +169,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         # a backward will follow iff some input wants a gradient: the forward then also leaves the SH direction sums of the SH
         # backward in its geometry buffer (it has the SH rows in registers anyway), and the backward does not read the SH tensors
         ctx.prepared = any(ctx.needs_input_grad)
-        capacity, no_flow = (0, False) if s.debug else async_frames.next_call()      # (debug synchronises after every stage)
+        policy = current_policy()
+        capacity, no_flow = (0, False) if s.debug else policy.next_call()      # (debug synchronises after every stage)
         native_fwd = lambda *a: _C.rasterize_gaussians(*a, prepare_backward=ctx.prepared, instance_capacity=capacity, assume_no_flow=no_flow)
         (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, acc, flow, idxs) = _call_native(
             native_fwd, args, s.debug, "snapshot_fw.dump", "forward")
-        async_frames.record(num_rendered)
+        policy.record(num_rendered)
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered          # an int, or a _C.PendingFrame (asynchronous forward): the backward needs its capacity only
         # outputs that take no part in the loss arrive in backward as None instead of freshly filled zero tensors

@@ -50,13 +50,16 @@ class FrameTrainer:
     all-gather; implies optimizer).  optimizer: False | True (replicated fused RAdam when exchange != "sharded")."""
 
     def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None, spatial_lr_scale=1.0,
-                 force_collectives=False):
+                 force_collectives=False, async_forward=False):
         """lrs: overrides of the reference table reference_lrs(spatial_lr_scale).
         sliced (default: on whenever a replicated optimizer runs): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from the
         attribute backward through the exchange (all-gather of the ranks' windows) into ex4d_radam_step_sliced -- no 196 MB zero fill,
         no dense read, 16 MB per rank on the wire instead of 196.
         force_collectives: issue the exchange's collectives even in a process group of one rank (dist.py: the RCCL-native branches
-        run and are checked on a one-GPU box)."""
+        run and are checked on a one-GPU box).
+        async_forward (single rank, exchange "none"): the rasterizer forward runs asynchronously (no instance-count read-back:
+        include/ex4d_rasterizer.h Ex4dParams.instance_capacity, under an AsyncFrames policy of the trainer's own); the frame's status is looked at once, right before its gradients are applied, and a frame that overflowed its
+        capacity is RE-RUN first -- the parameters are those of the synchronous path.  `replays` counts such re-runs."""
         assert exchange in ("none", "allreduce", "sharded")
         self.model = model
         self.names = list(attr.PARAM_ORDER)
@@ -110,6 +113,14 @@ class FrameTrainer:
                 self.v = [torch.zeros_like(p) for p in self.params]
                 self.steps = 0
         self.optimizer = bool(optimizer) or self.mode == "sharded"
+        self.async_forward = bool(async_forward)
+        self.replays = 0
+        self._frame = self._last_args = None
+        if self.async_forward:
+            if self.mode != "none":
+                raise ValueError("async_forward re-runs an overflowing frame on its own: single rank, exchange 'none' only")
+            from .diff_gaussian_rasterization_df import AsyncFrames
+            self._policy = AsyncFrames().enable(headroom=1.25, strict=False)     # this trainer's own: other callers stay synchronous
         self._grads = None
         self._zero_sub = {}
         self.last = {}
@@ -157,14 +168,35 @@ class FrameTrainer:
     def step(self, cam, bg, t, upstream, near=0.2, far=300.0):
         """upstream: callable(render dict) -> (list of outputs, list of their gradients), e.g. a loss evaluated with the fused
         L1+SSIM op, or fixed synthetic gradients.  Returns the render dict (tensors of this frame, detached)."""
-        m = self.model
-        main = torch.cuda.current_stream(self.device)
-        scal = attr.time_scalars(t, m.num_static, m.num_dynamic, m._xyz_motion.shape[1] if m.num_dynamic else 0,
-                                 m.duration, m.interval, m.time_shift, m.var_pad)
         # the previous frame's exchange must be complete before this frame's optimizer-updated parameters are read (optimizer on) --
         # without an optimizer it only has to finish before its buffers are overwritten by this frame's attribute backward
         if self.optimizer and self._grads is not None:
             self._apply_optimizer()
+        elif self.async_forward:
+            self._settle_frame()
+        self._last_args = (cam, bg, t, upstream, near, far)
+        return self._run_frame(cam, bg, t, upstream, near, far)
+
+    def _settle_frame(self):
+        """async_forward: the pending frame's status; a frame whose tile lists were truncated is run again (with the capacity the policy
+        has regrown) until it is whole -- before anybody consumes its gradients."""
+        for _ in range(3):
+            fr, self._frame = self._frame, None
+            if fr is None:
+                return
+            fr.wait()
+            self._policy.poll()                     # (non-strict: counts the invalid frame, regrows the capacity, learns the flow flag)
+            if fr.valid:
+                return
+            self.replays += 1
+            self._run_frame(*self._last_args)
+        raise RuntimeError("a frame overflowed its instance capacity three times in a row")
+
+    def _run_frame(self, cam, bg, t, upstream, near, far):
+        m = self.model
+        main = torch.cuda.current_stream(self.device)
+        scal = attr.time_scalars(t, m.num_static, m.num_dynamic, m._xyz_motion.shape[1] if m.num_dynamic else 0,
+                                 m.duration, m.interval, m.time_shift, m.var_pad)
         with torch.no_grad():
             xyz, rot, opa, scl, _ = attr.forward_raw(scal, self.params, with_shs=False)
         leaves = [x.requires_grad_(True) for x in (xyz, rot, opa, scl)]
@@ -173,7 +205,13 @@ class FrameTrainer:
         dir3D = torch.zeros_like(xyz, requires_grad=True)
         e = torch.Tensor([])
         st = self._settings(cam, bg, near, far)
-        color, radii, depth, flow, acc, idx = rasterize_gaussians(leaves[0], means2D, dir3D, SplitSH(*feats), e, leaves[2], leaves[3], leaves[1], e, st)
+        if self.async_forward:
+            from .diff_gaussian_rasterization_df import use_policy
+            with use_policy(self._policy):
+                color, radii, depth, flow, acc, idx = rasterize_gaussians(leaves[0], means2D, dir3D, SplitSH(*feats), e, leaves[2], leaves[3], leaves[1], e, st)
+            self._frame = self._policy.pending[-1] if self._policy.pending else None      # (None: the policy's synchronous seed frame)
+        else:
+            color, radii, depth, flow, acc, idx = rasterize_gaussians(leaves[0], means2D, dir3D, SplitSH(*feats), e, leaves[2], leaves[3], leaves[1], e, st)
         out = {"render": color, "depth": depth, "opticalflow": flow, "acc": acc, "radii": radii, "dominent_idxs": idx,
                "viewspace_points": means2D, "viewspace_l1points": dir3D, "visibility_filter": radii > 0}
         outs, gouts = upstream(out)
@@ -213,6 +251,8 @@ class FrameTrainer:
         return out
 
     def _apply_optimizer(self):
+        if self.async_forward:
+            self._settle_frame()
         self.finish_exchange()
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
@@ -241,6 +281,8 @@ class FrameTrainer:
         if self.optimizer and self._grads is not None:
             self._apply_optimizer()
         else:
+            if self.async_forward:
+                self._settle_frame()
             self.finish_exchange()
             if self.side is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self.side)

@@ -206,3 +206,45 @@ def test_compiled_host_path_asynchronous_mode_is_exact_and_replays_overflowing_f
         a, b = getattr(mc, n), getattr(md, n)
         assert float((a - b).abs().max()) <= 1e-3 * float((a - p0[n]).abs().max()) + 4 * 2.0 ** -23 * float(a.abs().max()) + 1e-12, n
     nc.close(); nd.close()
+
+
+def test_frame_trainer_asynchronous_forward_replays_and_matches_the_synchronous_trainer(hip_lib):
+    """trainer.FrameTrainer(async_forward=True): the Python owner of the iteration checks the frame's status before its gradients are
+    applied and re-runs an overflowing frame.  Against the synchronous trainer on a copy of the model: a run over several timestamps,
+    then a 20x jump of the instance count (the capacity was seeded by tiny footprints) -- replays >= 1, same parameters."""
+    from ex4dgs_amd.diff_gaussian_rasterization_df import async_frames
+    from ex4dgs_amd.loss import l1_ssim_loss
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.trainer import FrameTrainer
+    assert not async_frames.enabled
+    ma, cam, bg = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    mb, _, _ = make_scene("cfg3", P=8000, device="cuda", fused=True)
+    cam = cam.to("cuda"); bg = bg.cuda()
+    gt = torch.rand(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(11)).cuda()
+    lrs = {n: 1e-4 for n in ma.PARAM_NAMES}
+    p0 = {n: getattr(ma, n).clone() for n in ma.PARAM_NAMES}
+    up = lambda out: ([l1_ssim_loss(out["render"], gt, 0.2)[0]], [None])
+    try:
+        fa = FrameTrainer(ma, optimizer=True, lrs=lrs)
+        fb = FrameTrainer(mb, optimizer=True, lrs=lrs, async_forward=True)
+        with torch.no_grad():
+            for m in (ma, mb):
+                m._scaling -= 3.0; m._scaling_motion -= 3.0
+        fa.step(cam, bg, 0, up); fb.step(cam, bg, 0, up)          # tiny footprints: seeds a small capacity
+        fa.flush(); fb.flush()
+        with torch.no_grad():
+            for m in (ma, mb):
+                m._scaling += 3.0; m._scaling_motion += 3.0
+        for t in (5, 137, 41, 299, 7, 138):
+            fa.step(cam, bg, t, up); fb.step(cam, bg, t, up)
+        fa.flush(); fb.flush(); torch.cuda.synchronize()
+        assert fb.replays >= 1 and fb._policy.invalid_frames >= 1 and not async_frames.enabled      # (the process-wide policy stayed off)
+        for n in ma.PARAM_NAMES:
+            a, b = getattr(ma, n), getattr(mb, n)
+            moved = float((a - p0[n]).abs().max())
+            assert moved > 0 and float((a - b).abs().max()) <= 1e-3 * moved + 4 * 2.0 ** -23 * float(a.abs().max()) + 1e-12, (n, float((a - b).abs().max()), moved)
+        with pytest.raises(ValueError, match="single rank"):
+            FrameTrainer(mb, exchange="sharded", async_forward=True)
+    finally:
+        async_frames.enabled = False
+        async_frames.pending = []
