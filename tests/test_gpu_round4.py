@@ -248,3 +248,20 @@ def test_frame_trainer_asynchronous_forward_replays_and_matches_the_synchronous_
     finally:
         async_frames.enabled = False
         async_frames.pending = []
+
+
+@pytest.mark.parametrize("mode", ["--async-frames", "--graph"])
+def test_bench_asynchronous_and_graph_modes_print_a_valid_line(hip_lib, mode):
+    """`bench.py --async-frames` / `--graph` (the asynchronous forward through the autograd surface / forward + backward replayed from one
+    hipGraph) run, refuse nothing, and print ONE JSON line that says which mode was timed."""
+    import json, os, subprocess, sys
+    cmd = [sys.executable, os.path.join(h.ROOT, "bench.py"), "--config", "cfg2", "--points", "20000", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline", "--no-model-step", mode]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 1
+    assert ("hipGraph" in d["config"]["step"]) if mode == "--graph" else ("asynchronous forward" in d["config"]["step"])
