@@ -130,6 +130,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     l.tiles_touched = c.off;  g.tiles_touched = c.take<uint32_t>(P);
     l.rects = c.off;          g.rects = c.take<uint2>(P);
     g.sorted_rects = c.take<uint2>(P);
+    g.rects4 = c.take<uint32_t>(P);
     l.depth_order = c.off;    g.depth_order = c.take<uint32_t>(P);
     l.sorted_offsets = c.off; g.sorted_offsets = c.take<uint32_t>(P);
     g.sort_keys_a = c.take<uint32_t>(P);
@@ -267,6 +268,7 @@ static int forward_impl(
     uint32_t *keys0 = start_in_b ? g.sort_keys_b : g.sort_keys_a, *vals0 = start_in_b ? g.sort_vals_b : g.depth_order;
     uint32_t *keys1 = start_in_b ? g.sort_keys_a : g.sort_keys_b, *vals1 = start_in_b ? g.depth_order : g.sort_vals_b;
 
+    const bool packed_rects = gx <= 255 && gy <= 255;       // the tile scan gathers 32-bit packed rects (L2-resident) instead of the 8-byte ones
     g_prof.begin(0, stream);
     HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));        // the frame flags / Ex4dFrameStatus words
     // 1. per-Gaussian preprocess
@@ -274,7 +276,7 @@ static int forward_impl(
     if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
-                                     keys0, vals0, key_base, key_invisible, stream), prm, stream);
+                                     keys0, vals0, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
@@ -292,7 +294,7 @@ static int forward_impl(
     if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
     MARK(0, "depth_sort");
     // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)
-    STAGE(ex4d_launch_scan_tiles(P, g.rects, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
+    STAGE(ex4d_launch_scan_tiles(P, g.rects, packed_rects ? g.rects4 : nullptr, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
     MARK(0, "scan_tiles");
     uint32_t R = 0;                      // instance count (synchronous) or capacity (asynchronous): sizes the binning buffer and the grids
     const uint32_t *n_dev = nullptr;     // asynchronous: the kernels read the actual count here

@@ -27,6 +27,7 @@ struct GeomState {
     uint32_t *tiles_touched;
     uint2 *rects;             // [P] tile rect of every Gaussian: .x = x0 | y0 << 16, .y = w | h << 16 (w*h == tiles_touched)
     uint2 *sorted_rects;      // [P] the same in depth order (gathered once by the scan kernel, streamed by duplicate)
+    uint32_t *rects4;         // [P] the rects packed into 32 bits (x0 | y0 << 8 | w << 16 | h << 24): the array the scan kernel gathers from when the image has at most 255 x 255 tiles
     uint32_t *depth_order;
     uint32_t *sorted_offsets;
     // scratch used only inside forward (not needed by backward)
@@ -75,7 +76,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
-    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream);
+    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream);
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);
@@ -100,7 +101,7 @@ size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits);
 hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
     uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 
-hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
+hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rects4, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream);

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
-    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int sh_predicate)
+    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -670,6 +670,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         radii[idx] = out_radius;
         if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
         rects[idx] = rect;
+        if (rects4) rects4[idx] = (rect.x & 0xFFu) | ((rect.x >> 16) << 8) | ((rect.y & 0xFFu) << 16) | ((rect.y >> 16) << 24);      // (<= 255 x 255 tiles)
         depth_keys[idx] = depth_key;
         depth_vals[idx] = (uint32_t)idx;
     }
@@ -1048,7 +1049,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
-    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, hipStream_t stream)
+    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream)
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
@@ -1058,7 +1059,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
         radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split,
         (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr,
-        g_preprocess_tune.load(std::memory_order_relaxed));
+        g_preprocess_tune.load(std::memory_order_relaxed), rects4);
     return hipGetLastError();
 }
 
