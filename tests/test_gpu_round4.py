@@ -265,3 +265,51 @@ def test_bench_asynchronous_and_graph_modes_print_a_valid_line(hip_lib, mode):
     d = json.loads(lines[0])
     assert d["value"] > 0 and d["n_gpus"] == 1
     assert ("hipGraph" in d["config"]["step"]) if mode == "--graph" else ("asynchronous forward" in d["config"]["step"])
+
+
+def test_asynchronous_frames_soak_over_changing_views(hip_lib):
+    """120 frames through the autograd surface under the asynchronous policy (strict: a truncated frame would raise), the timestamp and the
+    camera distance changing from frame to frame so that the instance count moves by tens of percent, every frame's image and gradients
+    compared with the synchronous call on the same inputs: images bit-equal, gradients to the order of the float atomics.  Frames that
+    outgrow the capacity are allowed at most while it is being learned (the policy then re-seeds synchronously at no loss of frames)."""
+    from ex4dgs_amd.diff_gaussian_rasterization_df import AsyncFrames, use_policy, rasterize_gaussians, async_frames
+    from ex4dgs_amd.scene import make_scene, focal_camera, CONFIGS
+    from ex4dgs_amd.render import render
+    model, cam, bg = make_scene("cfg3", P=6000, device="cuda", fused=True)
+    cam = cam.to("cuda"); bg = bg.cuda()
+    cfg = CONFIGS["cfg3"]
+    params = model.parameters()
+    for p in params:
+        p.requires_grad_(True)
+    H, W = cam.image_height, cam.image_width
+    w = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).cuda()
+    pol = AsyncFrames().enable(headroom=1.3, strict=False)
+    rng = np.random.default_rng(5)
+    counts = []
+    for i in range(120):
+        t = int(rng.integers(0, 300))
+        # move the camera back and forth along its axis: the footprints (and with them the instance count) shrink and grow
+        cam = focal_camera(cfg.width, cfg.height, cfg.focal, T=[0.0, 0.0, float(rng.uniform(-1.5, 3.0))], znear=0.01, zfar=100.0,
+                           cxr=cfg.cxr, cyr=cfg.cyr).to("cuda")
+        for p in params:
+            p.grad = None
+        with use_policy(pol):
+            out = render(cam, model, None, bg, timestamp=t, near=4.0, far=300.0)
+        (out["render"] * w).sum().backward()
+        ga = [p.grad.clone() for p in params]
+        img = out["render"].detach().clone()
+        for p in params:
+            p.grad = None
+        ref = render(cam, model, None, bg, timestamp=t, near=4.0, far=300.0)      # process-wide policy: off -> synchronous
+        (ref["render"] * w).sum().backward()
+        pol.drain()
+        invalid_now = pol.invalid_frames
+        counts.append(pol.capacity)
+        if invalid_now == getattr(test_asynchronous_frames_soak_over_changing_views, "_seen", 0):
+            assert torch.equal(img, ref["render"]), i
+            for name, a, p in zip(model.PARAM_NAMES, ga, params):
+                assert float((a - p.grad).abs().max()) <= 2e-5 * float(p.grad.abs().max()) + 1e-12, (i, name)
+        test_asynchronous_frames_soak_over_changing_views._seen = invalid_now
+    assert not async_frames.enabled and pol.frames == 120
+    assert pol.invalid_frames <= 6, pol.invalid_frames            # only while the capacity is being learned
+    assert counts[-1] >= counts[0]
