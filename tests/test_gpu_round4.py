@@ -32,14 +32,20 @@ def _raw_backward(ins, s, fwd, grads, device="cuda", **kw):
         s.sh_degree, s.campos, geom, R, binning, img, s.debug, **kw)
 
 
-@pytest.mark.parametrize("cfg,P,dir_scale", [("cfg2", 20000, 0.1), ("cfg3", 12000, 0.0), ("cfg1", None, 0.1)])
+def _huge():
+    from ex4dgs_amd.scene import SceneConfig
+    return SceneConfig("huge: 4112x4112", 1500, 4112, 4112, 2200.0, seed=31, sigma_px_med=30.0)
+
+
+@pytest.mark.parametrize("cfg,P,dir_scale", [("cfg2", 20000, 0.1), ("cfg3", 12000, 0.0), ("cfg1", None, 0.1), ("huge", None, 0.1)])
 def test_asynchronous_forward_equals_the_synchronous_one(hip_lib, cfg, P, dir_scale):
     """Same frame through the reference-style forward (blocking instance-count read-back, exact buffer) and through the asynchronous
     one (capacity-sized buffer, count read from device memory by every kernel behind the scan): every output bit-equal, the sorted
     point list and the tile ranges equal, the status word equal to the synchronous count; the backward on the capacity-sized buffers
-    returns the same gradients (to the order of the float atomics).  cfg1 (256x256: 256 tiles) takes the key/value tile sort."""
+    returns the same gradients (to the order of the float atomics).  cfg1 (256x256: 256 tiles) takes the key/value tile sort in one
+    pass, "huge" (4112x4112 = 66 049 tiles, 17 key bits) in three passes whose ping-pong buffers hold garbage behind the device-side count."""
     from ex4dgs_amd import _C
-    ins, st = h.scene_inputs(cfg, P=P, dir_scale=dir_scale)
+    ins, st = h.scene_inputs(_huge() if cfg == "huge" else cfg, P=P, dir_scale=dir_scale)
     ins = {k: v.cuda() for k, v in ins.items()}
     s, sync = _raw_forward(ins, st)
     R = sync[0]
