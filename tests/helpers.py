@@ -34,9 +34,13 @@ def scene_inputs(cfg, P=None, t=0, sh_degree=3, dir_scale=0.1, device="cpu", see
     return ins, settings
 
 
+FRAG_EPS = float(os.environ.get("EX4D_FRAG_EPS", "5e-6"))     # relative distance of a decision to its threshold below which a pixel is "fragile" (rounds 1-3: 1e-4)
+
+
 def oracle_forward(ins, settings, **over):
     from oracle import oracle
     kw = dict(settings); kw.update(over)
+    kw.setdefault("frag_eps", FRAG_EPS)
     opt = {k: ins.get(k) for k in ("shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")}
     return oracle.forward(ins["means3D"], ins.get("dir3D"), ins["opacities"], **opt, **kw)
 
@@ -109,11 +113,12 @@ def to_np(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
-def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=1e-4, tag=""):
+def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=None, tag=""):
     """o: oracle dict, g: gpu dict.  Integers bit-exact; floats <= atol (relative to max(1,|ref|)) on every
     pixel that is not 'fragile' (an alpha/T/power decision within frag_eps of its threshold in the oracle:
     a 1-ulp exp() difference legitimately flips those, CR/forward.cu:372-387)."""
     rep = {}
+    frag_eps = FRAG_EPS if frag_eps is None else frag_eps
     P = o["P"]
     if P:
         vis = o["radii"] > 0

@@ -39,7 +39,7 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     rep = h.compare_forward(o, g, max_fragile_frac=max_fragile_frac, tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t}")
     H, W = st["image_height"], st["image_width"]
     grads = list(h.upstream_grads(torch.from_numpy(o["acc"]), H, W, seed=seed, grad_acc_zero=grad_acc_zero))
-    solid = torch.from_numpy(o["fragile"] > 1e-4)
+    solid = torch.from_numpy(o["fragile"] > h.FRAG_EPS)
     grads = [x * solid[None] for x in grads]          # a flipped pair changes the whole pixel: exclude fragile pixels
     # The backward consumes the forward's per-pixel state (out_depth, out_acc, final_T, n_contrib).  dL_dalpha contains
     # (final_depth - depth) * dL_ddepth, a difference of nearly equal depths, so a 1e-6 relative difference in out_depth
