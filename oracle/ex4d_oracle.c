@@ -549,8 +549,15 @@ void ex4d_oracle_render_bwd(
     double *sum13, double *abs13,
     const uint32_t *pixel_order /* may be NULL: row-major */,
     const float *dstate /* [3,H,W] |delta out_depth|, |delta out_acc|, |delta final_T| per pixel; may be NULL */,
-    double *state13 /* [P,13]; may be NULL */)
+    double *state13 /* [P,13]; may be NULL */,
+    double *cmag13 /* [P,13]; may be NULL */)
 {
+    /* cmag13 (optional, test instrumentation): like abs13, but for the six accumulators that dL_dalpha feeds the magnitude of a term is
+     * taken BEFORE the cancellation inside dL_dalpha = sum_ch (c - accum_rec) dL_dchannel T + (final_depth - depth) dL_ddepth T T +
+     * bg term (CR/backward.cu:603-662): |coefficient| x (sum_ch (|c| + |accum_rec|) |dL_dchannel| T + |depth part| + |bg part|).  A
+     * Gaussian whose colour nearly equals what lies behind it has a small dL_dalpha made of O(1) parts; two float evaluations of the
+     * reference's own formula then differ by ulps of the PARTS, which the coefficient (up to 0.5 W x conic x dx ~ 1e3 for a sharp
+     * Gaussian) turns into 1e-4 of the gradient.  The hand-built accumulator bar of the tests scales with max(abs13, cmag13). */
     /* dstate / state13 (optional, test instrumentation): the backward consumes the forward's per-pixel state (out_depth, out_acc,
      * final_T).  Two forward evaluations differ in that state by rounding, and the backward AMPLIFIES the difference where a term is a
      * small difference of large ones -- (final_depth - depth) dL_ddepth / acc at small acc, CR/backward.cu:535-541, :603-613.
@@ -632,10 +639,12 @@ void ex4d_oracle_render_bwd(
                 float dL_dalpha = 0.0f;
 
                 const float dep = depths[global_id];
+                double a_mag = 0.0;          /* magnitude of the parts of dL_dalpha (before the factor T below) */
                 double s_alpha = 0.0;        /* bound on |delta dL_dalpha| (before the factor T below) */
                 if ((dep > min_depth) & (alpha * T > 0.0f)) {
                     ACC(&dL_dmean2D[3 * (size_t)global_id + 2], 2, dL_ddepth * dchannel_dcolor);
                     dL_dalpha += (final_depth - dep) * dL_ddepth * T;
+                    a_mag += fabs(((double)final_depth - dep) * dL_ddepth * T);
                     STATE(2, fabs((double)dL_ddepth * dchannel_dcolor) * (e_A + e_T));
                     s_alpha += (e_fd + fabs((double)final_depth - dep) * (e_A + e_T)) * fabs((double)dL_ddepth) * T;
                 }
@@ -645,6 +654,7 @@ void ex4d_oracle_render_bwd(
                     last_color[ch] = c;
                     const float dL_dchannel = dL_dpixel[ch];
                     dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+                    a_mag += (fabs((double)c) + fabs((double)accum_rec[ch])) * fabs((double)dL_dchannel);
                     ACC(&dL_dcolors[global_id * 3 + ch], 7 + ch, dchannel_dcolor * dL_dchannel);
                     STATE(7 + ch, fabs((double)dchannel_dcolor * dL_dchannel) * e_T);
                 }
@@ -664,6 +674,11 @@ void ex4d_oracle_render_bwd(
                 for (int i = 0; i < 3; i++) bg_dot_dpixel += bg_color[i] * dL_dpixel[i];
                 dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
                 s_alpha += fabs((double)(-T_final / (1.f - alpha)) * bg_dot_dpixel) * e_T;
+                {
+                    double bg_abs = 0.0;
+                    for (int i = 0; i < 3; i++) bg_abs += fabs((double)bg_color[i] * dL_dpixel[i]);
+                    a_mag = a_mag * T + fabs((double)T_final / (1.0 - alpha)) * bg_abs;
+                }
 
                 const float dL_dG = con_o[3] * dL_dalpha;
                 const float gdx = G * dx;
@@ -680,6 +695,16 @@ void ex4d_oracle_render_bwd(
                 ACC(&dL_dconic2D[4 * (size_t)global_id + 3], 5, -0.5f * gdy * dy * dL_dG);
                 ACC(&dL_dopacity[global_id], 6, G * dL_dalpha);
                 ACC(&dL_dopacity[global_id], 6, G * dL_dacc);
+                if (cmag13) {
+                    const double m_G = fabs((double)con_o[3]) * a_mag * cond;     /* |dL_dG| with the parts of dL_dalpha un-cancelled */
+                    double *cm = cmag13 + 13 * (size_t)global_id;
+                    cm[0] += m_G * (fabs((double)gdx * con_o[0]) + fabs((double)gdy * con_o[1])) * ddelx_dx;
+                    cm[1] += m_G * (fabs((double)gdy * con_o[2]) + fabs((double)gdx * con_o[1])) * ddely_dy;
+                    cm[3] += 0.5 * fabs((double)gdx * dx) * m_G;
+                    cm[4] += 0.5 * fabs((double)gdx * dy) * m_G;
+                    cm[5] += 0.5 * fabs((double)gdy * dy) * m_G;
+                    cm[6] += (double)G * a_mag * cond + fabs((double)G * dL_dacc) * cond;
+                }
                 if (dstate && state13) {
                     const double s_G = fabs((double)con_o[3]) * s_alpha;          /* bound on |delta dL_dG| */
                     STATE(0, s_G * (fabs((double)gdx * con_o[0]) + fabs((double)gdy * con_o[1])) * ddelx_dx);

@@ -179,6 +179,8 @@ def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True, p
     colors = i["colors_precomp"] if i["colors_precomp"] is not None else fwd["rgb"]
     res["sum13"] = np.zeros((P, 13), np.float64) if want_sums else None
     res["abs13"] = np.zeros((P, 13), np.float64) if want_sums else None
+    # like abs13, with the parts of dL_dalpha taken before they cancel (ex4d_oracle.c: cmag13); the other seven accumulators = abs13
+    res["cmag13"] = np.zeros((P, 13), np.float64) if want_sums else None
     dstate = None
     res["state13"] = None
     if state_delta is not None:
@@ -191,7 +193,9 @@ def backward(fwd, grad_color, grad_depth, grad_flow, grad_acc, want_sums=True, p
         _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(gc), _p(gd), _p(gf), _p(ga),
         _p(res["dL_dmeans2D"]), _p(res["dL_dconic"]), _p(res["dL_ddir"]), _p(res["dL_dopacity"]), _p(res["dL_dcolors"]),
         _p(res["sum13"]), _p(res["abs13"]), _p(None if pixel_order is None else np.ascontiguousarray(pixel_order, dtype=np.uint32)),
-        _p(dstate), _p(res["state13"]))
+        _p(dstate), _p(res["state13"]), _p(res["cmag13"]))
+    if want_sums:
+        res["cmag13"] = np.maximum(res["cmag13"], res["abs13"])
     if stage:
         preprocess_backward(fwd, res)
     return res

@@ -284,6 +284,11 @@ def propagated_tolerance(fwd_o, tol13, acc13=None, noise_trials=6):
 
 ACC_GROUPS = {"dL_dmeans2D": slice(0, 3), "dL_dconic": slice(3, 6), "dL_dopacity": slice(6, 7), "dL_dcolors": slice(7, 10), "dL_ddir": slice(10, 13)}
 NOISE_C = 4.0            # HIP error <= NOISE_C x the reference's own run-to-run spread (VERDICT r02 item 1a asks for c <= 4)
+CANCEL_EPS = 2.0         # half-ulps of the UN-CANCELLED parts of dL_dalpha (oracle: cmag13) allowed on top of every accumulator bar: a Gaussian
+                         # whose colour nearly equals what lies behind it has a small dL_dalpha made of O(1) parts (measured: 634x for one row of
+                         # a random scene), and two float evaluations of the reference's own formula differ by an ulp of the PARTS -- which a
+                         # sharp Gaussian's coefficient (0.5 W x conic x dx ~ 1e3) turns into 1e-4 of its mean gradient.  Typical rows: cmag13 =
+                         # 3.4 x abs13 (median), so this adds ~7 half-ulps to the 64 of the bar
 NOISE_ABS = 1e-5         # north_star's absolute bar: a row whose error is below it passes whatever its noise estimate
 NOISE_FLOOR_EPS = 16.0   # ... or NOISE_FLOOR_EPS half-ulps of sum|terms| x cond where the replayed spread is below that (rows with 1-3 terms:
                          # a sum of two terms has NO order noise, yet two float evaluations of its terms -- expf vs v_exp_f32, fused
@@ -342,15 +347,18 @@ def compare_with_noise(rep, ref, gb, dev, P, floor_acc=None, floor_derived=None,
         iw = int(ratio.argmax())
         worst_row = dict(row=iw, err=float(row_err[iw]), ref_noise=float(row_noise[iw]), floor=float(np.broadcast_to(floor, row_err.shape)[iw]),
                          ref_abs_max=float(np.abs(a[iw]).max()))
-        out[k] = dict(err_max=err_t, ref_noise_max=noise_t, err_over_ref_noise=(err_t / noise_t if noise_t > 0 else 0.0),
+        floor_t = float(np.max(floor)) if np.ndim(floor) else float(floor)
+        out[k] = dict(err_max=err_t, ref_noise_max=noise_t, floor_max=floor_t, err_over_ref_noise=(err_t / noise_t if noise_t > 0 else 0.0),
                       row_ratio_max=float(ratio.max()), row_ratio_p999=float(np.quantile(ratio[live], 0.999)) if live.any() else 0.0,
                       rows_above_c=int((ratio > NOISE_C).sum()), rows=int(live.sum()), worst_row=worst_row,
                       row_ratio_noise_only_p999=float(np.quantile((row_err / (row_noise + 1e-300))[live & (row_noise > 0)], 0.999)) if (live & (row_noise > 0)).any() else 0.0)
     rep["noise_floor"] = out
     for k, r in out.items():
         if r["ref_noise_max"] > 0:
-            assert r["err_max"] <= NOISE_C * r["ref_noise_max"] + 1e-30, (f"{k}: max error {r['err_max']:.3e} is {r['err_over_ref_noise']:.2f}x the reference's own "
-                                                                       f"run-to-run spread {r['ref_noise_max']:.3e} (> {NOISE_C})")
+            # (the tensor's bar is the rows' bar at its largest: replayed spread or float-evaluation floor, whichever is larger)
+            bar_t = NOISE_C * max(r["ref_noise_max"], r["floor_max"])
+            assert r["err_max"] <= bar_t + 1e-30, (f"{k}: max error {r['err_max']:.3e} is {r['err_over_ref_noise']:.2f}x the reference's own "
+                                                   f"run-to-run spread {r['ref_noise_max']:.3e} (> {NOISE_C}; float-evaluation floor {r['floor_max']:.3e})")
         if assert_rows:
             assert r["rows_above_c"] == 0, f"{k}: {r['rows_above_c']} rows exceed {NOISE_C}x max(reference spread, float floor); worst x{r['row_ratio_max']:.2f}"
     return out
@@ -375,7 +383,8 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
     eps = 2.0 ** -24
     conic = fwd_o["conic_opacity"] if conic is None else conic
     acc = acc16_in_reference_units(gb["acc16"], fwd_o["W"], fwd_o["H"], conic=conic)[:, :13].astype(np.float64)
-    tol = atol + k_eps * eps * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
+    cancel = CANCEL_EPS * eps * ob["cmag13"] if ob.get("cmag13") is not None else 0.0
+    tol = atol + k_eps * eps * ob["abs13"] + cancel + 3e-6 * np.abs(ob["sum13"])
     extra_t = {}
     if extra13 is not None:
         extra13 = np.asarray(extra13, dtype=np.float64)
@@ -405,7 +414,7 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
     if noise is not None:
         # first check: the reference's own atomics-order noise floor (the hand-built bound below stays as the second check)
         dev = noise_floor(fwd_o, noise, ob["sum13"])
-        floor13 = NOISE_FLOOR_EPS * eps * ob["abs13"]
+        floor13 = NOISE_FLOOR_EPS * eps * ob["abs13"] + cancel
         fl = propagated_tolerance(fwd_o, floor13)
         compare_with_noise(rep, ref, gb, dev, P, floor_acc=floor13, floor_derived={k: fl[k] for k in DERIVED},
                            assert_rows=os.environ.get("EX4D_NOISE_ROWS_ASSERT", "1") != "0")

@@ -34,7 +34,7 @@ for k in ("kernel_size", "scale_modifier"):
 o = h.oracle_forward(ins, st, subpixel_offset=sub)
 H_, W_ = st["image_height"], st["image_width"]
 grads = list(h.upstream_grads(torch.from_numpy(o["acc"]), H_, W_, seed=kw["seed"], grad_acc_zero=kw["grad_acc_zero"]))
-solid = torch.from_numpy(o["fragile"] > 1e-4)
+solid = torch.from_numpy(o["fragile"] > h.FRAG_EPS)
 grads = [x * solid[None] for x in grads]
 for asm in (1, 0):
     _C.set_option("composite_fwd_asm", asm)
@@ -43,18 +43,24 @@ for asm in (1, 0):
     ob_state.update(depth=h.to_np(g["depth"]), acc=h.to_np(g["acc"]), final_T=np.ascontiguousarray(h.to_np(g["final_T"])),
                     n_contrib=np.ascontiguousarray(h.to_np(g["n_contrib"]).astype(np.uint32)))
     ob = oracle.backward(ob_state, *grads)
-    ob2 = oracle.backward(o, *grads)
+    dstate = [np.abs(o[k].astype(np.float64) - h.to_np(g[k]).astype(np.float64)).astype(np.float32).reshape(H_, W_) for k in ("depth", "acc", "final_T")]
+    ob2 = oracle.backward(o, *grads, state_delta=dstate)
     print("asm", asm, "n_contrib equal to oracle on solid:", bool((torch.from_numpy(o["n_contrib"].astype(np.int64))[solid] == g["n_contrib"].cpu()[solid]).all()),
           "max |final_T diff|", float(np.abs(h.to_np(g["final_T"]) - o["final_T"]).max()))
     for r in range(reps):
         gb = h.gpu_backward_raw(ins, g, grads)
         acc = h.acc16_in_reference_units(gb["acc16"], W_, H_, conic=o["conic_opacity"])[:, :13].astype(np.float64)
-        for name, obx, atol, keps in (("gpu-state", ob, 1e-5, 64.0), ("end-to-end", ob2, 3e-5, 256.0)):
-            tol = atol + keps * 2.0 ** -24 * obx["abs13"] + 3e-6 * np.abs(obx["sum13"])
+        for name, obx, atol, keps in (("gpu-state", ob, 1e-5, 64.0), ("end-to-end", ob2, 1e-5, 64.0)):
+            tol = atol + keps * 2.0 ** -24 * obx["abs13"] + 3e-6 * np.abs(obx["sum13"]) + (2.0 * obx["state13"] if obx.get("state13") is not None else 0.0)
             err = np.abs(acc - obx["sum13"])
             ratio = err / tol
             i, j = np.unravel_index(ratio.argmax(), ratio.shape)
             print(f"  rep {r} {name}: worst ratio {ratio.max():.3f} at {(int(i), int(j))}: gpu {acc[i, j]:.9g} ref {obx['sum13'][i, j]:.9g} abs13 {obx['abs13'][i, j]:.6g} tol {tol[i, j]:.3g}")
         if r == 0:
-            i = 959 if acc.shape[0] > 959 else 0
+            ratio = np.abs(acc - ob["sum13"]) / (1e-5 + 64.0 * 2.0 ** -24 * ob["abs13"] + 3e-6 * np.abs(ob["sum13"]))
+            i = int(np.unravel_index(ratio.argmax(), ratio.shape)[0])
+            px, py = o["means2D"][i]
+            x0, y0 = max(0, int(px) - 2), max(0, int(py) - 2)
+            print("   fragile margins around the mean:", o["fragile"][y0:y0 + 5, x0:x0 + 5].min(), "acc there", o["acc"][0, y0:y0 + 5, x0:x0 + 5].min(), o["acc"][0, y0:y0 + 5, x0:x0 + 5].max(),
+                  "n_contrib gpu/oracle equal there:", bool((h.to_np(g["n_contrib"])[y0:y0 + 5, x0:x0 + 5] == o["n_contrib"][y0:y0 + 5, x0:x0 + 5]).all()))
             print("   row", i, "gpu", acc[i, :7], "\n   ref", ob["sum13"][i, :7], "\n   abs", ob["abs13"][i, :7], "\n   conic/opacity", o["conic_opacity"][i], "mean2D", o["means2D"][i], "radius", o["radii"][i], "tiles", o["tiles_touched"][i])
