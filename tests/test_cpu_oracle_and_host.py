@@ -570,8 +570,8 @@ def test_drop_in_packages_import_under_the_reference_names():
 
 
 def test_build_refuses_kernels_with_vector_register_spills(tmp_path):
-    """ex4dgs_amd.build parses the compiler's resource remarks of every object: a kernel with VGPR spills fails the build (a spilling
-    build of the per-Gaussian backward returned wrong gradients), and the remarks do not drown the compiler's real diagnostics."""
+    """ex4dgs_amd.build parses the compiler's resource remarks of every object: a kernel with VGPR spills fails the build (every kernel
+    is laid out for its register budget), and the remarks do not drown the compiler's real diagnostics."""
     from ex4dgs_amd import build
     ok = ("a.hip:3:1: remark: Function Name: k_fine [-Rpass-analysis=kernel-resource-usage]\n"
           "a.hip:3:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n")
@@ -587,6 +587,37 @@ def test_build_refuses_kernels_with_vector_register_spills(tmp_path):
     text = bad + "a.hip:20:5: warning: unused variable 'x' [-Wunused-variable]\n   20 |     int x;\n      |         ^\n2 remarks generated.\n"
     kept = build._without_remarks(text)
     assert "unused variable" in kept and "int x;" in kept and "remark" not in kept and "Spill" not in kept
+
+
+def test_build_refuses_64bit_shifts_by_the_last_vector_register(tmp_path):
+    """gfx950: a 64-bit shift whose shift amount sits in the last register of the wave's allocation shifts by VGPR0 in waves that share
+    their SIMD (tools/dev/micro/topreg_probe.hip, profiles/r04_topreg_probe.txt): this, not its spills, made the 128-register build of
+    the per-Gaussian backward wrong.  The build disassembles every object and refuses such a kernel: a kernel that does it on purpose is
+    found, the same kernel with the amount one register lower is not, and none of the library's own objects holds one."""
+    import subprocess
+    from ex4dgs_amd import build
+    src = """#include <hip/hip_runtime.h>
+__global__ __launch_bounds__(256, 4) void k(unsigned long long *out, unsigned long long need, unsigned x)
+{
+    unsigned long long d;
+    asm volatile("v_mov_b32_e32 REG, %1\\n\\ts_nop 1\\n\\tv_lshrrev_b64 %0, REG, %2" : "=&v"(d) : "v"(x + threadIdx.x), "s"(need) : "REG", "v127");
+    out[blockIdx.x * 256 + threadIdx.x] = d;
+}
+"""
+    for reg, expect in (("v127", 1), ("v126", 0)):
+        hip, obj = tmp_path / f"k_{reg}.hip", tmp_path / f"k_{reg}.o"
+        hip.write_text(src.replace("REG", reg))
+        subprocess.check_call([build._hipcc(), "-O3", f"--offload-arch={build.ARCH}", "-c", str(hip), "-o", str(obj)])
+        found = build.shift_amount_in_last_vgpr(str(obj))
+        assert len(found) == expect, (reg, found)
+        if expect:
+            assert "v_lshrrev_b64" in found[0][1] and "v127" in found[0][1]
+            with pytest.raises(RuntimeError, match="last vector register"):
+                build._no_shift_amount_in_last_vgpr("k.hip", str(obj))
+            assert not obj.exists()
+    build.build()
+    for f in build.SOURCES:
+        assert build.shift_amount_in_last_vgpr(os.path.join(build.CSRC, f.replace(".hip", ".o"))) == [], f
 
 
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports

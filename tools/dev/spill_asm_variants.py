@@ -1,0 +1,257 @@
+"""Developer probe, part 2 of tools/dev/spill_probe.py: the spilling build of preprocess_bwd_kernel<false>
+(__launch_bounds__(256, 4)) returns wrong dL_dmeans3D for the Gaussians in lanes 37-42 of waves that are not the first on their SIMD.
+Those six are exactly the rows whose SH chunks travel as 16-byte chunk index 1 of the second half slice (chunks 448..511 of the wave's
+block: rows 37.33 .. 42.58), so the fault sits in that chunk's way from memory to LDS or in what the sums read back, not necessarily
+in the scratch reloads.  This script patches the DEVICE ASSEMBLY of that build -- one intervention per variant -- and links one
+library per variant; `spill_probe.py variants <dir>` then runs them on the GPU and says which intervention makes the fault go away.
+
+    python tools/dev/spill_asm_variants.py [outdir]        # CPU only (hipcc cross-compiles); default outdir tools/dev/spill_variants
+
+Variants (all from the same device assembly):
+  base       unpatched round trip through the assembler (must still fail: validates the pipeline)
+  dswait     s_waitcnt lgkmcnt(0) behind every ds_write_b128 of the packed half-slice staging of half 1 (a VGPR of the store's data or
+             address is overwritten by the next VALU instruction: an operand-read hazard would show here)
+  ldwait     s_waitcnt vmcnt(0) behind every global_load_dwordx4 of that staging
+  scrwait    s_waitcnt vmcnt(0) lgkmcnt(0) + s_nop 7 before every scratch load and behind every scratch store of the kernel
+  rdwait     s_waitcnt lgkmcnt(0) behind every LDS read of the kernel
+  vnop       s_nop 3 behind every VALU instruction of the kernel (any missing wait state between a VALU instruction and its consumer)
+  ldcheck    detector: the chunk's registers at commit time against a second load of the same bytes (mismatch -> NaN)
+  ldcheck_cN the same for chunk N (0..5) of half 1;  ldzero / ldnonzero: ldcheck restricted to registers that hold zero / something else
+  ld2x       the chunk is loaded a second time before the commit;  ldmove: its load takes its address from registers outside its destination
+  lowregs    chunk 1's q / row index move from the wave's two highest registers (v126, v127: used for nothing else) to v14, v15
+  swapregs   chunk 1 and chunk 3 trade those registers (the fault should move to chunk 3's rows 48..53 if it belongs to the registers)
+  pad136     the kernel descriptor allocates 136 registers instead of 128 (v127 is no longer the top of the allocation)
+  ldscheck   detector: the chunk read back from LDS right behind its write against the registers (mismatch -> NaN into LDS)
+  keepcheck  detector: a copy of the chunk's first dword against LDS behind all six writes of the commit (mismatch -> NaN into LDS)
+  rowcalc    the LDS row of chunk 1 recomputed from the chunk's own row index (the compiler reuses the register that holds chunk 1 of
+             half 0's row: v118) -- a corrupted v118 would show here
+  rowcheck   detector: lanes whose v118 differs from the recomputed row get NaN into the chunk's first dword (NaNs in the output =
+             v118 was corrupted)
+"""
+import os, re, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "ex4dgs_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True, **kw)
+    assert r.returncode == 0, " ".join(cmd) + "\n" + r.stderr[-3000:]
+    return r
+
+
+def kernel_span(lines):
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and "preprocess_bwd_kernelILb0E" in l and ":" in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+    return start, end
+
+
+def staging_span(lines, k0, k1):
+    """packed staging of half 1: from the chunk index 0x180 | lane to the end of its LDS commit (the next label behind the ds_writes)"""
+    a = next(i for i in range(k0, k1) if re.search(r"v_or_b32_e32 v\d+, 0x180, v\d+", lines[i]))
+    # the commit ends at the first label behind the first group of six ds_write_b128 without an `offset:` (the packed path computes addresses)
+    writes = [i for i in range(a, k1) if "ds_write_b128" in lines[i]]
+    six = writes[:6]
+    assert all("offset:" not in lines[i] for i in six), [lines[i] for i in six]
+    b = next(i for i in range(six[-1], k1) if lines[i].startswith(".LBB"))
+    return a, b
+
+
+def patch(lines, name):
+    k0, k1 = kernel_span(lines)
+    a, b = staging_span(lines, k0, k1)
+    out = list(lines)
+
+    def insert_after(pred, text, lo, hi):
+        n = 0
+        for i in range(hi - 1, lo - 1, -1):
+            if pred(out[i]):
+                out[i + 1:i + 1] = text
+                n += 1
+        return n
+
+    def insert_before(pred, text, lo, hi):
+        n = 0
+        for i in range(hi - 1, lo - 1, -1):
+            if pred(out[i]):
+                out[i:i] = text
+                n += 1
+        return n
+
+    if name == "base":
+        n = 1
+    elif name == "dswait":
+        n = insert_after(lambda l: "ds_write_b128" in l, ["\ts_waitcnt lgkmcnt(0)"], a, b)
+        assert n == 6, n
+    elif name == "ldwait":
+        n = insert_after(lambda l: "global_load_dwordx4" in l, ["\ts_waitcnt vmcnt(0)"], a, b)
+        assert n == 6, n
+    elif name == "scrwait":
+        n = insert_after(lambda l: "scratch_store_dword" in l, ["\ts_waitcnt vmcnt(0)"], k0, k1)
+        n += insert_before(lambda l: "scratch_load_dword" in l, ["\ts_waitcnt vmcnt(0) lgkmcnt(0)", "\ts_nop 7"], k0, k1 + 16)
+        assert n == 3 + 12, n
+    elif name in ("predA", "predB", "snapexp", "lateexp"):
+        # which read of v126 / v127 is wrong?  predA / predB: the compare `row < rows of the wave` / `chunk-in-row < chunks per row` came out
+        # false (never legitimate in a full wave);  snapexp: copies taken by the two instructions right behind the write differ from the
+        # values recomputed at commit time;  lateexp: v126 / v127 read at commit time differ from the recomputed values
+        i_or = next(i for i in range(a, b) if re.search(r"v_or_b32_e32 v126, 0x1c0, (v\d+)", out[i]))
+        lane = re.search(r"0x1c0, (v\d+)", out[i_or]).group(1)
+        assert "v_lshrrev_b32_e32 v127, 16" in out[i_or + 2] and "v_cmp_gt_i32_e32 vcc" in out[i_or + 3] and "v127" in out[i_or + 3]
+        i_b = next(i for i in range(i_or, i_or + 20) if "v_mad_i32_i24" in out[i] and "v127, -12, v126" in out[i])
+        assert "v_cmp_gt_i32_e32 vcc" in out[i_b + 1]
+        writes = [i for i in range(a, b) if "ds_write_b128" in out[i]]
+        i_join = max(i for i in range(a, writes[0]) if out[i].strip().startswith("s_or_b64 exec, exec,"))
+        tmp_s = re.search(r"s_or_b64 exec, exec, (s\[\d+:\d+\])", out[i_join]).group(1)
+        assert "v_mul_lo_u16_e32 v56" in out[i_join + 1], out[i_join + 1]           # v56 / v57 (the base pointer) are dead from here on
+        assert not any(re.search(r"\bv1[45]\b|\[14:15\]", out[i]) for i in range(a, b))
+        expect = [f"\tv_or_b32_e32 v56, 0x1c0, {lane}", "\tv_mul_u32_u24_e32 v57, 0x1556, v56", "\tv_lshrrev_b32_e32 v57, 16, v57"]
+        mark = ["\tv_mov_b32_e32 v15, 0x7fc00000", "\tv_cndmask_b32_e32 v22, v22, v15, vcc"]
+        if name in ("predA", "predB"):
+            at = i_or + 3 if name == "predA" else i_b + 1
+            out[i_join + 1:i_join + 1] = ["\ts_waitcnt vmcnt(0)", "\tv_cmp_eq_u32_e32 vcc, 1, v14"] + mark
+            out[at + 1:at + 1] = ["\tv_cndmask_b32_e64 v14, 1, 0, vcc"]
+            out[i_or:i_or] = ["\tv_mov_b32_e32 v14, 0"]
+        elif name == "snapexp":
+            out[i_join + 1:i_join + 1] = ["\ts_waitcnt vmcnt(0)"] + expect + ["\tv_cmp_ne_u32_e32 vcc, v15, v57", f"\tv_cmp_ne_u32_e64 {tmp_s}, v14, v56",
+                                                                                f"\ts_or_b64 vcc, vcc, {tmp_s}"] + mark
+            out[i_or + 3:i_or + 3] = ["\tv_mov_b32_e32 v15, v127", "\tv_mov_b32_e32 v14, v126"]
+        else:
+            out[i_join + 1:i_join + 1] = ["\ts_waitcnt vmcnt(0)"] + expect + ["\tv_cmp_ne_u32_e32 vcc, v127, v57", f"\tv_cmp_ne_u32_e64 {tmp_s}, v126, v56",
+                                                                                f"\ts_or_b64 vcc, vcc, {tmp_s}"] + mark
+        n = 1
+    elif name in ("lowregs", "swapregs"):
+        # chunk 1's q and row index live in the two HIGHEST registers of the wave (v126, v127) and nowhere else are those two used
+        i_or = next(i for i in range(a, b) if re.search(r"v_or_b32_e32 v\d+, 0x1c0, v\d+", out[i]))
+        q1 = re.search(r"v_or_b32_e32 (v\d+), 0x", out[i_or]).group(1)
+        g1 = re.search(r"v_lshrrev_b32_e32 (v\d+), 16, v\d+", out[i_or + 2]).group(1)
+        assert (q1, g1) == ("v126", "v127"), (q1, g1)
+        assert not any(re.search(r"\bv12[67]\b", out[i]) for i in list(range(k0, a)) + list(range(b, k1)))
+        if name == "lowregs":
+            assert not any(re.search(r"\bv1[45]\b|\[14:15\]", out[i]) for i in range(a, b))
+            ren = {"v126": "v14", "v127": "v15"}
+        else:
+            i_or3 = next(i for i in range(a, b) if re.search(r"v_or_b32_e32 v\d+, 0x240, v\d+", out[i]))
+            q3 = re.search(r"v_or_b32_e32 (v\d+), 0x", out[i_or3]).group(1)
+            g3 = re.search(r"v_lshrrev_b32_e32 (v\d+), 16, v\d+", out[i_or3 + 2]).group(1)
+            print(f"  chunk 3: q {q3}, row {g3} trade places with v126, v127")
+            ren = {"v126": q3, "v127": g3, q3: "v126", g3: "v127"}
+        for i in range(a, b):
+            out[i] = re.sub(r"\bv\d+\b", lambda m: ren.get(m.group(0), m.group(0)), out[i])
+        n = 1
+    elif name == "pad136":
+        # the kernel descriptor asks for 136 registers: v127 is no longer the last register of the wave's allocation
+        i_k = next(i for i in range(len(out)) if out[i].strip().startswith(".amdhsa_kernel") and "preprocess_bwd_kernelILb0E" in out[i])
+        for key in (".amdhsa_next_free_vgpr", ".amdhsa_accum_offset"):
+            j = next(i for i in range(i_k, i_k + 80) if out[i].strip().startswith(key))
+            assert out[j].split()[-1] == "128", out[j]
+            out[j] = out[j].replace("128", "136")
+        n = 1
+    elif name == "rdwait":
+        n = insert_after(lambda l: l.strip().startswith("ds_read"), ["\ts_waitcnt lgkmcnt(0)"], k0, k1)
+    elif name == "vnop":
+        n = insert_after(lambda l: l.strip().startswith("v_"), ["\ts_nop 3"], k0, k1)
+    elif name in ("ldcheck", "ldscheck", "keepcheck", "ldzero", "ldnonzero", "ld2x", "ldmove") or re.fullmatch(r"ldcheck_c\d", name):
+        # chunk c of half 1 (default 1): its chunk index q, the wave's base pointer, its data registers and its LDS address register
+        c = int(name[-1]) if re.fullmatch(r"ldcheck_c\d", name) else 1
+        i_or = next(i for i in range(a, b) if re.search(r"v_or_b32_e32 v\d+, 0x%x, v\d+" % (0x180 + 64 * c), out[i]))
+        q = re.search(r"v_or_b32_e32 (v\d+), 0x", out[i_or]).group(1)
+        m_rows = re.search(r"v_cmp_gt_i32_e32 vcc, (v\d+), (v\d+)", out[i_or + 3])
+        nrows, g = m_rows.group(1), m_rows.group(2)
+        loads = [i for i in range(a, b) if "global_load_dwordx4" in out[i]]
+        d0 = int(re.search(r"global_load_dwordx4 v\[(\d+):\d+\]", out[loads[c]]).group(1))
+        base = re.search(r"v_lshl_add_u64 v\[\d+:\d+\], (v\[\d+:\d+\]), 0,", out[loads[c] - 1]).group(1)
+        writes = [i for i in range(a, b) if "ds_write_b128" in out[i]]
+        i_w = next(i for i in writes if f"v[{d0}:{d0 + 3}]" in out[i])
+        addr = re.search(r"ds_write_b128 (v\d+),", out[i_w]).group(1)
+        i_join = max(i for i in range(a, writes[0]) if out[i].strip().startswith("s_or_b64 exec, exec,"))
+        tmp_s = re.search(r"s_or_b64 exec, exec, (s\[\d+:\d+\])", out[i_join]).group(1)
+        assert not any(re.search(r"\bv1[45]\b|\[14:15\]", out[i]) for i in range(i_join, b)), "v14 / v15 are not free here"
+        assert not any("vcc" in out[i] for i in range(i_join, b))
+        print(f"  chunk 1 of half 1: q {q}, base {base}, data v[{d0}:{d0 + 3}], LDS address {addr}, scalar temporary {tmp_s}")
+        nan_to_lds = [f"\tv_mov_b32_e32 v15, 0x7fc00000", f"\ts_and_saveexec_b64 {tmp_s}, vcc", f"\tds_write_b32 {addr}, v15", f"\ts_or_b64 exec, exec, {tmp_s}"]
+        reload = ["\ts_waitcnt vmcnt(0)", f"\tv_lshlrev_b32_e32 v14, 4, {q}", "\tv_mov_b32_e32 v15, 0", f"\tv_lshl_add_u64 v[14:15], {base}, 0, v[14:15]"]
+        if name in ("ldzero", "ldnonzero"):      # ldcheck split by what the wrong register holds: zero (= the chunk was not loaded) or other data
+            out[i_join + 1:i_join + 1] = reload + ["\tglobal_load_dword v14, v[14:15], off", "\ts_waitcnt vmcnt(0)", f"\tv_cmp_ne_u32_e32 vcc, v14, v{d0}",
+                                                   f"\tv_cmp_eq_u32_e64 {tmp_s}, 0, v{d0}",
+                                                   f"\ts_and_b64 vcc, vcc, {tmp_s}" if name == "ldzero" else f"\ts_andn2_b64 vcc, vcc, {tmp_s}",
+                                                   "\tv_mov_b32_e32 v15, 0x7fc00000", f"\tv_cndmask_b32_e32 v{d0}, v{d0}, v15, vcc"]
+        elif name == "ld2x":          # the chunk loaded a second time (all rows of the wave) before the commit
+            out[i_join + 1:i_join + 1] = reload + [f"\tv_cmp_gt_i32_e32 vcc, {nrows}, {g}", f"\ts_and_saveexec_b64 {tmp_s}, vcc",
+                                                   f"\tglobal_load_dwordx4 v[{d0}:{d0 + 3}], v[14:15], off", f"\ts_or_b64 exec, exec, {tmp_s}"]
+        elif name == "ldmove":        # the chunk's own load with address registers that are not part of its destination
+            assert not any(re.search(r"\bv1[45]\b|\[14:15\]", out[i]) for i in range(a, b)), "v14 / v15 are not free in the staging"
+            i_l = loads[c]
+            assert re.search(r"v_lshlrev_b32_e32 v%d, 4, %s" % (d0, q), out[i_l - 3]) and f"v_mov_b32_e32 v{d0 + 1}, 0" in out[i_l - 2], out[i_l - 3:i_l + 1]
+            out[i_l - 3:i_l + 1] = [f"\tv_lshlrev_b32_e32 v14, 4, {q}", "\tv_mov_b32_e32 v15, 0", f"\tv_lshl_add_u64 v[14:15], {base}, 0, v[14:15]",
+                                    f"\tglobal_load_dwordx4 v[{d0}:{d0 + 3}], v[14:15], off"]
+        elif name.startswith("ldcheck"):         # registers at commit time against a second load of the same 4 bytes
+            out[i_join + 1:i_join + 1] = ["\ts_waitcnt vmcnt(0)", f"\tv_lshlrev_b32_e32 v14, 4, {q}", "\tv_mov_b32_e32 v15, 0",
+                                          f"\tv_lshl_add_u64 v[14:15], {base}, 0, v[14:15]", "\tglobal_load_dword v14, v[14:15], off",
+                                          "\ts_waitcnt vmcnt(0)", f"\tv_cmp_ne_u32_e32 vcc, v14, v{d0}", "\tv_mov_b32_e32 v15, 0x7fc00000",
+                                          f"\tv_cndmask_b32_e32 v{d0}, v{d0}, v15, vcc"]
+        elif name == "ldscheck":      # LDS read back right behind the chunk's write against the registers
+            out[i_w + 1:i_w + 1] = ["\ts_waitcnt lgkmcnt(0)", f"\tds_read_b32 v14, {addr}", "\ts_waitcnt lgkmcnt(0)",
+                                    f"\tv_cmp_ne_u32_e32 vcc, v14, v{d0}"] + nan_to_lds
+        else:                          # a copy of the chunk's first dword against LDS at the end of the commit (behind all six writes)
+            end = [f"\ts_waitcnt lgkmcnt(0)", f"\tds_read_b32 v15, {addr}", "\ts_waitcnt lgkmcnt(0)", "\tv_cmp_ne_u32_e32 vcc, v15, v14"] + nan_to_lds \
+                  + [f"\ts_mov_b64 {tmp_s}, 0"]
+            out[writes[5] + 1:writes[5] + 1] = end
+            out[i_w:i_w] = [f"\tv_mov_b32_e32 v14, v{d0}"]
+        n = 1
+    elif name in ("rowcalc", "rowcheck"):
+        # chunk 1: its row index g = q / 12 and the reused register
+        i_or = next(i for i in range(a, b) if re.search(r"v_or_b32_e32 v\d+, 0x1c0, v\d+", out[i]))
+        g = re.search(r"v_lshrrev_b32_e32 (v\d+), 16, v\d+", out[i_or + 2]).group(1)
+        i_mul = [i for i in range(a, b) if re.search(r"v_mul_u32_u24_e32 v\d+, 0xd0, v\d+", out[i])][1]
+        m = re.search(r"v_mul_u32_u24_e32 (v\d+), 0xd0, (v\d+)", out[i_mul])
+        dst, reused = m.group(1), m.group(2)
+        # the chunk's data registers: the ds_write behind the multiplication
+        i_w = next(i for i in range(i_mul, b) if "ds_write_b128" in out[i])
+        d0 = re.search(r"ds_write_b128 v\d+, v\[(\d+):\d+\]", out[i_w]).group(1)
+        print(f"  chunk 1 of half 1: row index {g}, reused row register {reused}, product {dst}, data v[{d0}:..]")
+        if name == "rowcalc":
+            out[i_mul:i_mul + 1] = [f"\tv_subrev_u32_e32 {dst}, 32, {g}", f"\tv_mul_u32_u24_e32 {dst}, 0xd0, {dst}"]
+        else:
+            out[i_mul:i_mul] = [f"\tv_subrev_u32_e32 {dst}, 32, {g}", f"\tv_cmp_ne_u32_e32 vcc, {dst}, {reused}",
+                                f"\tv_mov_b32_e32 {dst}, 0x7fc00000", f"\tv_cndmask_b32_e32 v{d0}, v{d0}, {dst}, vcc"]
+        n = 1
+    else:
+        raise ValueError(name)
+    return out
+
+
+def main():
+    outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "dev", "spill_variants")
+    from ex4dgs_amd import build
+    build.build()
+    tmp = "/tmp/ex4d_spill_asm"
+    shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp); os.makedirs(outdir, exist_ok=True)
+    src = open(os.path.join(CSRC, "ex4d_preprocess.hip")).read()
+    a = "template <bool DSUMS>\n__global__ __launch_bounds__(256) void preprocess_bwd_kernel("
+    assert a in src
+    src = src.replace(a, a.replace("(256)", "(256, 4)")).replace('#include "ex4d_internal.h"', f'#include "{CSRC}/ex4d_internal.h"')
+    hip = os.path.join(tmp, "pre.hip")
+    open(hip, "w").write(src)
+    flags = build.COMMON + build.SOURCES["ex4d_preprocess.hip"] + [f"-I{ROOT}/include"]
+    run([build._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", os.path.join(tmp, "dev.s"), hip])
+    lines = open(os.path.join(tmp, "dev.s")).read().split("\n")
+    others = [os.path.join(CSRC, f.replace(".hip", ".o")) for f in build.SOURCES if f != "ex4d_preprocess.hip"]
+    for name in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("base", "dswait", "ldwait", "scrwait", "rdwait", "vnop", "rowcalc", "rowcheck", "ldcheck", "ldscheck", "keepcheck")):
+        print(name, flush=True)
+        d = os.path.join(tmp, name); os.makedirs(d)
+        s = os.path.join(d, "dev.s")
+        open(s, "w").write("\n".join(patch(lines, name)))
+        run([f"{LLVM}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s, "-o", os.path.join(d, "dev.o")])
+        run([f"{LLVM}/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", os.path.join(d, "dev.out"), os.path.join(d, "dev.o")])
+        run([f"{LLVM}/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
+             "-input=/dev/null", f"-input={os.path.join(d, 'dev.out')}", f"-output={os.path.join(d, 'dev.hipfb')}"])
+        run([build._hipcc()] + flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", os.path.join(d, "dev.hipfb"),
+                                        "-c", hip, "-o", os.path.join(d, "pre.o")])
+        lib = os.path.join(outdir, f"lib_{name}.so")
+        run([build._hipcc(), "-shared", "-fPIC", f"--offload-arch={build.ARCH}", "-o", lib, os.path.join(d, "pre.o")] + others)
+        print("  ->", lib, os.path.getsize(lib))
+
+
+if __name__ == "__main__":
+    main()

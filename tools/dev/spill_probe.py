@@ -4,12 +4,16 @@ into /tmp, runs the same forward + backward through the default library and thro
 process) on BASELINE config 2 at 100 k Gaussians, and prints WHICH Gaussians differ, in which tensors, and what they have in common.
 
     python tools/dev/spill_probe.py            # driver: builds, runs both, compares
-    python tools/dev/spill_probe.py run <out>  # worker: forward + backward with the library EX4D_HIP_LIB names, results -> <out>"""
+    python tools/dev/spill_probe.py run <out>  # worker: forward + backward with the library EX4D_HIP_LIB names, results -> <out>
+    python tools/dev/spill_probe.py variants <dir>   # the assembly-patched libraries of tools/dev/spill_asm_variants.py, one line each
+
+Result (round 4): not the spills -- a 64-bit shift whose shift amount the register allocator had put into the wave's
+last register (v127) reads VGPR0 instead on gfx950 in waves that share their SIMD; stand-alone: tools/dev/micro/topreg_probe.hip."""
 import os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "ex4dgs_amd", "csrc")
-SIZES = (100_000, 65_536, 40_000, 131_072)
+SIZES = tuple(int(x) for x in os.environ.get("EX4D_SPILL_PROBE_SIZES", "100000,65536,40000,131072").split(","))
 
 
 def build_variant(dst, patch):
@@ -88,8 +92,45 @@ def main():
                 print(f"    row {i}: default {x[i][:8]} variant {y[i][:8]} bit-equal accumulators: {bool(same_acc[i])}")
 
 
+def variants(libdir):
+    """the assembly-patched libraries of tools/dev/spill_asm_variants.py against the default build, P = 100 000"""
+    import glob
+    import numpy as np
+    os.environ["EX4D_SPILL_PROBE_SIZES"] = "100000"
+    dst = "/tmp/ex4d_spill_probe_variants"
+    shutil.rmtree(dst, ignore_errors=True); os.makedirs(dst)
+    libs = sorted(glob.glob(os.path.join(libdir, "lib_*.so")), key=lambda p: (os.path.basename(p) != "lib_base.so", p))
+    runs = [("default", None)] + [(os.path.basename(p)[4:-3], p) for p in libs]
+    ref = None
+    for name, lib in runs:
+        out = os.path.join(dst, name + ".npz")
+        e = dict(os.environ)
+        e.pop("EX4D_HIP_LIB", None)
+        if lib: e["EX4D_HIP_LIB"] = lib
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "run", out], env=e, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            print(f"{name}: FAILED to run\n{r.stderr[-800:]}", flush=True); continue
+        d = np.load(out)
+        if ref is None: ref = d; continue
+        P = 100000
+        x, y = ref[f"{P}/0/dL_dmeans3D"].reshape(P, -1), d[f"{P}/0/dL_dmeans3D"].reshape(P, -1)
+        radii = ref[f"{P}/radii"]
+        scale = np.maximum(np.abs(x).max(1), 1e-30)
+        rel = np.abs(x - y).max(1) / scale
+        bad = np.nonzero(((rel > 1e-3) | ~np.isfinite(y).all(1)) & (radii > 0))[0]
+        nan_rows = np.nonzero(~np.isfinite(y).all(1) & (radii > 0))[0]
+        lanes = np.bincount(bad % 64, minlength=64)
+        nz = np.nonzero(lanes)[0]
+        print(f"{name}: rows off by > 1e-3: {len(bad)} (non-finite: {len(nan_rows)}); lanes {nz.min() if len(nz) else '-'}..{nz.max() if len(nz) else '-'}; "
+              f"blocks from {int(bad.min()) // 256 if len(bad) else '-'}; other tensors off: "
+              + ", ".join(f"{k} {int((np.abs(ref[f'{P}/0/{k}'].reshape(P, -1) - d[f'{P}/0/{k}'].reshape(P, -1)).max(1) / np.maximum(np.abs(ref[f'{P}/0/{k}'].reshape(P, -1)).max(1), 1e-30) > 1e-3)[radii > 0].sum())}"
+                          for k in ("dL_dsh", "dL_dscales", "dL_drotations")), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "run":
+    if len(sys.argv) > 2 and sys.argv[1] == "variants":
+        variants(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "run":
         worker(sys.argv[2])
     else:
         main()
