@@ -5,6 +5,7 @@ process) on BASELINE config 2 at 100 k Gaussians, and prints WHICH Gaussians dif
 
     python tools/dev/spill_probe.py            # driver: builds, runs both, compares
     python tools/dev/spill_probe.py run <out>  # worker: forward + backward with the library EX4D_HIP_LIB names, results -> <out>
+    python tools/dev/spill_probe.py build_fix <dir>  # CPU: the 128-register build as is and with a 32-bit visibility predicate (the source fix)
     python tools/dev/spill_probe.py variants <dir>   # the assembly-patched libraries of tools/dev/spill_asm_variants.py, one line each
 
 Result (round 4): not the spills -- a 64-bit shift whose shift amount the register allocator had put into the wave's
@@ -63,8 +64,7 @@ def main():
     import numpy as np
     dst = "/tmp/ex4d_spill_probe"
     shutil.rmtree(dst, ignore_errors=True)
-    lib = build_variant(dst, lambda s: s.replace("template <bool DSUMS>\n__global__ __launch_bounds__(256) void preprocess_bwd_kernel(",
-                                                 "template <bool DSUMS>\n__global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel("))
+    lib = build_variant(dst, lambda s: s.replace(*BOUNDS))
     outs = {}
     for name, env in (("default", {}), ("variant", {"EX4D_HIP_LIB": lib})):
         out = os.path.join(dst, name + ".npz")
@@ -90,6 +90,27 @@ def main():
                 print("    (row // 64) % 4 (wave in block) histogram:", np.bincount((bad // 64) % 4, minlength=4).tolist(), " blocks:", sorted(set((bad // 256).tolist()))[:20])
                 i = int(bad[0])
                 print(f"    row {i}: default {x[i][:8]} variant {y[i][:8]} bit-equal accumulators: {bool(same_acc[i])}")
+
+
+BOUNDS = ("template <bool DSUMS>\n__global__ __launch_bounds__(256) void preprocess_bwd_kernel(",
+          "template <bool DSUMS>\n__global__ __launch_bounds__(256, 4) void preprocess_bwd_kernel(")
+NEED32 = "mask_bit(need, g)"                       # what the sources hold since round 4
+NEED64 = "(((need >> g) & 1ull) != 0ull)"          # what they held before: a 64-bit shift by a per-lane amount
+
+
+def build_fix(outdir):
+    """CPU: the forced-128-register build of the sources as they are (lib_fixed32.so: the visibility predicate of the SH chunk loads
+    comes from the two 32-bit halves of the mask, so no 64-bit shift by a per-lane amount is left for the allocator to place in v127) and
+    with the predicate they had before round 4 (lib_base.so: `(need >> g) & 1`); says what build.shift_amount_in_last_vgpr finds in
+    each.  Run them with `variants <outdir>` on the GPU: base has the wrong rows, fixed32 none -- with the same three spills."""
+    from ex4dgs_amd import build
+    os.makedirs(outdir, exist_ok=True)
+    for name, patch in (("base", lambda s: s.replace(*BOUNDS).replace(NEED32, NEED64)), ("fixed32", lambda s: s.replace(*BOUNDS))):
+        dst = f"/tmp/ex4d_spill_fix_{name}"
+        shutil.rmtree(dst, ignore_errors=True)
+        lib = build_variant(dst, patch)
+        print(name, "-> 64-bit shifts by the last register:", build.shift_amount_in_last_vgpr(os.path.join(dst, "ex4d_preprocess.o")), flush=True)
+        shutil.copy(lib, os.path.join(outdir, f"lib_{name}.so"))
 
 
 def variants(libdir):
@@ -128,7 +149,9 @@ def variants(libdir):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "variants":
+    if len(sys.argv) > 2 and sys.argv[1] == "build_fix":
+        build_fix(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "variants":
         variants(sys.argv[2])
     elif len(sys.argv) > 2 and sys.argv[1] == "run":
         worker(sys.argv[2])
