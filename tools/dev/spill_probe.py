@@ -17,8 +17,9 @@ CSRC = os.path.join(ROOT, "ex4dgs_amd", "csrc")
 SIZES = tuple(int(x) for x in os.environ.get("EX4D_SPILL_PROBE_SIZES", "100000,65536,40000,131072").split(","))
 
 
-def build_variant(dst, patch):
-    """All objects of the in-tree build except ex4d_preprocess.o, which is compiled from a patched copy of the source."""
+def build_variant(dst, patch, info=None):
+    """All objects of the in-tree build except ex4d_preprocess.o, which is compiled from a patched copy of the source.
+    info (a dict, optional) receives {kernel name: (VGPRs, spilled VGPRs)} of the preprocess_bwd instantiations and "obj"."""
     from ex4dgs_amd import build
     build.build()
     os.makedirs(dst, exist_ok=True)
@@ -34,6 +35,8 @@ def build_variant(dst, patch):
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?VGPRs Spill: (\d+)", r.stderr, re.S):
         if "preprocess_bwd" in m.group(1):
             print("variant", m.group(1)[:60], "VGPRs", m.group(2), "spilled", m.group(3), flush=True)
+            if info is not None: info[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    if info is not None: info["obj"] = obj
     objs = [obj] + [os.path.join(CSRC, f.replace(".hip", ".o")) for f in build.SOURCES if f != "ex4d_preprocess.hip"]
     lib = os.path.join(dst, "libex4d_hip_variant.so")
     subprocess.check_call([build._hipcc(), "-shared", "-fPIC", f"--offload-arch={build.ARCH}", "-o", lib] + objs)
