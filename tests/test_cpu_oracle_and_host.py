@@ -620,6 +620,44 @@ __global__ __launch_bounds__(256, 4) void k(unsigned long long *out, unsigned lo
         assert build.shift_amount_in_last_vgpr(os.path.join(build.CSRC, f.replace(".hip", ".o"))) == [], f
 
 
+def test_wait_state_check_of_the_machine_code(tmp_path):
+    """ex4dgs_amd.isa_check.wait_state_violations: the software wait states that matter to the library's inline assembly (a DPP read
+    2 states behind a VALU write, a transcendental result 1 state, a VALU-written SGPR read as a constant 2 states) are checked on the
+    disassembly of every object.  A kernel that breaks each rule inside asm strings is reported rule by rule, the same kernel with the
+    pads in place is clean, and the library's own objects -- some 3 000 DPP instructions and the hand-scheduled forward walk among
+    them -- have no finding."""
+    import subprocess
+    from ex4dgs_amd import build, isa_check
+    src = """#include <hip/hip_runtime.h>
+__global__ void k(float *out, const float *in, unsigned *mask)
+{
+    float x = in[threadIdx.x], y, z;
+    unsigned long long m, w;
+    asm volatile("v_mov_b32 %0, %1\\n\\tPAD1v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "=&v"(y) : "v"(x));
+    asm volatile("v_exp_f32 %0, %1\\n\\tPAD0v_add_f32 %0, %0, %0" : "=&v"(z) : "v"(x));
+    asm volatile("v_cmp_gt_f32 %0, %2, %3\\n\\tPAD1v_lshlrev_b64 %1, 1, %0" : "=&s"(m), "=&v"(w) : "v"(x), "v"(y) : "vcc");
+    out[threadIdx.x] = y + z;
+    mask[threadIdx.x] = (unsigned)w;
+}
+"""
+    rules = {}
+    for name, pad1, pad0 in (("bad", "", ""), ("good", "s_nop 1\\n\\t", "s_nop 0\\n\\t")):
+        hip, obj = tmp_path / f"w_{name}.hip", tmp_path / f"w_{name}.o"
+        hip.write_text(src.replace("PAD1", pad1).replace("PAD0", pad0))
+        subprocess.check_call([build._hipcc(), "-O3", f"--offload-arch={build.ARCH}", "-c", str(hip), "-o", str(obj)])
+        rules[name] = sorted(r for _, r, _, _ in isa_check.wait_state_violations(str(obj)))
+    assert rules["good"] == [], rules["good"]
+    assert len(rules["bad"]) == 3 and "DPP" in rules["bad"][0] and "SGPR" in rules["bad"][1] and "transcendental" in rules["bad"][2], rules["bad"]
+    build.build()
+    seen = dict(dpp=0, trans=0, valu_sgpr_writes=0, instructions=0)
+    for f in build.SOURCES:
+        obj = os.path.join(build.CSRC, f.replace(".hip", ".o"))
+        assert isa_check.wait_state_violations(obj) == [], f
+        for k, v in isa_check.coverage(obj).items():
+            seen[k] += v
+    assert seen["dpp"] > 2000 and seen["trans"] > 200 and seen["valu_sgpr_writes"] > 1000 and seen["instructions"] > 50000, seen
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
