@@ -7,8 +7,8 @@ Two kinds of rule the compiler does not enforce for us:
   allocation shifts by VGPR0 instead in waves that share their SIMD.  The register allocator hands that register out like any other.
 * `wait_state_violations` -- the software-managed wait states of gfx940-class hardware that matter to this library's INLINE ASSEMBLY
   (the compiler pads its own instructions, but it neither looks inside an asm string nor re-checks the boundary when its scheduling
-  around an asm block changes with a toolchain): a DPP instruction reading a VGPR a VALU instruction wrote fewer than 2 wait states
-  earlier; a VALU instruction reading the result of a transcendental instruction in the very next slot; a VALU instruction reading,
+  around an asm block changes with a toolchain): a DPP instruction (or v_permlane16/32_swap) reading a VGPR a VALU instruction wrote fewer than
+  2 wait states earlier; a VALU instruction reading the result of a transcendental instruction in the very next slot; a VALU instruction reading,
   as a CONSTANT (not as the lane mask of a select / carry), an SGPR / VCC that a VALU instruction wrote fewer than 2 wait states earlier;
   v_readlane / v_writelane with a lane select, or v_div_fmas with a VCC, written by VALU < 4 states earlier.  (Rules as LLVM's GCNHazardRecognizer states them for gfx940; the second and
   third were hit on hardware while the hand-scheduled forward walk was written.)  One wait state = one issued instruction of the wave;
@@ -182,6 +182,7 @@ def run_violations(run):
         if not c["valu"]:
             continue
         div_fmas = c["mnemonic"].startswith("v_div_fmas")
+        swap = c["mnemonic"].startswith(("v_permlane16_swap", "v_permlane32_swap"))         # (both operands are read and written)
         states, j, rewritten = 0, i - 1, set()
         while j >= 0 and states < 4:
             p = dec[j]
@@ -190,6 +191,8 @@ def run_violations(run):
                 sg = {r for r in p["dsts"] if r[0] == "s" or r in ("vcc", "exec")} - rewritten
                 if c["dpp"] and states < 2 and (vg & c["src0"]):
                     out.append((i, "VALU write -> DPP read needs 2 wait states", run[i], run[j]))
+                if swap and states < 2 and (vg & (c["srcs"] | c["dsts"])):
+                    out.append((i, "VALU write -> v_permlane16/32_swap operand needs 2 wait states", run[i], run[j]))
                 if p["trans"] and not c["trans"] and states < 1 and (vg & c["srcs"]):
                     out.append((i, "transcendental result -> VALU read needs 1 wait state", run[i], run[j]))
                 if states < 2 and (sg & {r for r in c["srcs"] if r[0] == "s" or r == "vcc"}):
