@@ -230,6 +230,11 @@ def main():
     src = open(os.path.join(CSRC, "ex4d_preprocess.hip")).read()
     a = "template <bool DSUMS>\n__global__ __launch_bounds__(256) void preprocess_bwd_kernel("
     assert a in src
+    # the build under study: 128 registers AND the visibility predicate the sources held until round 4 (`(need >> g) & 1`: the 64-bit shift
+    # whose amount the allocator puts into v127; the sources now take the bit from 32-bit halves, mask_bit, and the fault is gone)
+    old_pred, new_pred = "(((need >> g) & 1ull) != 0ull)", "mask_bit(need, g)"
+    assert src.count(new_pred) == 2
+    src = src.replace(new_pred, old_pred)
     src = src.replace(a, a.replace("(256)", "(256, 4)")).replace('#include "ex4d_internal.h"', f'#include "{CSRC}/ex4d_internal.h"')
     hip = os.path.join(tmp, "pre.hip")
     open(hip, "w").write(src)
