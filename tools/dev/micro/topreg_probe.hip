@@ -1,9 +1,17 @@
-// Developer probe (part 3): tools/dev/spill_asm_variants.py traced the wrong gradients of the spilling
-// preprocess_bwd build to the wave's two HIGHEST vector registers (v126 / v127 of a 128-register kernel): values written there and read
-// back by the next instructions were wrong in waves that share their SIMD with an earlier wave; other registers, or a 136-register
-// allocation, and the fault is gone.  This stand-alone kernel repeats that window -- a 16-byte load in flight, v126 / v127 written, read
-// by compares, a multiply-add, a 64-bit shift (as its shift amount) and plain moves -- in a kernel of the same shape (256 threads, 4 waves per SIMD = 128 registers, 26 KB of
-// LDS, optionally 16 bytes of scratch per lane) and counts what comes back wrong.
+// Developer probe (part 3) -- stand-alone reproducer of a gfx950 operand fault.
+// tools/dev/spill_asm_variants.py traced the wrong gradients of the 128-register preprocess_bwd build to ONE instruction,
+// `v_lshrrev_b64 v[22:23], v127, s[4:5]`: a 64-bit shift whose 32-bit shift amount sits in the LAST vector register of the wave's
+// allocation.  This program shows it without the rest of that kernel (256 threads, __launch_bounds__(256, 4) = 128 registers, 26 KB of
+// LDS, with and without scratch):
+//   probe       the window of the original kernel (a 16-byte load in flight, v126 / v127 written, read by compares, a multiply-add,
+//               plain moves AND the 64-bit shift): only the shift is ever wrong -- it shifts by `threadIdx.x & 63`, i.e. by VGPR0 (what
+//               the ISA prescribes for an out-of-range source) -- never in blocks < 256 (the first wave of a SIMD), never with the same
+//               amount in v125, never when the kernel allocates 136 registers;
+//   ops_probe   sixteen instructions with a 32-bit operand in v127 against the same operand in v125: v_lshlrev_b64, v_lshrrev_b64 and
+//               v_ashrrev_i64 differ, v_mad_u64_u32 / v_mad_i64_i32 / v_ldexp_f64 / v_cvt_f64_* / v_trig_preop_f64 / 32-bit ops never;
+//   base_probe  per wave: HW_REG_GPR_ALLOC.VGPR_BASE and whether any of its shifts was wrong -- with four waves per SIMD every wave at
+//               base 48 (registers 384..511, the top of the file) is wrong, the others sometimes.
+// Output of the round-4 run: profiles/r04_topreg_probe.txt.  ex4dgs_amd/isa_check.py refuses objects that hold such an instruction.
 //      hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage topreg_probe.hip -o topreg_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
