@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--async-frames", action="store_true", help="N = 1 rasterizer steps with the ASYNCHRONOUS forward (no instance-count read-back: Ex4dParams.instance_capacity)")
     ap.add_argument("--graph", action="store_true", help="N = 1: forward + backward (asynchronous forward, raw C-ABI mirror calls) captured into ONE hipGraph and replayed per step")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="tuning / A-B runs: any library option of ex4d_set_option, e.g. --set depth_sort_msd=0 (the 3-pass LSD depth sort)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -371,6 +372,9 @@ def main():
         _C.set_option("composite_fwd_asm", args.fwd_asm)
     if args.bwd_variant is not None:
         _C.set_option("composite_bwd_variant", args.bwd_variant)
+    for kv in args.set:
+        name, _, value = kv.partition("=")
+        _C.set_option(name, int(value))
 
     cfg = CONFIGS[args.config]
     train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only

@@ -16,6 +16,8 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 std::atomic<int> g_bwd_variant{4};
 std::atomic<int> g_tile_ids{0};
+std::atomic<int> g_depth_msd{1};     // "depth_sort_msd": MSD-first depth sort with the buckets finished in LDS (default) or the 3-pass LSD sort (0)
+std::atomic<int> g_depth_local_cap{0};      // "depth_sort_local_cap": largest bucket the MSD depth sort finishes in LDS (0 = the kernel's capacity; tests force the through-memory path with a small value)
 std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
 thread_local char g_err[512] = "";
 
@@ -136,6 +138,9 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_keys_a = c.take<uint32_t>(P);
     g.sort_keys_b = c.take<uint32_t>(P);
     g.sort_vals_b = c.take<uint32_t>(P);
+    g.sort_vals_a = c.take<uint32_t>(P);
+    g.rects4_b = c.take<uint32_t>(P);
+    g.bucket_starts = c.take<uint32_t>((size_t)1 << EX4D_DLS_MSD_BITS);
     g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
     g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-chunk instance counts
@@ -263,12 +268,26 @@ static int forward_impl(
         key_bits = 1;
         while (key_bits < 32 && (key_invisible >> key_bits) != 0u) key_bits++;
     }
-    // the sort ping-pongs between the (a) and (b) pairs and has to end in (a) = depth_order: start in (b) for an odd pass count
+    const bool packed_rects = gx <= 255 && gy <= 255;       // the tile scan gathers 32-bit packed rects (L2-resident) instead of the 8-byte ones
+    // MSD-first depth sort (round 5; ex4d_binning.hip: depth_local_sort_kernel): applies when the rects travel packed and the key bits
+    // under the top digit fit its LDS word.  The invisible Gaussians get a key whose top digit is theirs alone -- one past the digit of
+    // the largest visible key (still behind every visible key: the order is the same)
+    bool msd_depth = g_depth_msd.load(std::memory_order_relaxed) != 0 && packed_rects && key_bits < 32;
+    uint32_t inv_digit = 0;
+    if (msd_depth) {
+        const uint32_t span = key_invisible - 1u;          // the largest visible key
+        int kb = key_bits, rem = ex4d_depth_sort_msd_rem(kb);
+        inv_digit = (span >> rem) + 1u;
+        if (inv_digit >= (1u << EX4D_DLS_MSD_BITS)) { kb++; rem = ex4d_depth_sort_msd_rem(kb); inv_digit = (span >> rem) + 1u; }
+        if (kb < 32 && ex4d_depth_sort_msd_applies((uint32_t)P, kb)) { key_bits = kb; key_invisible = inv_digit << rem; }
+        else msd_depth = false;
+    }
+    // the LSD sort ping-pongs between the (a) and (b) pairs and has to end in (a) = depth_order: start in (b) for an odd pass count
     const bool start_in_b = (ex4d_radix_passes((uint32_t)P, key_bits) & 1) != 0;
     uint32_t *keys0 = start_in_b ? g.sort_keys_b : g.sort_keys_a, *vals0 = start_in_b ? g.sort_vals_b : g.depth_order;
     uint32_t *keys1 = start_in_b ? g.sort_keys_a : g.sort_keys_b, *vals1 = start_in_b ? g.depth_order : g.sort_vals_b;
+    if (msd_depth) { keys0 = g.sort_keys_a; vals0 = g.sort_vals_a; }      // partition: (keys_a, vals_a, rects4) -> (keys_b, depth_order, rects4_b)
 
-    const bool packed_rects = gx <= 255 && gy <= 255;       // the tile scan gathers 32-bit packed rects (L2-resident) instead of the 8-byte ones
     g_prof.begin(0, stream);
     HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));        // the frame flags / Ex4dFrameStatus words
     // 1. per-Gaussian preprocess
@@ -289,13 +308,24 @@ static int forward_impl(
         HIP_TRY(hipEventRecord(g_readback.ev, stream));
     }
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
-    bool in_first = true;
-    STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream), prm, stream);
-    if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
-    MARK(0, "depth_sort");
-    // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)
-    STAGE(ex4d_launch_scan_tiles(P, g.rects, packed_rects ? g.rects4 : nullptr, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
-    MARK(0, "scan_tiles");
+    if (msd_depth) {
+        STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_bits, inv_digit,
+                                  g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream), prm, stream);
+        MARK(0, "depth_sort");
+        // 3. instance offsets in depth order + total: the rects arrive in depth order (rects4_b), nothing to gather
+        STAGE(ex4d_launch_scan_tiles(P, nullptr, g.rects4_b, nullptr, nullptr, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
+        MARK(0, "scan_tiles");
+    } else {
+        bool in_first = true;
+        STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream), prm, stream);
+        if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
+        MARK(0, "depth_sort");
+        // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)
+        STAGE(ex4d_launch_scan_tiles(P, g.rects, packed_rects ? g.rects4 : nullptr, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
+        MARK(0, "scan_tiles");
+    }
+    const uint2 *dup_rects = msd_depth ? nullptr : g.sorted_rects;
+    const uint32_t *dup_rects4 = msd_depth ? g.rects4_b : nullptr;
     uint32_t R = 0;                      // instance count (synchronous) or capacity (asynchronous): sizes the binning buffer and the grids
     const uint32_t *n_dev = nullptr;     // asynchronous: the kernels read the actual count here
     bool has_flow;
@@ -332,7 +362,7 @@ static int forward_impl(
     if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
         // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
-        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, b.tile_ids, b.vals_tmp, R, stream), prm, stream);
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, b.tile_ids, b.vals_tmp, R, stream), prm, stream);
         MARK(0, "duplicate");
         STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
                                  R, tile_bits(T), b.sort_hist, im.ranges, stream, n_dev), prm, stream);
@@ -340,7 +370,7 @@ static int forward_impl(
         MARK(0, "tile_ranges");
     } else {
         if (R > 0) {
-            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, g.sorted_rects, k0, v0, R, stream), prm, stream);
+            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, k0, v0, R, stream), prm, stream);
             MARK(0, "duplicate");
             bool res_a = true;
             STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream, n_dev), prm, stream);
@@ -493,6 +523,8 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "depth_sort_msd") && (value == 0 || value == 1)) { g_depth_msd.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "depth_sort_local_cap") && value >= 0 && value <= 8192) { g_depth_local_cap.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }
 
@@ -506,6 +538,8 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "preprocess_sh_predicate")) return ex4d_get_preprocess_tune();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
+    if (name && !strcmp(name, "depth_sort_msd")) return g_depth_msd.load();
+    if (name && !strcmp(name, "depth_sort_local_cap")) return g_depth_local_cap.load();
     return -1;
 }
 

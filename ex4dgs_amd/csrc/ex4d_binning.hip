@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
 // MODE 1: pairs in, ONE packed word out: (key & low_mask) << (32 - low_bits) | value  (pass A of the tile sort, below).
 // MODE 2: packed words in (digit = word >> shift), values out; the workgroup's item range and bucket come from the block table, its
 //         global digit starts from the bucket's span of the row-scanned histogram; also writes the tile ranges (pass B).
+// MODE 3: (key, value, packed rect) triples in, triples out, and workgroup 0 leaves the first output position of every digit in
+//         `bucket_starts` (the MSD partition of the depth sort, below: depth_local_sort_kernel finishes every bucket in LDS).
 // Pass B of the tile sort cuts every bucket (= high digit) into blocks of <= 4096 items, so that no block straddles two buckets.
 // Every workgroup derives its own block from the <= 256 bucket totals of pass A (two scans + a 8-step search: cheaper than a
 // one-workgroup table kernel and its launch in the middle of the sort):
@@ -164,7 +166,8 @@ template <int ITEMS, int BINS, int MODE, int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
-    int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges, const uint32_t *__restrict__ n_dev)
+    int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges, const uint32_t *__restrict__ n_dev,
+    const uint32_t *__restrict__ rects_in = nullptr, uint32_t *__restrict__ rects_out = nullptr, uint32_t *__restrict__ bucket_starts = nullptr)
 {
     if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }      // (see rs_histogram_kernel)
     if (MODE != 2 && blockIdx.x * (uint32_t)(RS_THREADS * ITEMS) >= n) return;      // behind the last item (uniform: the whole workgroup)
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __shared__ uint32_t global_base[BINS];        // global position of this block's first item of each digit
     __shared__ uint32_t scan_tmp[8];
     __shared__ uint2 stage[RS_THREADS * ITEMS];             // (key, value) in block-local sorted order
+    __shared__ uint32_t stage_r[MODE == 3 ? RS_THREADS * ITEMS : 1];      // MODE 3: the third word of the triple
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (NBITS > 0) nbits = NBITS;
     const uint32_t mask = (1u << nbits) - 1u;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     }
     const uint32_t base = block_first + wave * (CHUNK / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
+    uint32_t key[ITEMS], val[ITEMS], pos[ITEMS], rct[MODE == 3 ? ITEMS : 1];
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         // unconditional loads from a clamped index (no exec-masked branch per item): the waits before the first ranking steps
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         const uint32_t ic = i < block_end ? i : block_end - 1;
         key[it] = keys_in[ic];
         val[it] = (MODE == 2) ? 0u : vals_in[ic];
+        if constexpr (MODE == 3) rct[it] = rects_in[ic];
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
                 global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x] - pf[k];
                 // tile (bucket, d) occupies [gb, gb + gtot): identifyTileRanges (CR/rasterizer_impl.cu:118-140) without reading the keys
                 if (MODE == 2 && blockIdx.x == tb.fb_first && gtot[k] != 0u) ranges[((size_t)bucket << nbits) + d] = make_uint2(gb, gb + gtot[k]);
+                if (MODE == 3 && blockIdx.x == 0) bucket_starts[d] = gb;            // first output position of digit d
                 wave_cnt[0][d] = ls; wave_cnt[1][d] = ls + c[k][0]; wave_cnt[2][d] = ls + c[k][0] + c[k][1]; wave_cnt[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
             }
             ls += tot[k]; gb += gtot[k];
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         if (i < block_end) {
             const uint32_t d = (key[it] >> shift) & mask;
             stage[wave_cnt[wave][d] + pos[it]] = make_uint2(key[it], val[it]);
+            if constexpr (MODE == 3) stage_r[wave_cnt[wave][d] + pos[it]] = rct[it];
         }
     }
     __syncthreads();
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         const uint32_t d = (kv.x >> shift) & mask;
         const uint32_t dst = global_base[d] + (p - local_start[d]);
         if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; }
+        if constexpr (MODE == 3) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; rects_out[dst] = stage_r[p]; }
         if (MODE == 1) keys_out[dst] = ((kv.x & ((1u << low_bits) - 1u)) << (32 - low_bits)) | kv.y;
         if (MODE == 2) {
             vals_out[dst] = kv.x & (0xFFFFFFFFu >> nbits);
@@ -355,6 +363,189 @@ __global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t
 }
 
 
+// ---------------------------------------------------------------- depth sort, MSD first: every bucket finished in LDS
+// Round 5.  The LSD depth sort was nine launches (3 x histogram / row scan / scatter) of 5-13 us each, bound by launch ramp and
+// latency, not by its 8 MB.  Now: ONE global partition of the P (key, id, packed rect) triples by the TOP DLS_MSD_BITS bits of the
+// depth key (histogram -> row scan -> scatter, MODE 3 above; stable, so equal keys keep ascending ids) -- a bucket then holds
+// ~1.5 k Gaussians at 1.0 M -- and ONE kernel in which a workgroup per bucket sorts its bucket on the remaining `rem` key bits
+// entirely in LDS and permutes (id, rect) IN PLACE: the depth order and the rects in depth order (which the tile scan used to
+// gather at random: 52 MB of traffic for a 4 MB array) fall out of the same kernel.  4 launches instead of 9 + a streaming scan.
+//   * LDS word = (key & remmask) << 13 | arrival index: sorting the words by their key bits with a STABLE LSD radix sort (9-bit digits,
+//     wave-private ballot ranking like the scatter kernel) is the stable sort by key; the payload is fetched once at the end through the
+//     arrival index (a gather inside the bucket's own 8-32 KB window).
+//   * invisible Gaussians carry a key whose top digit is theirs alone (host: one past the digit of max_depth): the partition
+//     leaves them in id order behind every visible bucket with their zero rect; nobody touches that bucket again.
+//   * a bucket with more than `cap` (<= DLS_CAP = 8192) Gaussians -- a scene squeezed into < 1 % of [min_depth, max_depth] -- is sorted
+//     by its workgroup through global memory (ping-pong with the partition's input arrays, whose slice [start, start + n) nobody
+//     else uses): correct for any size, slow by design (tests force it with a small `cap`).
+#define DLS_THREADS 512
+#define DLS_WAVES 8
+#define DLS_ITEMS 16
+#define DLS_CAP (DLS_THREADS * DLS_ITEMS)
+#define DLS_IDX_BITS 13
+static_assert((1 << DLS_IDX_BITS) == DLS_CAP, "arrival index bits");
+struct DlsLds { uint32_t buf[DLS_CAP]; uint32_t cnt[DLS_WAVES][512]; uint32_t scan_tmp[DLS_WAVES]; };
+
+__device__ __forceinline__ void dls_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// lanes of the wave that hold the same digit as this lane (among the valid ones); invalid lanes get 0
+__device__ __forceinline__ uint64_t dls_peers(uint32_t d, int nbits, bool valid)
+{
+    const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+    uint32_t plo = (uint32_t)vmask, phi = (uint32_t)(vmask >> 32);
+    for (int b = 0; b < nbits; b++) {
+        const uint32_t bit = (d >> b) & 1u;
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
+        const uint32_t flip = bit - 1u;                   // 0 when my bit is set, ~0 otherwise
+        plo &= (uint32_t)bal ^ flip;
+        phi &= (uint32_t)(bal >> 32) ^ flip;
+    }
+    const uint64_t peers = ((uint64_t)phi << 32) | plo;
+    return valid ? peers : 0ull;
+}
+// stable rank of this lane's item among the wave's items processed so far: returns the index among the wave's items of digit d
+// (wave-private counter row `cnt`), and bumps the counter.  All 64 lanes call it.
+__device__ __forceinline__ uint32_t dls_rank(uint32_t *cnt, uint32_t d, int nbits, bool valid, int lane)
+{
+    const uint64_t peers = dls_peers(d, nbits, valid);
+    const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)peers) - 1;
+    uint32_t before = 0;
+    if (valid && rank == 0) {                     // one lane per distinct digit
+        before = cnt[d];
+        cnt[d] = before + (uint32_t)__popcll(peers);
+    }
+    before = __shfl(before, leader < 0 ? 0 : leader, 64);
+    dls_wave_sync();
+    return before + rank;
+}
+// cnt[w][d] (counts of digit d among wave w's items) -> first destination slot of (d, w): exclusive scan over (digit, wave)
+__device__ __forceinline__ void dls_scan_counts(DlsLds &L, int nbits)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // 512 threads = 512 digits
+    const bool live = tid < (1 << nbits);
+    uint32_t c[DLS_WAVES], tot = 0;
+#pragma unroll
+    for (int w = 0; w < DLS_WAVES; w++) { c[w] = live ? L.cnt[w][tid] : 0u; tot += c[w]; }
+    uint32_t x = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) L.scan_tmp[wave] = x;
+    __syncthreads();
+    uint32_t run = x - tot;
+    for (int w = 0; w < wave; w++) run += L.scan_tmp[w];
+    if (live) {
+#pragma unroll
+        for (int w = 0; w < DLS_WAVES; w++) { L.cnt[w][tid] = run; run += c[w]; }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ int dls_pass_bits(int rem, int lo, int npass, int pass) { return (rem - lo + (npass - pass) - 1) / (npass - pass); }
+
+// n > cap: the workgroup sorts the bucket's (key, id, rect) triples through global memory; X = the partition's output slice (where the
+// result has to end), Y = the same slice of the partition's input arrays
+__device__ __forceinline__ void dls_sort_through_memory(DlsLds &L, uint32_t *xk, uint32_t *xv, uint32_t *xr, uint32_t *yk, uint32_t *yv, uint32_t *yr,
+    uint32_t n, int rem)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int npass = (rem + 8) / 9;
+    const uint32_t m = ((n + DLS_WAVES * 64 - 1) / (DLS_WAVES * 64)) * 64;          // items per wave (a multiple of 64)
+    const uint32_t wbase = wave * m < n ? wave * m : n, wend = (wbase + m) < n ? (wbase + m) : n;
+    uint32_t *sk = xk, *sv = xv, *sr = xr, *dk = yk, *dv = yv, *dr = yr;
+    for (int pass = 0, lo = 0; pass < npass; pass++) {
+        const int nbits = dls_pass_bits(rem, lo, npass, pass);
+        const uint32_t mask = (1u << nbits) - 1u;
+        for (int i = lane; i < 512; i += 64) L.cnt[wave][i] = 0;
+        dls_wave_sync();
+        for (uint32_t i = wbase + lane; i < wend; i += 64) atomicAdd(&L.cnt[wave][(sk[i] >> lo) & mask], 1u);
+        __syncthreads();
+        dls_scan_counts(L, nbits);
+        for (uint32_t base = wbase; base < wend; base += 64) {        // wave-uniform trip count, items in order
+            const uint32_t i = base + lane;
+            const bool valid = i < wend;
+            const uint32_t k = valid ? sk[i] : 0u, v = valid ? sv[i] : 0u, r = valid ? sr[i] : 0u;
+            const uint32_t d = (k >> lo) & mask;
+            const uint32_t dst = dls_rank(L.cnt[wave], d, nbits, valid, lane);
+            if (valid) { dk[dst] = k; dv[dst] = v; dr[dst] = r; }
+        }
+        __threadfence();
+        __syncthreads();
+        uint32_t *t;
+        t = sk; sk = dk; dk = t; t = sv; sv = dv; dv = t; t = sr; sr = dr; dr = t;
+        lo += nbits;
+    }
+    if (sv != xv) {                 // odd number of passes: the result sits in Y
+        for (uint32_t i = tid; i < n; i += DLS_THREADS) { xv[i] = sv[i]; xr[i] = sr[i]; }
+    }
+}
+
+__global__ __launch_bounds__(DLS_THREADS) void depth_local_sort_kernel(uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t *ka, uint32_t *va, uint32_t *ra,
+    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ totals, int rem, uint32_t inv_digit, uint32_t cap)
+{
+    __shared__ DlsLds L;
+    const uint32_t b = blockIdx.x;
+    if (b == inv_digit) return;                          // invisible Gaussians: already in id order, rect 0
+    const uint32_t n = totals[b];
+    if (n < 2u || rem == 0) return;                      // nothing to order (rem == 0: all keys of a bucket are equal, the partition was stable)
+    const uint32_t s = starts[b];
+    if (n > cap) { dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem); return; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t remmask = (1u << rem) - 1u;
+    for (uint32_t i = tid; i < n; i += DLS_THREADS) L.buf[i] = ((kb[s + i] & remmask) << DLS_IDX_BITS) | i;
+    __syncthreads();
+    const int npass = (rem + 8) / 9;
+    const uint32_t m = ((n + DLS_WAVES * 64 - 1) / (DLS_WAVES * 64)) * 64;          // items per wave: a multiple of 64, <= 1024
+    const uint32_t wbase = wave * m;
+    for (int pass = 0, lo = 0; pass < npass; pass++) {
+        const int nbits = dls_pass_bits(rem, lo, npass, pass);
+        const uint32_t mask = (1u << nbits) - 1u;
+        const int sh = DLS_IDX_BITS + lo;
+        for (int i = lane; i < 512; i += 64) L.cnt[wave][i] = 0;
+        dls_wave_sync();
+        uint32_t word[DLS_ITEMS], pos[DLS_ITEMS];
+#pragma unroll
+        for (int it = 0; it < DLS_ITEMS; it++) {
+            word[it] = 0u; pos[it] = 0u;
+            if ((uint32_t)(it * 64) < m) {                    // (wave-uniform)
+                const uint32_t i = wbase + it * 64 + lane;
+                const bool valid = i < n;
+                word[it] = valid ? L.buf[i] : 0u;
+                pos[it] = dls_rank(L.cnt[wave], (word[it] >> sh) & mask, nbits, valid, lane);
+            }
+        }
+        __syncthreads();                   // every word is in a register, every count final
+        dls_scan_counts(L, nbits);
+#pragma unroll
+        for (int it = 0; it < DLS_ITEMS; it++) {
+            if ((uint32_t)(it * 64) < m) {
+                const uint32_t i = wbase + it * 64 + lane;
+                if (i < n) L.buf[L.cnt[wave][(word[it] >> sh) & mask] + pos[it]] = word[it];
+            }
+        }
+        __syncthreads();
+        lo += nbits;
+    }
+    // payload: position p takes the (id, rect) that arrived at index idx(p).  In place: every load lands before any store goes out
+    uint32_t v[DLS_ITEMS], r[DLS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DLS_ITEMS; j++) {
+        const uint32_t p = tid + j * DLS_THREADS;
+        v[j] = 0u; r[j] = 0u;
+        if (p < n) { const uint32_t idx = L.buf[p] & (DLS_CAP - 1u); v[j] = vb[s + idx]; r[j] = rb[s + idx]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DLS_ITEMS; j++) {
+        const uint32_t p = tid + j * DLS_THREADS;
+        if (p < n) { vb[s + p] = v[j]; rb[s + p] = r[j]; }
+    }
+}
+
 // ---------------------------------------------------------------- scan of tiles_touched in depth order
 // rects4 (optional): the same rects packed into 32 bits (x0 | y0 << 8 | w << 16 | h << 24; images of at most 255 x 255 tiles).  The
 // gather in depth order is random: from the 8-byte array every read pulls a whole cache line of an 8 MB array that no L2 holds (round 3:
@@ -379,7 +570,8 @@ __global__ __launch_bounds__(256) void scan_tiles_local_kernel(int P, const uint
         // the only random gather of the binning stage: the rect of the i-th Gaussian in depth order (8 bytes), written
         // back in that order so that the duplication kernel streams it
         uint2 rc = make_uint2(0u, 0u);
-        if (i < P) { rc = rects4 ? unpack_rect(rects4[order[i]]) : rects[order[i]]; sorted_rects[i] = rc; }
+        // (order == nullptr: rects4 already IS in depth order -- the MSD depth sort carried it along -- and is streamed; nothing is written back)
+        if (i < P) { rc = rects4 ? unpack_rect(rects4[order ? order[i] : (uint32_t)i]) : rects[order[i]]; if (sorted_rects) sorted_rects[i] = rc; }
         cnt[it * 256 + threadIdx.x] = (rc.y & 0xFFFFu) * (rc.y >> 16);
     }
     __syncthreads();
@@ -441,7 +633,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_max_u32(uint32_t x)
 struct DupRec { uint32_t off, gid, xy, w, magic; };
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
-    const uint2 *__restrict__ sorted_rects,
+    const uint2 *__restrict__ sorted_rects, const uint32_t *__restrict__ sorted_rects4,
     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals, uint32_t cap)
 {
     // cap: capacity of the output arrays -- the instance count itself (synchronous forward) or Ex4dParams.instance_capacity (an
@@ -456,7 +648,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
         gid = order[k];
         // exclusive offset = inclusive scan value of the previous element (+ its scan chunk's base, below)
         off = (k == 0) ? 0u : sorted_offsets[k - 1];
-        const uint2 rc = sorted_rects[k];                 // getRect (CR/auxiliary.h:46-56) was evaluated once, by the preprocess kernel
+        const uint2 rc = sorted_rects4 ? unpack_rect(sorted_rects4[k]) : sorted_rects[k];      // getRect (CR/auxiliary.h:46-56) was evaluated once, by the preprocess kernel
         x0 = (int)(rc.x & 0xFFFFu); y0 = (int)(rc.x >> 16);
         w = (int)(rc.y & 0xFFFFu);
         count = (uint32_t)w * (rc.y >> 16);
@@ -544,7 +736,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint
 static inline int rs_items_for(uint32_t n) { return n <= (2u << 20) ? RS_SMALL_ITEMS : RS_ITEMS; }
 static inline uint32_t rs_blocks_for(uint32_t n) { const uint32_t c = RS_THREADS * rs_items_for(n); return (n + c - 1) / c; }
 static inline int rs_max_bits_for(uint32_t n) { return rs_items_for(n) == RS_SMALL_ITEMS ? 9 : 8; }
-size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)512 * rs_blocks_for(n) + 512; }
+size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)1024 * rs_blocks_for(n) + 1024; }      // (1024: the MSD depth sort's bins)
 int ex4d_radix_passes(uint32_t n, int end_bit) { const int mb = rs_max_bits_for(n); return (end_bit + mb - 1) / mb; }
 
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
@@ -576,6 +768,36 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         *result_in_a = !*result_in_a;
         shift += nbits;
     }
+    return hipGetLastError();
+}
+
+// ---- MSD depth sort (depth_local_sort_kernel above): histogram / row scan / partition on the top DLS_MSD_BITS key bits, buckets in LDS.
+// (ka, va, ra): keys / ids / packed rects as the preprocess kernel wrote them (scratch afterwards); (kb, vb, rb): the result --
+// vb = Gaussian ids in depth order, rb = their packed rects in that order.  key_bits: significant bits of the keys; the invisible key
+// is inv_digit << (key_bits - DLS_MSD_BITS).  hist: ex4d_radix_hist_words(n) words; starts: 1 << DLS_MSD_BITS words.
+int ex4d_depth_sort_msd_rem(int key_bits) { return key_bits > EX4D_DLS_MSD_BITS ? key_bits - EX4D_DLS_MSD_BITS : 0; }
+bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits) { return n <= (1u << 26) && ex4d_depth_sort_msd_rem(key_bits) + DLS_IDX_BITS <= 32; }
+hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, int key_bits,
+    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    constexpr int MB = EX4D_DLS_MSD_BITS, BINS = 1 << MB;
+    const int rem = ex4d_depth_sort_msd_rem(key_bits);
+    const uint32_t nb = rs_blocks_for(n);
+    const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
+    if (local_cap == 0 || local_cap > DLS_CAP) local_cap = DLS_CAP;
+    if (small) {
+        hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, BINS, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, rem, (uint32_t)(BINS - 1), nb, hist, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
+        hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, rem, MB, nb, hist,
+            0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts);
+    } else {
+        hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, BINS, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, rem, (uint32_t)(BINS - 1), nb, hist, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
+        hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, rem, MB, nb, hist,
+            0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts);
+    }
+    hipLaunchKernelGGL(depth_local_sort_kernel, dim3(BINS), dim3(DLS_THREADS), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, rem, inv_digit, local_cap);
     return hipGetLastError();
 }
 
@@ -625,11 +847,11 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rec
 }
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const uint2 *sorted_rects, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream)
+    const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        sorted_rects, tile_keys, vals, cap);
+        sorted_rects, sorted_rects4, tile_keys, vals, cap);
     return hipGetLastError();
 }
 
