@@ -16,8 +16,9 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 std::atomic<int> g_bwd_variant{4};
 std::atomic<int> g_tile_ids{0};
-std::atomic<int> g_depth_msd{1};     // "depth_sort_msd": MSD-first depth sort with the buckets finished in LDS (default) or the 3-pass LSD sort (0)
+std::atomic<int> g_depth_msd{2};     // "depth_sort_msd": MSD-first depth sort with the buckets finished in LDS (default) or the 3-pass LSD sort (0)
 std::atomic<int> g_depth_local_cap{0};      // "depth_sort_local_cap": largest bucket the MSD depth sort finishes in LDS (0 = the kernel's capacity; tests force the through-memory path with a small value)
+std::atomic<int> g_depth_local_threads{0};  // "depth_sort_local_threads": 256 / 512 = workgroup size of the depth sort's bucket kernel, 0 = by Gaussian count
 std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
 thread_local char g_err[512] = "";
 
@@ -141,6 +142,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_vals_a = c.take<uint32_t>(P);
     g.rects4_b = c.take<uint32_t>(P);
     g.bucket_starts = c.take<uint32_t>((size_t)1 << EX4D_DLS_MSD_BITS);
+    g.bucket_sums = c.take<uint32_t>((size_t)1 << EX4D_DLS_MSD_BITS);
     g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
     g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-chunk instance counts
@@ -308,12 +310,18 @@ static int forward_impl(
         HIP_TRY(hipEventRecord(g_readback.ev, stream));
     }
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
+    // depth_sort_msd == 2 (default): the tile scan is fused into the bucket kernel of the depth sort (bucket-local inclusive scans +
+    // bucket sums; duplicate_kernel adds the bucket bases): no scan kernel at all.  1: the streaming scan kernel.
+    const bool fused_scan = msd_depth && g_depth_msd.load(std::memory_order_relaxed) == 2;
     if (msd_depth) {
         STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_bits, inv_digit,
-                                  g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream), prm, stream);
+                                  g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
+                                  fused_scan ? g.sorted_offsets : nullptr, fused_scan ? g.bucket_sums : nullptr, T, fused_scan ? im.ranges : nullptr,
+                                  g_depth_local_threads.load(std::memory_order_relaxed)), prm, stream);
         MARK(0, "depth_sort");
         // 3. instance offsets in depth order + total: the rects arrive in depth order (rects4_b), nothing to gather
-        STAGE(ex4d_launch_scan_tiles(P, nullptr, g.rects4_b, nullptr, nullptr, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
+        if (!fused_scan)
+            STAGE(ex4d_launch_scan_tiles(P, nullptr, g.rects4_b, nullptr, nullptr, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
         MARK(0, "scan_tiles");
     } else {
         bool in_first = true;
@@ -332,7 +340,8 @@ static int forward_impl(
     if (async) {
         static_assert(sizeof(Ex4dFrameStatus) == 8 * sizeof(uint32_t), "Ex4dFrameStatus mirrors the first eight frame-flag words");
         // (hipMemcpyDefault: the status may live in pinned host memory or -- e.g. for calls recorded into a graph -- in device memory)
-        HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
+        // (fused scan: the instance count is written by the duplication kernel -- the copy follows it, below)
+        if (!fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         R = (uint32_t)prm->instance_capacity;
         n_dev = g.total;
         has_flow = prm->assume_no_flow == 0;
@@ -362,7 +371,9 @@ static int forward_impl(
     if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
         // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
-        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, b.tile_ids, b.vals_tmp, R, stream), prm, stream);
+        STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, b.tile_ids, b.vals_tmp, R, stream,
+                                    fused_scan ? g.sort_keys_b : nullptr, ex4d_depth_sort_msd_rem(key_bits), g.bucket_sums, g.total), prm, stream);
+        if (async && fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         MARK(0, "duplicate");
         STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
                                  R, tile_bits(T), b.sort_hist, im.ranges, stream, n_dev), prm, stream);
@@ -370,7 +381,9 @@ static int forward_impl(
         MARK(0, "tile_ranges");
     } else {
         if (R > 0) {
-            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, k0, v0, R, stream), prm, stream);
+            STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, k0, v0, R, stream,
+                                        fused_scan ? g.sort_keys_b : nullptr, ex4d_depth_sort_msd_rem(key_bits), g.bucket_sums, g.total), prm, stream);
+            if (async && fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
             MARK(0, "duplicate");
             bool res_a = true;
             STAGE(ex4d_radix_sort_pairs(k0, v0, k1, v1, R, tile_bits(T), b.sort_hist, &res_a, stream, n_dev), prm, stream);
@@ -523,8 +536,9 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
-    if (name && !strcmp(name, "depth_sort_msd") && (value == 0 || value == 1)) { g_depth_msd.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 2) { g_depth_msd.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_cap") && value >= 0 && value <= 8192) { g_depth_local_cap.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "depth_sort_local_threads") && (value == 0 || value == 256 || value == 512)) { g_depth_local_threads.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }
 
@@ -540,6 +554,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     if (name && !strcmp(name, "depth_sort_msd")) return g_depth_msd.load();
     if (name && !strcmp(name, "depth_sort_local_cap")) return g_depth_local_cap.load();
+    if (name && !strcmp(name, "depth_sort_local_threads")) return g_depth_local_threads.load();
     return -1;
 }
 

@@ -239,13 +239,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         }
         const uint64_t peers = ((uint64_t)phi << 32) | plo;
         const uint32_t rank = __popcll(peers & lt);
-        const int leader = __ffsll((long long)peers) - 1;
-        uint32_t before = 0;
-        if (valid && rank == 0) {                 // one lane per distinct digit: no two leaders share an address
-            before = wave_cnt[wave][d];
-            wave_cnt[wave][d] = before + (uint32_t)__popcll(peers);
-        }
-        before = __shfl(before, leader < 0 ? 0 : leader, 64);
+        // every lane reads its digit's counter (the peers of a digit read ONE word: an LDS broadcast), then the first lane of every
+        // digit adds the digit's count -- a wave's LDS accesses execute in order, so the reads see the value before the update
+        // (round 5; rounds 1-4: the leader read, wrote and handed `before` to its peers through ds_bpermute: one more LDS round trip)
+        const uint32_t before = wave_cnt[wave][valid ? d : 0u];
+        if (valid && rank == 0) wave_cnt[wave][d] = before + (uint32_t)__popcll(peers);      // one lane per distinct digit: no two writers share an address
         pos[it] = before + rank;                  // index among this wave's items of digit d
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -378,13 +376,14 @@ __global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t
 //   * a bucket with more than `cap` (<= DLS_CAP = 8192) Gaussians -- a scene squeezed into < 1 % of [min_depth, max_depth] -- is sorted
 //     by its workgroup through global memory (ping-pong with the partition's input arrays, whose slice [start, start + n) nobody
 //     else uses): correct for any size, slow by design (tests force it with a small `cap`).
-#define DLS_THREADS 512
-#define DLS_WAVES 8
 #define DLS_ITEMS 16
-#define DLS_CAP (DLS_THREADS * DLS_ITEMS)
-#define DLS_IDX_BITS 13
-static_assert((1 << DLS_IDX_BITS) == DLS_CAP, "arrival index bits");
-struct DlsLds { uint32_t buf[DLS_CAP]; uint32_t cnt[DLS_WAVES][512]; uint32_t scan_tmp[DLS_WAVES]; };
+#define DLS_MAX_CAP 8192
+template <int THREADS> struct DlsLds {
+    static constexpr int WAVES = THREADS / 64, CAP = THREADS * DLS_ITEMS, IDX_BITS = (THREADS == 512 ? 13 : 12);
+    static_assert((1 << IDX_BITS) == CAP, "arrival index bits");
+    uint32_t buf[CAP]; uint32_t cnt[WAVES][512]; uint32_t scan_tmp[WAVES];
+};
+#define DLS_IDX_BITS 13      // (the widest arrival index: what the host checks the key bits against)
 
 __device__ __forceinline__ void dls_wave_sync()
 {
@@ -392,45 +391,61 @@ __device__ __forceinline__ void dls_wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// lanes of the wave that hold the same digit as this lane (among the valid ones); invalid lanes get 0
+// lanes of the wave that hold the same digit as this lane (among the valid ones); invalid lanes get 0.
+// NBITS > 0: digit width known at compile time (unrolled, 5 VALU per bit: see rs_scatter_kernel); 0: `nbits` at run time
+template <int NBITS>
 __device__ __forceinline__ uint64_t dls_peers(uint32_t d, int nbits, bool valid)
 {
     const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
     uint32_t plo = (uint32_t)vmask, phi = (uint32_t)(vmask >> 32);
-    for (int b = 0; b < nbits; b++) {
-        const uint32_t bit = (d >> b) & 1u;
-        const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
-        const uint32_t flip = bit - 1u;                   // 0 when my bit is set, ~0 otherwise
-        plo &= (uint32_t)bal ^ flip;
-        phi &= (uint32_t)(bal >> 32) ^ flip;
+    if (NBITS > 0) {
+#pragma unroll
+        for (int b = 0; b < NBITS; b++) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64((d & (1u << b)) != 0u);
+            uint32_t flip;                                    // 0 when my bit is set, ~0 otherwise: my bit IS my lane's bit of the ballot
+            asm("v_cndmask_b32_e64 %0, -1, 0, %1" : "=v"(flip) : "s"(bal));
+            plo &= (uint32_t)bal ^ flip;
+            phi &= (uint32_t)(bal >> 32) ^ flip;
+        }
+    } else {
+        for (int b = 0; b < nbits; b++) {
+            const uint32_t bit = (d >> b) & 1u;
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(bit != 0u);
+            const uint32_t flip = bit - 1u;                   // 0 when my bit is set, ~0 otherwise
+            plo &= (uint32_t)bal ^ flip;
+            phi &= (uint32_t)(bal >> 32) ^ flip;
+        }
     }
     const uint64_t peers = ((uint64_t)phi << 32) | plo;
     return valid ? peers : 0ull;
 }
 // stable rank of this lane's item among the wave's items processed so far: returns the index among the wave's items of digit d
 // (wave-private counter row `cnt`), and bumps the counter.  All 64 lanes call it.
+template <int NBITS>
 __device__ __forceinline__ uint32_t dls_rank(uint32_t *cnt, uint32_t d, int nbits, bool valid, int lane)
 {
-    const uint64_t peers = dls_peers(d, nbits, valid);
+    const uint64_t peers = dls_peers<NBITS>(d, nbits, valid);
     const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)peers) - 1;
-    uint32_t before = 0;
-    if (valid && rank == 0) {                     // one lane per distinct digit
-        before = cnt[d];
-        cnt[d] = before + (uint32_t)__popcll(peers);
-    }
-    before = __shfl(before, leader < 0 ? 0 : leader, 64);
+    const uint32_t before = cnt[valid ? d : 0u];                            // (all peers read one word; see rs_scatter_kernel)
+    if (valid && rank == 0) cnt[d] = before + (uint32_t)__popcll(peers);    // one lane per distinct digit
     dls_wave_sync();
     return before + rank;
 }
 // cnt[w][d] (counts of digit d among wave w's items) -> first destination slot of (d, w): exclusive scan over (digit, wave)
-__device__ __forceinline__ void dls_scan_counts(DlsLds &L, int nbits)
+template <int THREADS>
+__device__ __forceinline__ void dls_scan_counts(DlsLds<THREADS> &L, int nbits)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // 512 threads = 512 digits
-    const bool live = tid < (1 << nbits);
-    uint32_t c[DLS_WAVES], tot = 0;
+    constexpr int DLS_WAVES = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // thread t owns the PER consecutive digits PER * t ...: 512 threads = 512 digits, 256 threads = 2 digits each
+    constexpr int PER = 512 / THREADS;
+    uint32_t c[PER][DLS_WAVES], tot = 0;
 #pragma unroll
-    for (int w = 0; w < DLS_WAVES; w++) { c[w] = live ? L.cnt[w][tid] : 0u; tot += c[w]; }
+    for (int q = 0; q < PER; q++) {
+        const bool live = tid * PER + q < (1 << nbits);
+#pragma unroll
+        for (int w = 0; w < DLS_WAVES; w++) { c[q][w] = live ? L.cnt[w][tid * PER + q] : 0u; tot += c[q][w]; }
+    }
     uint32_t x = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
@@ -438,9 +453,12 @@ __device__ __forceinline__ void dls_scan_counts(DlsLds &L, int nbits)
     __syncthreads();
     uint32_t run = x - tot;
     for (int w = 0; w < wave; w++) run += L.scan_tmp[w];
-    if (live) {
 #pragma unroll
-        for (int w = 0; w < DLS_WAVES; w++) { L.cnt[w][tid] = run; run += c[w]; }
+    for (int q = 0; q < PER; q++) {
+        if (tid * PER + q < (1 << nbits)) {
+#pragma unroll
+            for (int w = 0; w < DLS_WAVES; w++) { L.cnt[w][tid * PER + q] = run; run += c[q][w]; }
+        }
     }
     __syncthreads();
 }
@@ -448,9 +466,11 @@ __device__ __forceinline__ int dls_pass_bits(int rem, int lo, int npass, int pas
 
 // n > cap: the workgroup sorts the bucket's (key, id, rect) triples through global memory; X = the partition's output slice (where the
 // result has to end), Y = the same slice of the partition's input arrays
-__device__ __forceinline__ void dls_sort_through_memory(DlsLds &L, uint32_t *xk, uint32_t *xv, uint32_t *xr, uint32_t *yk, uint32_t *yv, uint32_t *yr,
+template <int THREADS>
+__device__ __forceinline__ void dls_sort_through_memory(DlsLds<THREADS> &L, uint32_t *xk, uint32_t *xv, uint32_t *xr, uint32_t *yk, uint32_t *yv, uint32_t *yr,
     uint32_t n, int rem)
 {
+    constexpr int DLS_WAVES = THREADS / 64, DLS_THREADS = THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npass = (rem + 8) / 9;
     const uint32_t m = ((n + DLS_WAVES * 64 - 1) / (DLS_WAVES * 64)) * 64;          // items per wave (a multiple of 64)
@@ -469,7 +489,7 @@ __device__ __forceinline__ void dls_sort_through_memory(DlsLds &L, uint32_t *xk,
             const bool valid = i < wend;
             const uint32_t k = valid ? sk[i] : 0u, v = valid ? sv[i] : 0u, r = valid ? sr[i] : 0u;
             const uint32_t d = (k >> lo) & mask;
-            const uint32_t dst = dls_rank(L.cnt[wave], d, nbits, valid, lane);
+            const uint32_t dst = dls_rank<0>(L.cnt[wave], d, nbits, valid, lane);
             if (valid) { dk[dst] = k; dv[dst] = v; dr[dst] = r; }
         }
         __threadfence();
@@ -483,51 +503,133 @@ __device__ __forceinline__ void dls_sort_through_memory(DlsLds &L, uint32_t *xk,
     }
 }
 
-__global__ __launch_bounds__(DLS_THREADS) void depth_local_sort_kernel(uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t *ka, uint32_t *va, uint32_t *ra,
-    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ totals, int rem, uint32_t inv_digit, uint32_t cap)
+// Tile counts of the bucket's Gaussians in depth order -> bucket-local inclusive scan (local_incl[s + p]) and the bucket's instance
+// count: the tile scan of CR/rasterizer_impl.cu:295 without a kernel of its own -- duplicate_kernel adds the exclusive prefix of the
+// <= 1024 bucket sums itself.  Generic form (any n): chunks of DLS_CAP rects read back from memory.
+__device__ __forceinline__ uint32_t rect4_count(uint32_t r) { return ((r >> 16) & 0xFFu) * (r >> 24); }
+// counts of one chunk sit in L.buf[0 .. cn): inclusive scan in place (+ carry); returns the chunk total.  All threads call it.
+template <int THREADS>
+__device__ __forceinline__ uint32_t dls_scan_chunk(DlsLds<THREADS> &L, uint32_t cn, uint32_t carry)
 {
-    __shared__ DlsLds L;
-    const uint32_t b = blockIdx.x;
-    if (b == inv_digit) return;                          // invisible Gaussians: already in id order, rect 0
-    const uint32_t n = totals[b];
-    if (n < 2u || rem == 0) return;                      // nothing to order (rem == 0: all keys of a bucket are equal, the partition was stable)
-    const uint32_t s = starts[b];
-    if (n > cap) { dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem); return; }
+    constexpr int DLS_WAVES = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v[DLS_ITEMS], run = 0;
+#pragma unroll
+    for (int q = 0; q < DLS_ITEMS; q++) { const uint32_t i = tid * DLS_ITEMS + q; run += (i < cn) ? L.buf[i] : 0u; v[q] = run; }
+    uint32_t x = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) L.scan_tmp[wave] = x;
+    __syncthreads();
+    uint32_t excl = carry + x - run, total = 0;
+    for (int w = 0; w < DLS_WAVES; w++) { const uint32_t t = L.scan_tmp[w]; if (w < wave) excl += t; total += t; }
+#pragma unroll
+    for (int q = 0; q < DLS_ITEMS; q++) { const uint32_t i = tid * DLS_ITEMS + q; if (i < cn) L.buf[i] = excl + v[q]; }
+    __syncthreads();
+    return total;
+}
+template <int THREADS>
+__device__ __forceinline__ uint32_t dls_scan_from_memory(DlsLds<THREADS> &L, const uint32_t *rects, uint32_t *local_incl, uint32_t n)
+{
+    constexpr int DLS_THREADS = THREADS, DLS_CAP = THREADS * DLS_ITEMS;
+    const int tid = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += DLS_CAP) {
+        const uint32_t cn = (n - c0) < DLS_CAP ? (n - c0) : DLS_CAP;
+        uint32_t r[DLS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; r[j] = p < cn ? rects[c0 + p] : 0u; }
+#pragma unroll
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; if (p < cn) L.buf[p] = rect4_count(r[j]); }
+        __syncthreads();
+        carry += dls_scan_chunk(L, cn, carry);
+#pragma unroll
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; if (p < cn) local_incl[c0 + p] = L.buf[p]; }
+        __syncthreads();
+    }
+    return carry;
+}
+
+// one stable LSD pass over the n words in L.buf on the digit (word >> sh) & (2^nbits - 1): wave w owns the w-th run of m words
+template <int THREADS, int NBITS>
+__device__ __forceinline__ void dls_lds_pass(DlsLds<THREADS> &L, uint32_t n, uint32_t m, int sh, int nbits)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (NBITS > 0) nbits = NBITS;
+    const uint32_t mask = (1u << nbits) - 1u;
+    const uint32_t wbase = wave * m;
+    for (int i = lane; i < (1 << nbits); i += 64) L.cnt[wave][i] = 0;
+    dls_wave_sync();
+    uint32_t word[DLS_ITEMS], pos[DLS_ITEMS];
+#pragma unroll
+    for (int it = 0; it < DLS_ITEMS; it++) {
+        word[it] = 0u; pos[it] = 0u;
+        if ((uint32_t)(it * 64) < m) {                    // (wave-uniform)
+            const uint32_t i = wbase + it * 64 + lane;
+            const bool valid = i < n;
+            word[it] = valid ? L.buf[i] : 0u;
+            pos[it] = dls_rank<NBITS>(L.cnt[wave], (word[it] >> sh) & mask, nbits, valid, lane);
+        }
+    }
+    __syncthreads();                   // every word is in a register, every count final
+    dls_scan_counts(L, nbits);
+#pragma unroll
+    for (int it = 0; it < DLS_ITEMS; it++) {
+        if ((uint32_t)(it * 64) < m) {
+            const uint32_t i = wbase + it * 64 + lane;
+            if (i < n) L.buf[L.cnt[wave][(word[it] >> sh) & mask] + pos[it]] = word[it];
+        }
+    }
+    __syncthreads();
+}
+
+// THREADS = 256: buckets of <= 4096 in LDS, 24 KB of LDS (the choice up to ~1.2 M Gaussians: ~1.5 k per bucket, every workgroup of the
+// grid resident at once); 512: <= 8192, 48 KB (more Gaussians per bucket: 2 M and up)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_sort_kernel(uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t *ka, uint32_t *va, uint32_t *ra,
+    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ totals, int rem, uint32_t inv_digit, uint32_t cap,
+    uint32_t *__restrict__ local_incl, uint32_t *__restrict__ bucket_sums, int T, uint2 *__restrict__ ranges)
+{
+    constexpr int DLS_THREADS = THREADS, DLS_WAVES = THREADS / 64, DLS_CAP = THREADS * DLS_ITEMS, IDX_BITS = DlsLds<THREADS>::IDX_BITS;
+    __shared__ DlsLds<THREADS> L;
+    const uint32_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    // the zero-fill of the tile ranges (cudaMemset at CR/rasterizer_impl.cu:328) rides along here (it used to ride in the tile scan)
+    if (ranges) for (int i = b * DLS_THREADS + tid; i < T; i += gridDim.x * DLS_THREADS) ranges[i] = make_uint2(0u, 0u);
+    const uint32_t n = totals[b], s = starts[b];
+    if (b == inv_digit || n == 0u) {                     // invisible Gaussians: already in id order, rect 0; nobody reads their offsets
+        if (bucket_sums && tid == 0) bucket_sums[b] = 0u;
+        return;
+    }
+    const bool sorted_already = n < 2u || rem == 0;      // (rem == 0: all keys of a bucket are equal, the partition was stable)
+    if (sorted_already || n > cap) {
+        if (!sorted_already) { dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem); __threadfence(); __syncthreads(); }
+        if (local_incl) {
+            const uint32_t sum = dls_scan_from_memory(L, rb + s, local_incl + s, n);
+            if (tid == 0) bucket_sums[b] = sum;
+        }
+        return;
+    }
     const uint32_t remmask = (1u << rem) - 1u;
-    for (uint32_t i = tid; i < n; i += DLS_THREADS) L.buf[i] = ((kb[s + i] & remmask) << DLS_IDX_BITS) | i;
+    {
+        uint32_t k[DLS_ITEMS];                           // every load in flight before the first LDS store
+#pragma unroll
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; k[j] = p < n ? kb[s + p] : 0u; }
+#pragma unroll
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; if (p < n) L.buf[p] = ((k[j] & remmask) << IDX_BITS) | p; }
+    }
     __syncthreads();
     const int npass = (rem + 8) / 9;
     const uint32_t m = ((n + DLS_WAVES * 64 - 1) / (DLS_WAVES * 64)) * 64;          // items per wave: a multiple of 64, <= 1024
-    const uint32_t wbase = wave * m;
-    for (int pass = 0, lo = 0; pass < npass; pass++) {
-        const int nbits = dls_pass_bits(rem, lo, npass, pass);
-        const uint32_t mask = (1u << nbits) - 1u;
-        const int sh = DLS_IDX_BITS + lo;
-        for (int i = lane; i < 512; i += 64) L.cnt[wave][i] = 0;
-        dls_wave_sync();
-        uint32_t word[DLS_ITEMS], pos[DLS_ITEMS];
-#pragma unroll
-        for (int it = 0; it < DLS_ITEMS; it++) {
-            word[it] = 0u; pos[it] = 0u;
-            if ((uint32_t)(it * 64) < m) {                    // (wave-uniform)
-                const uint32_t i = wbase + it * 64 + lane;
-                const bool valid = i < n;
-                word[it] = valid ? L.buf[i] : 0u;
-                pos[it] = dls_rank(L.cnt[wave], (word[it] >> sh) & mask, nbits, valid, lane);
-            }
+    // digit widths of the common key ranges at compile time (rem = 16: depths in (4, 300]; 17: (0.01, 300]), any other at run time
+    if (rem == 16) { dls_lds_pass<THREADS, 8>(L, n, m, IDX_BITS, 8); dls_lds_pass<THREADS, 8>(L, n, m, IDX_BITS + 8, 8); }
+    else if (rem == 17) { dls_lds_pass<THREADS, 9>(L, n, m, IDX_BITS, 9); dls_lds_pass<THREADS, 8>(L, n, m, IDX_BITS + 9, 8); }
+    else {
+        for (int pass = 0, lo = 0; pass < npass; pass++) {
+            const int nbits = dls_pass_bits(rem, lo, npass, pass);
+            dls_lds_pass<THREADS, 0>(L, n, m, IDX_BITS + lo, nbits);
+            lo += nbits;
         }
-        __syncthreads();                   // every word is in a register, every count final
-        dls_scan_counts(L, nbits);
-#pragma unroll
-        for (int it = 0; it < DLS_ITEMS; it++) {
-            if ((uint32_t)(it * 64) < m) {
-                const uint32_t i = wbase + it * 64 + lane;
-                if (i < n) L.buf[L.cnt[wave][(word[it] >> sh) & mask] + pos[it]] = word[it];
-            }
-        }
-        __syncthreads();
-        lo += nbits;
     }
     // payload: position p takes the (id, rect) that arrived at index idx(p).  In place: every load lands before any store goes out
     uint32_t v[DLS_ITEMS], r[DLS_ITEMS];
@@ -542,7 +644,14 @@ __global__ __launch_bounds__(DLS_THREADS) void depth_local_sort_kernel(uint32_t 
 #pragma unroll
     for (int j = 0; j < DLS_ITEMS; j++) {
         const uint32_t p = tid + j * DLS_THREADS;
-        if (p < n) { vb[s + p] = v[j]; rb[s + p] = r[j]; }
+        if (p < n) { vb[s + p] = v[j]; rb[s + p] = r[j]; if (local_incl) L.buf[p] = rect4_count(r[j]); }
+    }
+    if (local_incl) {
+        __syncthreads();
+        const uint32_t sum = dls_scan_chunk(L, n, 0u);
+#pragma unroll
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; if (p < n) local_incl[s + p] = L.buf[p]; }
+        if (tid == 0) bucket_sums[b] = sum;
     }
 }
 
@@ -634,29 +743,57 @@ struct DupRec { uint32_t off, gid, xy, w, magic; };
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
     const uint2 *__restrict__ sorted_rects, const uint32_t *__restrict__ sorted_rects4,
-    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals, uint32_t cap)
+    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals, uint32_t cap,
+    const uint32_t *__restrict__ bucket_keys, int bucket_shift, const uint32_t *__restrict__ bucket_sums, int nbuckets, uint32_t *__restrict__ frame_total)
 {
     // cap: capacity of the output arrays -- the instance count itself (synchronous forward) or Ex4dParams.instance_capacity (an
     // instance count above it truncates the stream: the caller sees that in the frame status and re-runs the frame)
+    // bucket_keys != nullptr (MSD depth sort with the scan fused into its bucket kernel, round 5): sorted_offsets holds the inclusive
+    // scan INSIDE each depth bucket, bucket_sums the instance count of every bucket; the bucket of position k is the top digit of
+    // bucket_keys[k] (the partition's key output: all keys of a bucket's slice share it).  Every workgroup scans the <= 1024 bucket sums
+    // itself (4 KB from L2) -- there is no tile-scan kernel on this path; workgroup 0 leaves the frame's instance count in frame_total.
     __shared__ DupRec s_rec[4][64];
     __shared__ uint32_t s_mark[4][64];
+    __shared__ uint32_t s_base[1024];
+    __shared__ uint32_t s_wsum[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (bucket_keys) {
+        const int per = nbuckets >> 8;               // 2 or 4 consecutive buckets per thread (nbuckets = 512 or 1024)
+        uint32_t c[4], run = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { c[q] = q < per ? bucket_sums[threadIdx.x * per + q] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t t = c[q]; c[q] = run; run += t; }
+        uint32_t x = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        uint32_t excl = x - run;
+        for (int wv = 0; wv < wave; wv++) excl += s_wsum[wv];
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (q < per) s_base[threadIdx.x * per + q] = excl + c[q];
+        if (blockIdx.x == 0 && threadIdx.x == 255) *frame_total = excl + run;
+        __syncthreads();
+    }
     uint32_t gid = 0, off = 0, count = 0;
     int x0 = 0, y0 = 0, w = 1;
     if (k < P) {
         gid = order[k];
-        // exclusive offset = inclusive scan value of the previous element (+ its scan chunk's base, below)
-        off = (k == 0) ? 0u : sorted_offsets[k - 1];
         const uint2 rc = sorted_rects4 ? unpack_rect(sorted_rects4[k]) : sorted_rects[k];      // getRect (CR/auxiliary.h:46-56) was evaluated once, by the preprocess kernel
         x0 = (int)(rc.x & 0xFFFFu); y0 = (int)(rc.x >> 16);
         w = (int)(rc.y & 0xFFFFu);
         count = (uint32_t)w * (rc.y >> 16);
         if (w <= 0) w = 1;
+        // exclusive offset = inclusive scan value of the previous element (+ its scan chunk's base, below); bucket form: the bucket's
+        // base + the Gaussian's own inclusive value - its count (no neighbour, no bucket-boundary case)
+        if (!bucket_keys) off = (k == 0) ? 0u : sorted_offsets[k - 1];
+        else if (count != 0u) off = s_base[bucket_keys[k] >> bucket_shift] + sorted_offsets[k] - count;
     }
     // base of a scan chunk = sum of the chunk totals before it.  The (k-1) of a wave lie in at most two chunks; the wave sums
     // the few hundred totals itself instead of a one-workgroup scan kernel in between (one launch less)
-    {
+    if (!bucket_keys) {
         const int kf = blockIdx.x * 256 + (threadIdx.x & ~63) - 1;            // k - 1 of the wave's first lane (may be -1)
         const int c0 = kf < 0 ? 0 : kf / SCAN_CHUNK;
         uint32_t part = 0;
@@ -671,11 +808,14 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
     // row = local / w without a per-output division: local < 2^16 (a rect has at most gx*gy tiles; images with more than 65535 tiles
     // take the plain division below) and w < 2^16, so floor(local / w) == umulhi(local, floor((2^32 - 1) / w) + 1) exactly; one division per Gaussian
     const uint32_t magic = 0xFFFFFFFFu / (uint32_t)w + 1u;
-    uint32_t end = off + count;
+    // the wave's output range [start, end): from the first slot of its first Gaussian with instances to the last slot of its last one
+    // (Gaussians without instances -- invisible ones, lanes behind P -- take no part: their offsets may be anything)
+    uint32_t start = count != 0u ? off : 0xFFFFFFFFu, end = count != 0u ? off + count : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(end, o, 64); end = t > end ? t : end; }
-    if (k >= P) { off = end; count = 0; }
-    const uint32_t start = __shfl(off, 0, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(end, o, 64), u = __shfl_xor(start, o, 64);
+        end = t > end ? t : end; start = u < start ? u : start;
+    }
     s_rec[wave][lane] = { off, gid, (uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)w, magic };
     uint32_t carry = 0;                      // owner (lane index + 1) of the last output of the previous round
     for (uint32_t tb = start; tb < end; tb += 64) {       // wave-uniform trip count
@@ -778,14 +918,17 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
 int ex4d_depth_sort_msd_rem(int key_bits) { return key_bits > EX4D_DLS_MSD_BITS ? key_bits - EX4D_DLS_MSD_BITS : 0; }
 bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits) { return n <= (1u << 26) && ex4d_depth_sort_msd_rem(key_bits) + DLS_IDX_BITS <= 32; }
 hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, int key_bits,
-    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream)
+    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
+    uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads)
 {
     if (n == 0) return hipSuccess;
     constexpr int MB = EX4D_DLS_MSD_BITS, BINS = 1 << MB;
     const int rem = ex4d_depth_sort_msd_rem(key_bits);
     const uint32_t nb = rs_blocks_for(n);
     const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
-    if (local_cap == 0 || local_cap > DLS_CAP) local_cap = DLS_CAP;
+    if (local_threads != 256 && local_threads != 512) local_threads = n <= 1200000u ? 256 : 512;
+    const uint32_t kcap = (uint32_t)local_threads * DLS_ITEMS;
+    if (local_cap == 0 || local_cap > kcap) local_cap = kcap;
     if (small) {
         hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, BINS, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, rem, (uint32_t)(BINS - 1), nb, hist, (const uint32_t *)nullptr);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
@@ -797,7 +940,12 @@ hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_
         hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, rem, MB, nb, hist,
             0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts);
     }
-    hipLaunchKernelGGL(depth_local_sort_kernel, dim3(BINS), dim3(DLS_THREADS), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, rem, inv_digit, local_cap);
+    if (local_threads == 256)
+        hipLaunchKernelGGL(depth_local_sort_kernel<256>, dim3(BINS), dim3(256), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, rem, inv_digit, local_cap,
+            local_incl, bucket_sums, T, ranges);
+    else
+        hipLaunchKernelGGL(depth_local_sort_kernel<512>, dim3(BINS), dim3(512), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, rem, inv_digit, local_cap,
+            local_incl, bucket_sums, T, ranges);
     return hipGetLastError();
 }
 
@@ -847,11 +995,12 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rec
 }
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream)
+    const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream,
+    const uint32_t *bucket_keys, int bucket_shift, const uint32_t *bucket_sums, uint32_t *frame_total)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        sorted_rects, sorted_rects4, tile_keys, vals, cap);
+        sorted_rects, sorted_rects4, tile_keys, vals, cap, bucket_keys, bucket_shift, bucket_sums, 1 << EX4D_DLS_MSD_BITS, frame_total);
     return hipGetLastError();
 }
 

@@ -32,6 +32,7 @@ struct GeomState {
     uint32_t *sorted_offsets;
     // scratch used only inside forward (not needed by backward)
     uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
+    uint32_t *bucket_sums;                               // MSD depth sort with the fused tile scan: instance count of every depth bucket
     uint32_t *sort_vals_a, *rects4_b, *bucket_starts;    // MSD depth sort: the ids as preprocess wrote them, the packed rects in depth order, first position of every bucket
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
@@ -105,14 +106,16 @@ hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rects4, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
-    const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream);
+    const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream,
+    const uint32_t *bucket_keys = nullptr, int bucket_shift = 0, const uint32_t *bucket_sums = nullptr, uint32_t *frame_total = nullptr);
 
 // MSD-first depth sort (ex4d_binning.hip): one global partition on the top EX4D_DLS_MSD_BITS key bits, every bucket finished in LDS
 #define EX4D_DLS_MSD_BITS 10
 int ex4d_depth_sort_msd_rem(int key_bits);
 bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits);
 hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, int key_bits,
-    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream);
+    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
+    uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads);       // local_incl / bucket_sums: the tile scan fused into the bucket kernel (nullptr = not)
 hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // ptr 16-byte aligned, bytes a multiple of 4 (a kernel, not hipMemsetAsync: ex4d_binning.hip)
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 

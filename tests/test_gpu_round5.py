@@ -53,18 +53,22 @@ SCENES = [("cfg2", 20000, 0), ("cfg3", 12000, 137), ("cfg5", 6000, 0), ("cfg1", 
 @pytest.mark.parametrize("cfg,P,t", SCENES)
 def test_msd_depth_sort_equals_the_lsd_sort_and_a_host_sort(hip_lib, cfg, P, t):
     """depth_order / point_list / ranges / the image: bit-equal between the MSD-first depth sort (default), the same with every bucket
-    forced through global memory (local capacity 1: the path of oversize buckets), and the 3-pass LSD sort; depth_order equal to
-    a stable host sort of the depth bits."""
+    forced through global memory (local capacity 1: the path of oversize buckets), the variant that keeps the tile scan as a kernel of
+    its own (depth_sort_msd = 1), and the 3-pass LSD sort; depth_order equal to a stable host sort of the depth bits."""
     ins, st = h.scene_inputs(cfg, P=P, t=t)
     ins = {k: v.cuda() for k, v in ins.items()}
     lsd = _frame(ins, st, depth_sort_msd=0)
-    msd = _frame(ins, st, depth_sort_msd=1)
-    mem = _frame(ins, st, depth_sort_msd=1, depth_sort_local_cap=1)
-    mid = _frame(ins, st, depth_sort_msd=1, depth_sort_local_cap=7)
+    msd = _frame(ins, st, depth_sort_msd=2)
+    mem = _frame(ins, st, depth_sort_msd=2, depth_sort_local_cap=1, depth_sort_local_threads=512)
+    mid = _frame(ins, st, depth_sort_msd=2, depth_sort_local_cap=7, depth_sort_local_threads=256)
+    big = _frame(ins, st, depth_sort_msd=2, depth_sort_local_threads=512)
+    unfused = _frame(ins, st, depth_sort_msd=1, depth_sort_local_cap=5)
     assert torch.equal(lsd["depth_order"], _host_depth_order(lsd)), "LSD depth order differs from the host sort"
     _same(msd, lsd, "msd vs lsd")
     _same(mem, lsd, "msd through memory vs lsd")
     _same(mid, lsd, "msd mixed vs lsd")
+    _same(big, lsd, "msd with 512-thread bucket workgroups and the histogram kernel vs lsd")
+    _same(unfused, lsd, "msd with the scan kernel vs lsd")
 
 
 def _squeezed(P, z_lo, z_hi, ties=0, seed=5):
@@ -89,9 +93,10 @@ def test_msd_depth_sort_oversize_buckets_and_ties(hip_lib, P, z_lo, z_hi, ties):
     exact depth ties (order falls back to ascending id: CR/rasterizer_impl.cu:321-326 is a stable sort), all depths equal."""
     ins, st = _squeezed(P, z_lo, z_hi, ties)
     lsd = _frame(ins, st, depth_sort_msd=0)
-    msd = _frame(ins, st, depth_sort_msd=1)
+    msd = _frame(ins, st, depth_sort_msd=2)
     assert torch.equal(lsd["depth_order"], _host_depth_order(lsd))
     _same(msd, lsd, "msd vs lsd")
+    _same(_frame(ins, st, depth_sort_msd=1, depth_sort_local_threads=512), lsd, "msd with the scan kernel vs lsd")
     vis = int((lsd["radii"] > 0).sum())
     assert vis > P // 2
 
@@ -101,6 +106,7 @@ def test_msd_depth_sort_full_size_1M(hip_lib):
     ins, st = h.scene_inputs("cfg3", t=137)
     ins = {k: v.cuda() for k, v in ins.items()}
     lsd = _frame(ins, st, depth_sort_msd=0)
-    msd = _frame(ins, st, depth_sort_msd=1)
+    msd = _frame(ins, st, depth_sort_msd=2)
     assert torch.equal(lsd["depth_order"], _host_depth_order(lsd))
     _same(msd, lsd, "msd vs lsd at 1.0 M")
+    _same(_frame(ins, st, depth_sort_msd=1, depth_sort_local_threads=512), lsd, "msd with the scan kernel vs lsd at 1.0 M")
