@@ -536,6 +536,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "preprocess_fast_path") && (value == 0 || value == 1)) { ex4d_set_preprocess_fast(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 2) { g_depth_msd.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_cap") && value >= 0 && value <= 8192) { g_depth_local_cap.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_threads") && (value == 0 || value == 256 || value == 512)) { g_depth_local_threads.store(value); return EX4D_OK; }
@@ -552,6 +553,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "preprocess_sh_predicate")) return ex4d_get_preprocess_tune();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
+    if (name && !strcmp(name, "preprocess_fast_path")) return ex4d_get_preprocess_fast();
     if (name && !strcmp(name, "depth_sort_msd")) return g_depth_msd.load();
     if (name && !strcmp(name, "depth_sort_local_cap")) return g_depth_local_cap.load();
     if (name && !strcmp(name, "depth_sort_local_threads")) return g_depth_local_threads.load();

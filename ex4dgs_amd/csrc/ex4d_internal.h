@@ -121,6 +121,8 @@ hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, 
 
 void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: 1 (default) = SH rows of frustum-culled Gaussians are not requested
 int ex4d_get_preprocess_tune();
+void ex4d_set_preprocess_fast(int v);   // 1 (default) = frames with one [P,16,3] SH tensor at degree 3 and scale + rotation take the specialised kernel
+int ex4d_get_preprocess_fast();
 void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled entry walk (default) or the compiler's loop
 int ex4d_get_fwd_asm();
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,

@@ -204,6 +204,13 @@ __device__ __forceinline__ bool mask_bit(uint64_t need, int g)
 __device__ __forceinline__ void wave_issue_sh(const float *__restrict__ shs_wave, ShPrefetch &pf, int nrows, int nvec, int lane, uint64_t need)
 {
     const float4 *src = reinterpret_cast<const float4 *>(shs_wave);
+    // a full wave whose 64 rows are all wanted at degree 3 (every wave but the last of a frame whose Gaussians pass the frustum test):
+    // twelve plain loads.  The predicated form below costs ~30 instructions per load (three nested exec regions, divisions by 12, zero fills)
+    if (nrows == 64 && nvec == 12 && need == ~0ull) {          // (wave-uniform)
+#pragma unroll
+        for (int it = 0; it < 12; it++) pf.v[it] = src[it * 64 + lane];
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < 12; it++) {
         const int q = it * 64 + lane;
@@ -403,19 +410,29 @@ __device__ __forceinline__ void sh_direction_sums(const float *sh, int D, float 
 #undef SHK
 }
 
+// FAST: the configuration every training / rendering frame of the reference runs (one [P,16,3] SH tensor at degree 3, scale + rotation,
+// no precomputed colours or covariances) with its constants known at compile time -- the generic kernel carries runtime tests for
+// every other input combination around each of its loads (round 5: 1706 vector + ~500 scalar instructions per wave, a third of them
+// such bookkeeping).  Same arithmetic, same order: the results are bit-identical (tests/test_gpu_round5.py).
+template <bool FAST>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
-    int P, int D, int M,
+    int P, int D_, int M_,
     const float *__restrict__ means3D, const float *__restrict__ dir3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
-    const float *__restrict__ cov3D_precomp, const float *__restrict__ colors_precomp,
+    const float *__restrict__ cov3D_precomp_, const float *__restrict__ colors_precomp_,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos,
     int W, int H, float tanx, float tany, float fx, float fy, float kernel_size, float min_depth, float max_depth,
     int prefiltered, uint32_t *__restrict__ prefilter_violation,
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
-    uint32_t *__restrict__ total_instances, const ShSplit sp, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4)
+    uint32_t *__restrict__ total_instances, const ShSplit sp_, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4)
 {
+    const int D = FAST ? 3 : D_, M = FAST ? 16 : M_;
+    const float *__restrict__ cov3D_precomp = FAST ? nullptr : cov3D_precomp_;
+    const float *__restrict__ colors_precomp = FAST ? nullptr : colors_precomp_;
+    ShSplit sp = sp_;
+    if (FAST) { sp.dc[0] = sp.dc[1] = sp.rest[0] = sp.rest[1] = nullptr; sp.n_static = 0; __builtin_assume(shs != nullptr); }
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Every wave is independent (no workgroup barrier, wave-private LDS slice, per-wave instance count): chunk wc of 64 Gaussians.
@@ -1052,6 +1069,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 // "preprocess_sh_predicate" (ex4d_set_option): the SH rows of frustum-culled Gaussians are not requested (default 1)
 static int preprocess_option_default() { const char *e = getenv("EX4D_PREPROCESS_SH_PREDICATE"); return e ? (atoi(e) != 0) : 1; }    // developer override
+static std::atomic<int> g_preprocess_fast{1};      // "preprocess_fast_path": the compile-time-specialised forward kernel for the common input combination
+void ex4d_set_preprocess_fast(int v) { g_preprocess_fast.store(v); }
+int ex4d_get_preprocess_fast() { return g_preprocess_fast.load(); }
 static std::atomic<int> g_preprocess_tune{preprocess_option_default()};
 void ex4d_set_preprocess_tune(int v) { g_preprocess_tune.store(v != 0); }
 int ex4d_get_preprocess_tune() { return g_preprocess_tune.load(); }
@@ -1064,13 +1084,18 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, stream,
-        prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size,
-        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation,
-        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split,
-        (prm.prepare_backward && (shs != nullptr || split.rest[0] != nullptr || split.rest[1] != nullptr)) ? g.sh_dsums : (float *)nullptr,
-        g_preprocess_tune.load(std::memory_order_relaxed), rects4);
+    const bool is_split = split.rest[0] != nullptr || split.rest[1] != nullptr;
+    const bool fast = g_preprocess_fast.load(std::memory_order_relaxed) != 0 && shs != nullptr && !is_split && prm.D == 3 && prm.M == 16 &&
+                      cov3D_precomp == nullptr && colors_precomp == nullptr && scales != nullptr && rotations != nullptr;
+#define PF_ARGS prm.P, prm.D, prm.M, means3D, dir3D, scales, prm.scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, \
+        viewmatrix, projmatrix, campos, prm.W, prm.H, prm.tanfovx, prm.tanfovy, fx, fy, prm.kernel_size, \
+        prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation, \
+        radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split, \
+        (prm.prepare_backward && (shs != nullptr || is_split)) ? g.sh_dsums : (float *)nullptr, \
+        g_preprocess_tune.load(std::memory_order_relaxed), rects4
+    if (fast) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
+    else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
+#undef PF_ARGS
     return hipGetLastError();
 }
 

@@ -110,3 +110,39 @@ def test_msd_depth_sort_full_size_1M(hip_lib):
     assert torch.equal(lsd["depth_order"], _host_depth_order(lsd))
     _same(msd, lsd, "msd vs lsd at 1.0 M")
     _same(_frame(ins, st, depth_sort_msd=1, depth_sort_local_threads=512), lsd, "msd with the scan kernel vs lsd at 1.0 M")
+
+
+@pytest.mark.parametrize("cfg,P,t,prepare", [("cfg2", 20000, 0, False), ("cfg3", 12001, 137, True), ("cfg5", 6000, 0, True), ("cfg2", 63, 0, True)])
+def test_specialised_preprocess_kernel_is_bit_identical_to_the_generic_one(hip_lib, cfg, P, t, prepare):
+    """preprocess_fwd_kernel<FAST> (one [P,16,3] SH tensor at degree 3, scale + rotation: constants at compile time, plain SH loads for
+    full waves) against the generic kernel: every word of the geometry buffer the rest of the frame reads, and the frame itself."""
+    from ex4dgs_amd import _C
+    ins, st = h.scene_inputs(cfg, P=P, t=t)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    out = []
+    for fast in (0, 1):
+        _C.set_option("preprocess_fast_path", fast)
+        try:
+            s, f = _raw_forward(ins, st, prepare_backward=prepare)
+            torch.cuda.synchronize()
+        finally:
+            _C.set_option("preprocess_fast_path", 1)
+        n = ins["means3D"].shape[0]
+        g = _C.geom_views(f[3], n)
+        vis = f[2] > 0
+        out.append(dict(R=f[0], color=f[1].clone(), radii=f[2].clone(), records=g["records"][vis].clone(), clamped=g["clamped"][vis].clone(),
+                        rects=g["rects"].clone(), order=g["depth_order"].clone(), depth=f[6].clone(), acc=f[7].clone(), flow=f[8].clone(), idx=f[9].clone(),
+                        geom=f[3].clone()))
+    a, b = out
+    assert a["R"] == b["R"] and int((a["radii"] > 0).sum()) > 0
+    for k in ("color", "radii", "records", "clamped", "rects", "order", "depth", "acc", "flow", "idx"):
+        assert torch.equal(a[k].view(torch.uint8) if a[k].dtype == torch.float32 else a[k], b[k].view(torch.uint8) if b[k].dtype == torch.float32 else b[k]), k
+    if prepare:
+        # the SH direction sums the forward leaves for the backward (36 B per visible Gaussian): the last array of the geometry buffer
+        import ctypes
+        n = ins["means3D"].shape[0]
+        lay = _C.GeomLayout(); _C.load().ex4d_geom_layout(n, ctypes.byref(lay))
+        off = lay.total - ((36 * n + 255) // 256) * 256
+        vis = a["radii"] > 0
+        da, db = (x["geom"][off: off + 36 * n].view(torch.int32).view(n, 9)[vis] for x in (a, b))
+        assert torch.equal(da, db), "SH direction sums differ"
