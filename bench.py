@@ -379,7 +379,9 @@ def main():
     cfg = CONFIGS[args.config]
     train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only
     if args.optimizer is None:
-        args.optimizer = "replicated" if train_mode else "none"
+        # N >= 4: reduce-scatter + sharded RAdam (row-sharded keyframe windows) + all-gather -- half the bytes per link of the all-reduce
+        # and 1/N of the optimizer's HBM stream per rank; N < 4: the replicated optimizer
+        args.optimizer = ("sharded" if world >= 4 else "replicated") if train_mode else "none"
     H, W = cfg.height, cfg.width
     g = torch.Generator().manual_seed(1000 + rank)
     grads = [torch.randn(3, H, W, generator=g).to(dev), (0.1 * torch.randn(1, H, W, generator=g)).to(dev),
@@ -520,11 +522,20 @@ def main():
                 def ex_only(i):
                     tr.exchange_feat.launch(gfeat); tr.exchange.launch(grest); tr.exchange_feat.wait(); tr.exchange.wait()
                 ex_alone, _ = timed_loop(ex_only, max(4, args.steps // 4), 2, sync_all)
+            ms_noex_local = ms_noex
             ms_noex = xdist.allreduce_max_scalar(ms_noex, device=dev)
-            multi = {"ranks_seen": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+            # ranks that really took part: a sum all-reduce of ones over the process group (RCCL on the GPU backend), not the configured size
+            ones = torch.ones(1, device=dev)
+            torch.distributed.all_reduce(ones)
+            per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+            per_rank[rank] = max(0.0, ms_wall - ms_noex_local)          # this rank's own exposed exchange (its step with - without the exchange)
+            torch.distributed.all_reduce(per_rank)
+            multi = {"ranks_seen": int(round(float(ones.item()))), "world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                     "exposed_exchange_ms_per_rank": [round(float(x), 4) for x in per_rank.tolist()],
                      "optimizer": args.optimizer,
                      "collective_tensors": len(model.PARAM_NAMES) if tr.exchange is not None else 0,
-                     "exchange_bytes_per_rank": tr.exchange_bytes_on_wire() if exchange != "sharded" else tr.exchange.bytes_on_wire(),
+                     "exchange_bytes_per_rank": tr.exchange_bytes_on_wire(),
+                     "sliced_keyframe_gradients": bool(tr.sliced),
                      "ms_per_step_without_exchange": round(ms_noex, 4),
                      "allreduce_ms_per_step": None if ex_alone is None else round(xdist.allreduce_max_scalar(ex_alone, device=dev), 4),
                      "share_device": bool(args.share_device)}

@@ -81,18 +81,37 @@ class PendingFrame:
 
     def __del__(self):
         try:
-            if self._pool is not None and self._event is not None and not self._status.is_cuda and self._event.query():
-                self._pool.append(self._status)          # the pinned status words go back to the pool once the copy has landed
+            if self._pool is not None and self._event is not None and not self._status.is_cuda:
+                if self._event.query():
+                    self._pool.append(self._status)      # the pinned status words go back to the pool once the copy has landed
+                else:
+                    # the asynchronous copy into these words may still be in flight: keep the view (and with it the pinned block) alive
+                    # and hand the slot back once its event has passed (dropping it here lost the slot for good, and a block
+                    # whose 16 views were all gone could be handed out again by torch's host allocator while a copy was pending)
+                    _status_parked.append((self._event, self._status))
         except Exception:
             pass
 
 
 _status_pool = []
+_status_parked = []          # (event, pinned status words) of frames dropped before their status copy had landed
+
+
+def _recycle_parked():
+    if _status_parked:
+        still = []
+        for ev, st in _status_parked:
+            if ev.query():
+                _status_pool.append(st)
+            else:
+                still.append((ev, st))
+        _status_parked[:] = still
 
 
 def _pinned_status():
     """8 pinned int32 words for one frame's Ex4dFrameStatus (pooled: pinning host memory costs far more than a frame, and is not
     allowed while a stream is capturing -- the pool is filled 16 buffers at a time outside capture)."""
+    _recycle_parked()
     if not _status_pool:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("no pinned status buffer left during graph capture: run one asynchronous forward before capturing")

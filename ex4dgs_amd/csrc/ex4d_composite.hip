@@ -155,7 +155,7 @@ __device__ __forceinline__ PixelGeom pixel_of_lane(int tile, int quad, int gx, i
 // gets the contiguous tile band [x*chunk, (x+1)*chunk).  One workgroup = one wave = one quadrant of a tile: the four quadrant waves of
 // a tile are independent, and as separate workgroups each gives its wave slot and LDS back as soon as IT is done (round 3: as one
 // 256-thread workgroup the forward held four slots until its slowest quadrant finished, 0.150 -> 0.144 ms).
-// Measured and dropped in round 3 (profiles/r03_compositing_experiments.txt): stripes of 1 / 2 / 4 / 8 tile rows dealt to the XCDs
+// Measured and dropped in round 3 (profiles/archive/r03_compositing_experiments.txt): stripes of 1 / 2 / 4 / 8 tile rows dealt to the XCDs
 // instead of bands, and "heaviest tiles of a band first" (a counting sort of the band's tiles by list length in front of the
 // forward) -- neither moved either compositing kernel by more than the box-to-box noise: they do not end on a few late heavy tiles.
 __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &quad)
@@ -171,7 +171,7 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 // FLOW = false: no Gaussian of the frame carries a non-zero dir3D (the training loop passes the all-zero gradient-trap tensor,
 // gaussian_renderer/__init__.py:66-70): the flow image is zero, its three accumulations per pair and the staging of dir3D are skipped.
 //
-// Round 3, measured on MI355X (1.0 M Gaussians, rocprofv3 counters in profiles/r03_fwd_experiment.txt): the kernel is VALU-issue bound
+// Round 3, measured on MI355X (1.0 M Gaussians, rocprofv3 counters in profiles/archive/r03_fwd_experiment.txt): the kernel is VALU-issue bound
 // to the instruction -- 9.10e7 wave instructions x 4 cycles / 1024 SIMDs = 0.148 ms = its duration; a quadrant composites ~147 list
 // entries (3.2 M (entry, quadrant) pairs reach the pixel loop, 87 % of them with a contributing pixel), half of the entries of the
 // chunks it looks at survive the quadrant cull, and it stops at a fifth of the list.  Tried and rejected with numbers:
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
 // quadrant cull (BinState::qlist / qcount: Gaussian id + list position, in list order); this kernel streams it back to front and
 // gathers the records of the survivors only.
 //
-// Measured on MI355X, 1.0 M Gaussians / 7.5 M instances (profiles/r02_*): per-pixel kernel 0.458 ms, 2.32e8 VALU instructions;
+// Measured on MI355X, 1.0 M Gaussians / 7.5 M instances (profiles/archive/r02_*): per-pixel kernel 0.458 ms, 2.32e8 VALU instructions;
 // this kernel 0.35 ms, 1.79e8 (86 % VALU-busy; 55 % of the lanes of a step hold a contributing pair, 96 % of the staged
 // Gaussians contribute somewhere in their quadrant).
 //

@@ -5,7 +5,7 @@
 // MI355X at 1352x1014 the torch version costs 11.7 ms per iteration -- ten times the rasterizer it scores.
 //
 // The 11x11 window is the outer product of a 1-D Gaussian, so every convolution is separable.  Round 4: ROLLING WINDOW.  A workgroup
-// owns a strip of 64 output columns and walks down a segment of 64 output rows, four image rows per iteration: the rows' 11-tap row
+// owns a strip of 64 output columns and walks down a segment of SEG = 48 output rows, four image rows per iteration: the rows' 11-tap row
 // pass (five moment maps x, y, x^2, y^2, xy per channel in the forward, the three derivative maps in the backward) goes into a ring of
 // 16 rows in LDS, the column pass of the four output rows whose window is now complete reads 11 ring rows each.  Every input row is
 // read ONCE per strip (rounds 2-3: 16x16 output tiles with a 26x26 halo each read 2.6x the image, and their 104-byte halo rows pulled
@@ -29,6 +29,11 @@ namespace {
 #define RPI 4                       // image rows per iteration (256 threads = RPI rows x SW columns)
 #define RING 16                     // rows of row-pass results kept in LDS (>= 11 + RPI - 1, power of two)
 #define CG 3                        // channels convolved together (the reference's images are RGB; more channels run in groups)
+
+// static LDS of the two kernels: the input double buffer + the ring of row-pass results.  Both exceed the 64 KB a workgroup may take on
+// older parts and are sized for gfx950's 160 KB per CU (two workgroups per CU): this file builds for gfx950-class LDS only
+static_assert(sizeof(float) * (2 * 2 * CG * RPI * (SIN + 2) + CG * 5 * RING * SW + 8) <= 80 * 1024, "l1_ssim_fwd_kernel: two workgroups per CU need <= 80 KB of LDS each");
+static_assert(sizeof(float) * (2 * 3 * CG * RPI * (SIN + 2) + CG * 3 * RING * SW) <= 80 * 1024, "l1_ssim_bwd_kernel: two workgroups per CU need <= 80 KB of LDS each");
 
 struct Window { float w[EX4D_SSIM_WINDOW]; };
 

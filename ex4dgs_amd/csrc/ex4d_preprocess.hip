@@ -233,12 +233,12 @@ __device__ __forceinline__ bool wave_issue_sh_split(const ShSplit &sp, int wave_
     for (int it = 0; it < 12; it++) {
         const int q = it * 64 + lane;
         const int r_lo = (4 * q) / 45, r_hi = (4 * q + 3) / 45;        // the at most two rows a 16-byte chunk of the rest span touches
-        const bool want = q < 720 && (((need >> (r_lo & 63)) | (need >> (r_hi & 63))) & 1ull);
+        const bool want = q < 720 && (mask_bit(need, r_lo & 63) || mask_bit(need, r_hi & 63));      // (never a 64-bit shift by a per-lane amount: mask_bit)
         pf.v[it] = want ? reinterpret_cast<const float4 *>(rest)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     {
         const int r_lo = (4 * lane) / 3, r_hi = (4 * lane + 3) / 3;
-        const bool want = lane < 48 && (((need >> (r_lo & 63)) | (need >> (r_hi & 63))) & 1ull);
+        const bool want = lane < 48 && (mask_bit(need, r_lo & 63) || mask_bit(need, r_hi & 63));
         pf.v[12] = want ? reinterpret_cast<const float4 *>(dc)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return true;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * SH_HALF_FLOATS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Every wave is independent (no workgroup barrier, wave-private LDS slice, per-wave instance count): chunk wc of 64 Gaussians.
-    // Round 4, measured and dropped (profiles/r04b_experiments.txt, r04c_experiments.txt): distinct s_setprio levels per wave slot and
+    // Round 4, measured and dropped (profiles/archive/r04b_experiments.txt, r04c_experiments.txt): distinct s_setprio levels per wave slot and
     // one-wave workgroups, meant to pull the load / arithmetic / store phases of co-resident waves apart -- no effect (+-2 %).  What the
     // kernel's time is made of (tools/dev/pre_probe.py, 1.0 M Gaussians): 49 us with precomputed colours (no SH path at all), +24 us for
     // the SH staging and evaluation at degree 0 (16 of 192 bytes of SH read per Gaussian), +10 us for the other 176 bytes at degree 3,

@@ -49,7 +49,8 @@ class AsyncFrames:
     package by default.  `async_frames.enable()` removes that wait: the binning buffer is sized for
     `headroom x the largest instance count seen so far` (the first frame runs synchronously and seeds it), `ctx.num_rendered`
     becomes a `_C.PendingFrame` (an int on demand) and the status of a frame is looked at when it costs nothing -- at the start
-    of the NEXT forward, by which time its copy has long landed.  A frame whose instance count exceeded the capacity had its tile
+    of the NEXT forward and at the start of every backward, by which time its copy has long landed (`drain()` settles whatever is
+    still outstanding at the end of a loop: call it before trusting the last frames).  A frame whose instance count exceeded the capacity had its tile
     lists truncated: its outputs and gradients are invalid.  That cannot be repaired behind the caller's back (the image was
     already consumed), so it is reported: `strict` (default) raises at the next forward, otherwise `invalid_frames` counts and the
     capacity grows.  Callers that own the whole iteration -- trainer.FrameTrainer(async_forward=True), under a policy object of its
@@ -188,6 +189,11 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, grad_out_depth, grad_out_flow, grad_out_acc, _grad_idx):
         s = ctx.raster_settings
+        # asynchronous forward: frames whose status has landed by now are settled here as well (never blocks) -- an overflow in the LAST
+        # frame of a loop is then reported by that frame's own backward instead of waiting for a next forward that never comes
+        # (callers that stop without a backward call async_frames.drain())
+        if isinstance(ctx.num_rendered, _C.PendingFrame):
+            current_policy().poll()
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, depth, acc, _flow) = ctx.saved_tensors[:13]
         none = torch.Tensor([])

@@ -21,8 +21,42 @@ import shutil
 import subprocess
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
 ARCH = "gfx950"
+
+
+class IsaCheckError(RuntimeError):
+    """The machine-code checks could not be carried out (tools missing, metadata unreadable): the build fails CLOSED on it."""
+
+
+def _llvm_dir():
+    """Directory of llvm-objcopy / llvm-objdump / llvm-readelf / clang-offload-bundler: next to the ROCm installation hipcc belongs
+    to ($ROCM_PATH, the resolved hipcc, /opt/rocm), never a hard-coded path alone."""
+    cands = []
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin"), os.path.join(root, "llvm", "bin")]
+    cands.append("/opt/rocm/lib/llvm/bin")
+    need = ("llvm-objcopy", "llvm-objdump", "llvm-readelf", "clang-offload-bundler")
+    for c in cands:
+        if all(os.path.exists(os.path.join(c, t)) for t in need):
+            return c
+    raise IsaCheckError(f"the LLVM tools {need} were not found in any of {cands}: set ROCM_PATH; the machine-code checks of the build cannot run")
+
+
+class _Llvm:
+    """`f"{LLVM}/tool"` resolves the directory on first use (import of this module must not need the tools)."""
+    _dir = None
+
+    def __format__(self, spec):
+        if _Llvm._dir is None:
+            _Llvm._dir = _llvm_dir()
+        return _Llvm._dir
+
+
+LLVM = _Llvm()
 SHIFT64 = ("v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64")
 TRANS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rcp_iflag_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32",
          "v_exp_f16", "v_log_f16", "v_rcp_f16", "v_rsq_f16", "v_sqrt_f16", "v_sin_f16", "v_cos_f16", "v_exp_legacy_f32", "v_log_legacy_f32")
@@ -33,9 +67,14 @@ _DPP_CTRL = ("quad_perm:", "row_shl:", "row_shr:", "row_ror:", "wave_shl:", "wav
 def device_code(obj, workdir):
     """The gfx950 code object embedded in a host object; None for host-only objects."""
     fat, co = os.path.join(workdir, "fat.bin"), os.path.join(workdir, "dev.co")
-    r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], stderr=subprocess.DEVNULL)
+    sections = subprocess.run([f"{LLVM}/llvm-readelf", "-S", obj], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if sections.returncode != 0:
+        raise IsaCheckError(f"llvm-readelf cannot read {obj}: {sections.stderr.strip()[:200]}")
+    if ".hip_fatbin" not in sections.stdout:
+        return None                              # host-only object (no device code at all)
+    r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], stderr=subprocess.PIPE, text=True)
     if r.returncode != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
-        return None
+        raise IsaCheckError(f"{obj} has a .hip_fatbin section that llvm-objcopy could not extract: {r.stderr.strip()[:200]}")
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={fat}",
                            f"--output={co}", "--unbundle"])
     return co
@@ -85,7 +124,17 @@ def shift_amount_in_last_vgpr(obj, tmpdir=None):
             return []
         regs = kernel_registers(co)
         found = []
-        for kernel, run in disassembly(co):
+        runs = disassembly(co)
+        # every kernel of the code object (one `<name>.kd` descriptor symbol each) must have register metadata AND disassembled code:
+        # a metadata / symbol layout this parser does not understand must not turn the check into a silent pass
+        symtab = subprocess.run([f"{LLVM}/llvm-readelf", "-s", "-W", co], stdout=subprocess.PIPE, text=True, check=True).stdout
+        descriptors = sorted({m.group(1) for m in re.finditer(r"\s(\S+)\.kd\s*$", symtab, re.M)})
+        seen = {k for k, _ in runs}
+        missing = [k for k in descriptors if k not in regs or k not in seen]
+        if missing:
+            raise IsaCheckError(f"{obj}: kernels without register metadata or disassembly: {missing[:3]} (tool output layout changed?): "
+                                f"the shift-operand check cannot be made")
+        for kernel, run in runs:
             if kernel not in regs:
                 continue
             vgprs, agprs = regs[kernel]

@@ -50,14 +50,16 @@ class FrameTrainer:
     all-gather; implies optimizer).  optimizer: False | True (replicated fused RAdam when exchange != "sharded")."""
 
     def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None, spatial_lr_scale=1.0,
-                 force_collectives=False, async_forward=False):
+                 force_collectives=False, async_forward=None):
         """lrs: overrides of the reference table reference_lrs(spatial_lr_scale).
-        sliced (default: on whenever a replicated optimizer runs): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from the
-        attribute backward through the exchange (all-gather of the ranks' windows) into ex4d_radam_step_sliced -- no 196 MB zero fill,
-        no dense read, 16 MB per rank on the wire instead of 196.
+        sliced (default: on whenever an optimizer runs, replicated or sharded): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from
+        the attribute backward through the exchange into ex4d_radam_step_sliced -- no 196 MB zero fill, no dense read.  Replicated
+        optimizer: all-gather of the ranks' windows (16 MB per rank sent instead of 196); sharded optimizer: the keyframe tensors are
+        sharded by rows and one all-to-all hands every owner the rows of every rank's window (dist.SliceRowExchange: 14 MB sent per rank
+        at 8 ranks).
         force_collectives: issue the exchange's collectives even in a process group of one rank (dist.py: the RCCL-native branches
         run and are checked on a one-GPU box).
-        async_forward (single rank, exchange "none"): the rasterizer forward runs asynchronously (no instance-count read-back:
+        async_forward (default: ON for a single rank with exchange "none", off otherwise): the rasterizer forward runs asynchronously (no instance-count read-back:
         include/ex4d_rasterizer.h Ex4dParams.instance_capacity, under an AsyncFrames policy of the trainer's own); the frame's status is looked at once, right before its gradients are applied, and a frame that overflowed its
         capacity is RE-RUN first -- the parameters are those of the synchronous path.  `replays` counts such re-runs."""
         assert exchange in ("none", "allreduce", "sharded")
@@ -82,11 +84,12 @@ class FrameTrainer:
         self.exchange = None
         # one gradient window per rank reaches ex4d_radam_step_sliced: more ranks than it takes windows -> dense keyframe gradients
         from .optim import MAX_WINDOWS
-        gather_world = self.world if self.mode == "allreduce" else 1      # exchange "none": nothing is summed over ranks, keyframes included
+        gather_world = self.world if self.mode in ("allreduce", "sharded") else 1      # exchange "none": nothing is summed over ranks, keyframes included
         fits = gather_world <= MAX_WINDOWS
-        self.sliced = (bool(optimizer) and self.mode != "sharded" and model.num_dynamic > 0 and fits) if sliced is None else bool(sliced)
-        if self.sliced and (self.mode == "sharded" or not optimizer):
-            raise ValueError("sliced keyframe gradients need the replicated optimizer (the sharded one and plain gradient output are dense)")
+        has_opt = bool(optimizer) or self.mode == "sharded"
+        self.sliced = (has_opt and model.num_dynamic > 0 and fits) if sliced is None else bool(sliced)
+        if self.sliced and not has_opt:
+            raise ValueError("sliced keyframe gradients need an optimizer in the step (plain gradient output is dense)")
         if self.sliced and not fits:
             raise ValueError(f"sliced keyframe gradients take one window per rank, at most {MAX_WINDOWS}")
         self.kf_idx = [self.names.index(n) for n in attr.SLICED_SHAPES] if self.sliced else []
@@ -95,14 +98,16 @@ class FrameTrainer:
             for i in self.kf_idx:
                 shape = (self.params[i].shape[0],) + attr.SLICED_SHAPES[self.names[i]]
                 self.pgrad[i] = torch.zeros(shape, dtype=torch.float32, device=self.device)
-                self.kf_gather.append(xdist.SliceGather(shape, self.device, group=group, local_only=(self.mode != "allreduce"), force=force))
+                if self.mode != "sharded":      # replicated optimizer: every rank needs every window (all-gather); sharded: row all-to-all inside ShardedRAdam
+                    self.kf_gather.append(xdist.SliceGather(shape, self.device, group=group, local_only=(self.mode != "allreduce"), force=force))
         # two exchanges: the four feature gradients (3/4 of the bytes) leave the rasterizer backward and are on the wire while the
         # attribute backward still runs; the other parameters follow it
         self.feat_pos = [i for i in self.feature_idx]
         self.rest_pos = [i for i in range(len(self.params)) if i not in self.kf_idx and i not in self.feature_idx]
         self.exchange_feat = None
         if self.mode == "sharded":
-            self.opt = xdist.ShardedRAdam(self.params, self.lrs, group=group, nan_to_num=[n in NAN_TO_NUM for n in self.names], force=force)
+            self.opt = xdist.ShardedRAdam(self.params, self.lrs, group=group, nan_to_num=[n in NAN_TO_NUM for n in self.names], force=force,
+                                          sliced={i: attr.SLICED_SHAPES[self.names[i]][0] for i in self.kf_idx})
             self.exchange = self.opt.exchange
         else:
             if self.mode == "allreduce":
@@ -113,7 +118,8 @@ class FrameTrainer:
                 self.v = [torch.zeros_like(p) for p in self.params]
                 self.steps = 0
         self.optimizer = bool(optimizer) or self.mode == "sharded"
-        self.async_forward = bool(async_forward)
+        # the non-blocking forward is what callers of this class get wherever the class can recover from an overflow by itself
+        self.async_forward = (self.mode == "none") if async_forward is None else bool(async_forward)
         self.replays = 0
         self._frame = self._last_args = None
         if self.async_forward:
@@ -147,6 +153,9 @@ class FrameTrainer:
                 self.exchange.wait()
             for gth in self.kf_gather:
                 gth.wait()
+            if self.mode == "sharded":
+                for ex in self.opt.row_exchange.values():
+                    ex.wait()
         if self.exchange is not None or self.kf_gather:
             if self.side is not None:
                 with torch.cuda.stream(self.side):
@@ -163,6 +172,8 @@ class FrameTrainer:
                 n += ex.bytes_on_wire()
         if self.world > 1:
             n += sum(g.bytes_on_wire() for g in self.kf_gather if not g.local_only)
+            if self.mode == "sharded":
+                n += sum(ex.bytes_on_wire() for ex in self.opt.row_exchange.values())
         return n
 
     def step(self, cam, bg, t, upstream, near=0.2, far=300.0):
@@ -180,7 +191,8 @@ class FrameTrainer:
     def _settle_frame(self):
         """async_forward: the pending frame's status; a frame whose tile lists were truncated is run again (with the capacity the policy
         has regrown) until it is whole -- before anybody consumes its gradients."""
-        for _ in range(3):
+        attempts = 0
+        while True:
             fr, self._frame = self._frame, None
             if fr is None:
                 return
@@ -188,9 +200,11 @@ class FrameTrainer:
             self._policy.poll()                     # (non-strict: counts the invalid frame, regrows the capacity, learns the flow flag)
             if fr.valid:
                 return
+            if attempts == 3:                       # the frame and three re-runs with regrown capacities were all truncated
+                raise RuntimeError(f"a frame stayed invalid after {attempts} re-runs (last: {fr.num_rendered} instances for a capacity of {fr.capacity})")
+            attempts += 1
             self.replays += 1
-            self._run_frame(*self._last_args)
-        raise RuntimeError("a frame overflowed its instance capacity three times in a row")
+            self._run_frame(*self._last_args)       # leaves the re-run's pending status in self._frame: validated by the next turn of the loop
 
     def _run_frame(self, cam, bg, t, upstream, near, far):
         m = self.model
@@ -235,18 +249,21 @@ class FrameTrainer:
             for gth in self.kf_gather:
                 gth.wait()
             gout = attr.backward_raw(scal, self.params, (gin[0], gin[1], gin[2], gin[3], None), with_shs=False, out=self.pgrad, sliced=self.sliced)
+            windows = None
             if self.sliced:
                 gout, hint = gout
                 self._hint = hint
                 for gth, i, first in zip(self.kf_gather, self.kf_idx, (hint[0], hint[2])):
                     gth.launch(gout[i], first)               # all-gather of this rank's window (a plain copy for one rank)
+                if self.mode == "sharded":                   # row all-to-all of the windows (inside the sharded optimizer)
+                    windows = {i: (gout[i], first) for i, first in zip(self.kf_idx, (hint[0], hint[2]))}
             grads = [fgrads[self.feature_idx.index(i)] if i in self.feature_idx else gout[i] for i in range(len(self.params))]
             self._grads = grads
             if self.exchange is not None:
                 if self.exchange_feat is not None:
                     self.exchange.launch([grads[i] for i in self.rest_pos])
-                else:                                      # sharded: one reduce-scatter over all 15 tensors
-                    self.exchange.launch([g for i, g in enumerate(grads) if i not in self.kf_idx])
+                else:                                      # sharded: one reduce-scatter over the dense tensors + the window all-to-all
+                    self.opt.launch_exchange(grads, windows)
         self.last = {"radii": radii}
         return out
 
@@ -257,8 +274,7 @@ class FrameTrainer:
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
         if self.mode == "sharded":
-            self.opt._grads = self._grads
-            self.opt.step()
+            self.opt.step()                                # (its exchange was launched by _run_frame: launch_exchange(grads, windows))
         else:
             from .optim import radam_step_raw, radam_step_sliced_raw
             self.steps += 1

@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "long: opt-in soak tests (minutes of GPU + oracle time): selected only by an expression that names them, e.g. -m \"gpu and long\"")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`long` tests are opt-in: `-m gpu` (what the driver runs) does not select them, `-m "gpu and long"` does."""
+    if "long" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason='opt-in: run with -m "gpu and long"')
+    for item in items:
+        if "long" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

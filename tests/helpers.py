@@ -209,9 +209,11 @@ REPORT = []          # one dict per compared case; conftest.py writes it to gpur
 GRAD_NAMES = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_ddir", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
 
 
-def gradient_errors(ob, gb, P):
+def gradient_errors(ob, gb, P, rows=None):
     """Per returned gradient tensor: max-abs error, the tensor's max magnitude, their ratio (the number the 1e-5 bar applies to:
-    max-abs relative to max(1, |reference|_max) of that tensor) and the worst error relative to the row scale."""
+    max-abs relative to max(1, |reference|_max) of that tensor) and the worst error relative to the row scale.
+    rows (bool [P], optional): `frac_above_1e5` is taken over these rows only (the end-to-end comparison: rows whose modelled
+    forward-state allowance is negligible must still meet the plain bar)."""
     rep = {}
     for k in GRAD_NAMES:
         a, b = np.asarray(ob[k], dtype=np.float64), to_np(gb[k]).astype(np.float64)
@@ -223,8 +225,11 @@ def gradient_errors(ob, gb, P):
         ref_max = float(np.abs(a2).max())
         row = np.maximum(np.abs(a2).max(1, keepdims=True), 1.0)
         scale = max(1.0, ref_max)
+        sel = err if rows is None else err[rows]
         rep[k] = dict(max_abs=float(err.max()), ref_max=ref_max, rel_to_tensor_max=float(err.max() / scale),
-                      frac_above_1e5=float((err > 1e-5 * scale).mean()), rel_to_row_scale=float((err / row).max()))
+                      frac_above_1e5=float((sel > 1e-5 * scale).mean()) if sel.size else 0.0, rel_to_row_scale=float((err / row).max()))
+        if rows is not None:
+            rep[k]["rows_in_frac"] = int(np.asarray(rows).sum())
     return rep
 
 
@@ -386,10 +391,15 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
     cancel = CANCEL_EPS * eps * ob["cmag13"] if ob.get("cmag13") is not None else 0.0
     tol = atol + k_eps * eps * ob["abs13"] + cancel + 3e-6 * np.abs(ob["sum13"])
     extra_t = {}
+    plain_rows = None
+    # what each ALLOWANCE on top of the plain bar (1e-5 + k_eps half-ulps of sum|terms| + 3e-6 |sum|) is actually needed for is counted
+    # below (a bar that can only be loosened silently is not a bar): `rows_needing_cancel_term` / `rows_needing_state_term`
+    tol_plain = atol + k_eps * eps * ob["abs13"] + 3e-6 * np.abs(ob["sum13"])
     if extra13 is not None:
         extra13 = np.asarray(extra13, dtype=np.float64)
         rep["extra13_max"] = [float(x) for x in extra13.max(0)]
         rep["extra13_rows_above_atol"] = int((extra13.max(1) > atol).sum())
+        plain_rows = extra13.max(1) <= atol           # rows whose modelled allowance is below the absolute bar itself
         base_tol = tol
         tol = tol + extra13
         ex = propagated_tolerance(fwd_o, extra13)
@@ -404,13 +414,22 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
         rep["allowance_over_plain_bar_p50_p99"] = [float(x) for x in np.quantile((extra13 / base_tol).max(1), [0.5, 0.99])]
     rep["acc16_worst_ratio"] = float((err / tol).max())
     rep["acc16_max_abs"] = [float(x) for x in err.max(0)]
+    over_plain = (err > tol_plain).any(1)
+    over_cancel = (err > tol_plain + cancel).any(1)
+    rep["rows_needing_cancel_term"] = int((over_plain & ~over_cancel).sum())         # inside the bar only through CANCEL_EPS x cmag13
+    rep["rows_needing_state_term"] = int(over_cancel.sum())                           # inside the bar only through extra13 (end to end)
+    rep["rows_total"] = int(P)
+    # the allowances are for a handful of ill-conditioned rows, never for a systematic share of the Gaussians
+    # (round 4's 361 recorded comparisons: at most 4 of 1837 rows beyond the shared-state bar end to end, none at the BASELINE sizes)
+    assert rep["rows_needing_cancel_term"] <= max(3, 1e-3 * P), f"{rep['rows_needing_cancel_term']} of {P} rows need the cancellation allowance"
+    assert rep["rows_needing_state_term"] <= max(5, 5e-3 * P), f"{rep['rows_needing_state_term']} of {P} rows need the forward-state allowance"
     assert (err <= tol).all(), f"accumulators out of tolerance: worst ratio {rep['acc16_worst_ratio']}, at {np.unravel_index((err / tol).argmax(), err.shape)}"
     # reference for the returned gradients: the stage applied to the oracle's DOUBLE-precision sums (the oracle's own float32
     # outputs carry the rounding of its sequential float summation, up to the same order as the bound itself)
     ref = _stage(fwd_o, ob["sum13"])
     ref["dL_dmeans2D"], ref["dL_dcolors"] = ob["sum13"][:, 0:3], ob["sum13"][:, 7:10]
     ref["dL_dopacity"], ref["dL_ddir"] = ob["sum13"][:, 6:7], ob["sum13"][:, 10:13]
-    rep["grads"] = gradient_errors(ref, gb, P)
+    rep["grads"] = gradient_errors(ref, gb, P, rows=plain_rows)
     if noise is not None:
         # first check: the reference's own atomics-order noise floor (the hand-built bound below stays as the second check)
         dev = noise_floor(fwd_o, noise, ob["sum13"])
@@ -435,8 +454,9 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
         # (which the reference's own float32 stage has as well: the 4112 x 4112 / 30-px-footprint case sits at 1.7e-4 of the rotation
         # gradient's entries, everything else at 0) -- a handful of entries, never a systematic share
         bar_frac = frac_above_bar if k not in DERIVED else max(frac_above_bar, 5e-4 if r.get("stage_noise_max", 0.0) > 0 else frac_above_bar)
-        if extra13 is None:
-            assert r["frac_above_1e5"] <= bar_frac, f"{k}: {r['frac_above_1e5']:.2e} of the entries exceed 1e-5 x the tensor magnitude"
+        # (end to end: over the rows whose modelled forward-state allowance is itself below 1e-5 -- the others are bounded by the
+        # modelled bar above, and `extra13_rows_above_atol` says how many they are)
+        assert r["frac_above_1e5"] <= bar_frac, f"{k}: {r['frac_above_1e5']:.2e} of the entries exceed 1e-5 x the tensor magnitude"
         assert r["worst_err_over_bound"] <= 1.0, (f"{k}: error exceeds the propagated accumulator bound by x{r['worst_err_over_bound']:.2f} "
                                                   f"(max-abs {r['max_abs']:.3e}, tensor max {r['ref_max']:.3e})")
         bar = rel_tol * max(1.0, r["ref_max"]) + 8.0 * r.get("stage_noise_max", 0.0) + extra_t.get(k, 0.0)

@@ -95,6 +95,110 @@ def test_sharded_radam_and_gradient_exchange_gloo_world2(tmp_path):
         assert p.returncode == 0 and f"OK {r}" in o, o
 
 
+_WORKER4 = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from ex4dgs_amd import dist as xd
+from oracle import optim_oracle
+
+rank, world, local = xd.init_from_env(backend="gloo")
+assert world == 4
+# two keyframe tensors [rows, K, C] (rows not a multiple of the world size) whose gradients are WINDOWS of 4 / 2 time slices, and dense tensors
+K = 35
+shapes = [(1003, 3), (259, K, 3), (1003, 16, 3), (259, K, 4), (7,), (4099,)]
+SLICED = {1: 4, 3: 2}
+lrs = [1.6e-4, 1.6e-4, 2.5e-3, 1e-3, 1e-3, 5e-3]
+g0 = torch.Generator().manual_seed(11)
+init = [torch.randn(*s, generator=g0) for s in shapes]
+
+def frame(r, step):
+    # (dense gradients, {i: (window, first keyframe)}) of rank r's frame at this step; windows of different ranks overlap or not
+    g = torch.Generator().manual_seed(1000 * step + r)
+    dense = [torch.randn(*s, generator=g) * (0.1 + step) for s in shapes]
+    wins = {}
+    for i, count in SLICED.items():
+        first = (5 * step + 3 * r + i) % (K - count + 1) if step != 3 else 7          # step 3: all four windows coincide
+        wins[i] = (torch.randn(shapes[i][0], count, shapes[i][2], generator=g), first)
+    return dense, wins
+
+def dense_of(i, w, first):
+    d = torch.zeros(*shapes[i])
+    d[:, first:first + w.shape[1], :] = w
+    return d
+
+def oracle_step(items, betas, eps, device):
+    for p, g, m, v, n, lr, step, sanitize in items:
+        optim_oracle.radam_step(p.numpy(), g.numpy().copy(), m.numpy(), v.numpy(), step, lr, betas[0], betas[1], eps)
+
+def oracle_sliced(items, betas, eps, device):
+    # what ex4d_radam_step_sliced does: every element of the owned rows is updated, the gradient = the windows added in rank order
+    for p, m, v, rows, Kk, C, lr, step, wins, first_dev in items:
+        g = np.zeros((rows, Kk, C), np.float32)
+        assert len(wins) == world
+        for first, count, t in wins:
+            assert tuple(t.shape) == (rows, count, C)
+            g[:, first:first + count, :] += t.numpy()
+        optim_oracle.radam_step(p.numpy(), g.reshape(-1), m.numpy(), v.numpy(), step, lr, betas[0], betas[1], eps)
+
+params = [x.clone() for x in init]
+opt = xd.ShardedRAdam(params, lrs, step_fn=oracle_step, small_bytes=256, sliced=SLICED, sliced_step_fn=oracle_sliced)
+# the keyframe tensors are sharded by whole rows
+for i in SLICED:
+    lo, hi = opt.owned[i]
+    per = shapes[i][1] * shapes[i][2]
+    assert lo % per == 0 and hi % per == 0 and (hi - lo) // per in (259 // 4, 259 - 3 * (259 // 4))
+STEPS = 5
+for step in range(1, STEPS + 1):
+    dense, wins = frame(rank, step)
+    opt.launch_exchange(dense, windows=wins)
+    opt.step()
+# replicated dense reference: the dense gradients the windows stand for, summed in rank order, whole tensors
+ref = [x.clone() for x in init]
+m = [torch.zeros_like(x) for x in init]; v = [torch.zeros_like(x) for x in init]
+for step in range(1, STEPS + 1):
+    frames = [frame(r, step) for r in range(world)]
+    for i in range(len(ref)):
+        if i in SLICED:
+            # the windows are added per element in RANK ORDER (what ex4d_radam_step_sliced does): the reference is that sum, dense
+            gs = [dense_of(i, *frames[r][1][i]) for r in range(world)]
+            gsum = gs[0]
+            for r in range(1, world):
+                gsum = gsum + gs[r]
+        else:
+            # dense tensors: the sum IS the collective's (float addition is not associative: with more than two ranks the reference
+            # is the same collective on whole tensors -- what the replicated optimizer would be handed)
+            gsum = frames[rank][0][i].clone()
+            torch.distributed.all_reduce(gsum)
+        optim_oracle.radam_step(ref[i].numpy().reshape(-1), gsum.numpy().reshape(-1), m[i].numpy().reshape(-1), v[i].numpy().reshape(-1), step, lrs[i])
+for i, (a, b) in enumerate(zip(params, ref)):
+    assert torch.equal(a, b), (i, float((a - b).abs().max()))
+# wire volume of the windows: every rank sends only the rows it does not own
+for i, count in SLICED.items():
+    ex = opt.row_exchange[i]
+    assert ex.bytes_on_wire() == 4 * (259 - ex.my_rows) * count * shapes[i][2]
+# optimizer state of the keyframe tensors is sharded too
+assert opt.exp_avg[1].numel() == (opt.owned[1][1] - opt.owned[1][0]) < init[1].numel() // 3
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_sharded_radam_with_row_sharded_keyframe_windows_gloo_world4(tmp_path):
+    """the sharded optimizer with SLICED keyframe gradients (row-sharded windows, one all-to-all) equals the dense
+    replicated update bit for bit, in a world of four ranks (gloo, the oracle injected for the two HIP step functions)."""
+    script = tmp_path / "worker_dist4.py"
+    script.write_text(_WORKER4)
+    port = 33500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), h.ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o
+
+
 def test_shard_ranges_partition_every_tensor():
     from ex4dgs_amd.dist import shard_range
     for n in (0, 1, 7, 8, 31, 32, 33, 1000003, 9000000):

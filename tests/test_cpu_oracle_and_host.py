@@ -658,6 +658,37 @@ __global__ void k(float *out, const float *in, unsigned *mask)
     assert seen["dpp"] > 2000 and seen["trans"] > 200 and seen["valu_sgpr_writes"] > 1000 and seen["instructions"] > 50000, seen
 
 
+def test_machine_code_checks_fail_closed(tmp_path, monkeypatch):
+    """the checks must not turn into a silent pass when they cannot be made -- an object the tools cannot read, a kernel
+    whose register metadata the parser does not find, LLVM tools that are not where ROCm keeps them: each raises IsaCheckError (the
+    build stops); a host-only object has no device code and is simply skipped."""
+    import subprocess
+    from ex4dgs_amd import build, isa_check
+    junk = tmp_path / "junk.o"
+    junk.write_bytes(b"not an object file")
+    with pytest.raises(isa_check.IsaCheckError):
+        isa_check.shift_amount_in_last_vgpr(str(junk))
+    with pytest.raises(isa_check.IsaCheckError):
+        isa_check.wait_state_violations(str(junk))
+    host = tmp_path / "h.c"
+    host.write_text("int f(int x) { return x + 1; }\n")
+    subprocess.check_call(["gcc", "-c", str(host), "-o", str(tmp_path / "h.o")])
+    assert isa_check.shift_amount_in_last_vgpr(str(tmp_path / "h.o")) == []          # host-only: nothing to check
+    build.build()
+    obj = os.path.join(build.CSRC, "ex4d_binning.o")
+    monkeypatch.setattr(isa_check, "kernel_registers", lambda co: {})                 # a metadata layout the parser does not understand
+    with pytest.raises(isa_check.IsaCheckError, match="register metadata"):
+        isa_check.shift_amount_in_last_vgpr(obj)
+    monkeypatch.undo()
+    # the tool directory follows the ROCm installation (ROCM_PATH / the resolved hipcc), and a missing one is an error, not a skip
+    assert os.path.exists(os.path.join(isa_check._llvm_dir(), "llvm-objdump"))
+    monkeypatch.setenv("ROCM_PATH", str(tmp_path))
+    monkeypatch.setattr(isa_check.shutil, "which", lambda name: None)
+    monkeypatch.setattr(isa_check.os.path, "exists", lambda path: False)
+    with pytest.raises(isa_check.IsaCheckError, match="LLVM tools"):
+        isa_check._llvm_dir()
+
+
 # ------------------------------------------------------------------ C ABI library: builds, loads, exports
 def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     from ex4dgs_amd import build, _C
@@ -773,7 +804,7 @@ def test_integer_decisions_are_insensitive_to_fma_contraction():
     """The parity oracle is a NO-FMA evaluation (-ffp-contract=off); the reference binary is built by nvcc with contraction on
     (DGR/setup.py:21-29).  The same oracle source with gcc's contraction (-ffp-contract=fast -mfma) must take the same cull decisions
     and (all but a few in 1e5 of) the same radii / tile counts -- the error bar on "bit-exact against the reference binary".
-    Full corpus: tools/fma_sensitivity.py -> profiles/r02_fma_sensitivity.json (0 cull flips, 6 radii, 1 tile count in 1.05 M visible)."""
+    Full corpus: tools/fma_sensitivity.py -> profiles/archive/r02_fma_sensitivity.json (0 cull flips, 6 radii, 1 tile count in 1.05 M visible)."""
     import runpy
     mod = runpy.run_path(os.path.join(h.ROOT, "tools", "fma_sensitivity.py"), run_name="fma_sensitivity")
     from oracle import oracle

@@ -102,6 +102,10 @@ assert sh.state_bytes() < 0.6 * 8 * sum(p.numel() for p in A)
 # (3) the trainer's own sharded mode runs end to end and keeps the ranks' parameters identical
 m2, _, _ = make_scene("cfg3", P=20000, device="cuda", fused=True)
 tr2 = FrameTrainer(m2, exchange="sharded", lrs={n: 1e-6 for n in PARAM_ORDER})    # unrectified first RAdam steps move by lr * gradient
+# round 5: the sharded optimizer takes SLICED keyframe gradients too -- the two keyframe tensors are sharded by rows, the ranks' windows
+# travel by one all-to-all each (dist.SliceRowExchange) and never become dense tensors
+assert tr2.sliced and sorted(tr2.opt.row_exchange) == sorted(tr2.kf_idx) and len(tr2.kf_idx) == 2 and not tr2.kf_gather
+p2_before = [p.clone() for p in m2.parameters()]
 for k in range(3):
     tr2.step(cam, bg, stamps[(2 * k + rank) % len(stamps)], up)
 tr2.flush(); torch.cuda.synchronize()
@@ -122,6 +126,13 @@ for name, p in zip(PARAM_ORDER, m3.parameters()):
     q = p.clone()
     torch.distributed.broadcast(q, src=0)
     assert torch.equal(p, q) and torch.isfinite(p).all(), name
+# the sharded + sliced run of (3) and this replicated + sliced run saw the same frames with the same learning rates: the same parameter
+# movement up to the order of the rasterizer's float atomics
+for name, a0, a, b in zip(PARAM_ORDER, p2_before, m2.parameters(), m3.parameters()):
+    da, db = a - a0, b - a0
+    scale = float(db.abs().max())
+    assert float((da - db).abs().max()) <= 2e-3 * scale + 1e-12, (name, float((da - db).abs().max()), scale)
+assert tr2.exchange_bytes_on_wire() < tr3.exchange_bytes_on_wire() + 1
 assert tr3.kf_gather[0].bytes_on_wire() == 4 * m3.num_dynamic * 12 and tr3.exchange.bytes_on_wire() < 4 * sum(p.numel() for p in m3.parameters()) - 4 * m3.num_dynamic * 35 * 7 + 1
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 print("OK", rank)

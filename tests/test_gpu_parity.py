@@ -60,6 +60,13 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     # not absorbed into a wider bar: the oracle's backward takes the measured per-pixel state differences and returns the first-order
     # bound on what they move per accumulator (state13); the bars are the shared-state ones (1e-5, 64 half-ulps) + 2 x state13.
     dstate = [np.abs(o[k].astype(np.float64) - h.to_np(g[k]).astype(np.float64)).astype(np.float32).reshape(H, W) for k in ("depth", "acc", "final_T")]
+    # the allowance is computed from the MEASURED state difference, so that difference is capped first (otherwise a larger
+    # forward error would buy a wider backward bar): on the pixels that carry gradients it must be inside the forward's own 1e-5 bar
+    solid_np = solid.numpy().reshape(H, W)
+    rep["state_delta_max"] = {k: float((d * solid_np).max()) for k, d in zip(("depth", "acc", "final_T"), dstate)}
+    for k, d in zip(("depth", "acc", "final_T"), dstate):
+        cap = 1e-5 * max(1.0, float(np.abs(o[k]).max()))
+        assert float((d * solid_np).max()) <= cap, f"forward state {k} differs by {float((d * solid_np).max()):.3e} (> {cap:.1e}) on non-fragile pixels: no backward allowance is derived from that"
     ob_e2e = oracle.backward(o, *grads, state_delta=dstate)
     rep["e2e"] = h.compare_backward(ob_e2e, gb, o, extra13=2.0 * ob_e2e["state13"], tag=f"{cfg if isinstance(cfg, str) else cfg.name} P={o['P']} t={t} END-TO-END")
     # per-Gaussian backward stage in isolation: feed the GPU's own accumulators to the oracle's stage
@@ -802,6 +809,18 @@ def test_randomised_parity_sweep(hip_lib, n, seed, dir_scale):
     forward walk serves; round 3 ran that sweep outside the suite and had one case above the un-modelled end-to-end bar."""
     from tests import fuzz_sweep
     fails = fuzz_sweep.run(n, seed, dir_scale)
+    assert not fails, "\n".join(fails)
+
+
+@pytest.mark.gpu
+@pytest.mark.long
+@pytest.mark.parametrize("seed,dir_scale", [(11, 0.1), (12, 0.0), (13, 0.0)])
+def test_randomised_parity_sweep_long(hip_lib, seed, dir_scale):
+    """The 300 extra random scenes of round 4 (seeds 11-13, 100 each) as a committed, opt-in test:
+    `python -m pytest tests -m "gpu and long"`.  Its per-case numbers land in gpurun_out/parity_report.json like every other
+    comparison (round 5's run: profiles/r05_long_sweep_report.json)."""
+    from tests import fuzz_sweep
+    fails = fuzz_sweep.run(100, seed, dir_scale, verbose=False)
     assert not fails, "\n".join(fails)
 
 

@@ -231,8 +231,9 @@ def test_frame_trainer_asynchronous_forward_replays_and_matches_the_synchronous_
     p0 = {n: getattr(ma, n).clone() for n in ma.PARAM_NAMES}
     up = lambda out: ([l1_ssim_loss(out["render"], gt, 0.2)[0]], [None])
     try:
-        fa = FrameTrainer(ma, optimizer=True, lrs=lrs)
-        fb = FrameTrainer(mb, optimizer=True, lrs=lrs, async_forward=True)
+        fa = FrameTrainer(ma, optimizer=True, lrs=lrs, async_forward=False)
+        fb = FrameTrainer(mb, optimizer=True, lrs=lrs)              # round 5: the asynchronous forward is the DEFAULT of a single-rank trainer
+        assert fb.async_forward and not fa.async_forward
         with torch.no_grad():
             for m in (ma, mb):
                 m._scaling -= 3.0; m._scaling_motion -= 3.0

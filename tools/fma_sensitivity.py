@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""How much do the INTEGER decisions of the path depend on FMA contraction?   (CPU only; writes profiles/r02_fma_sensitivity.json)
+"""How much do the INTEGER decisions of the path depend on FMA contraction?   (CPU only; writes profiles/archive/r02_fma_sensitivity.json)
 
 The parity oracle (oracle/ex4d_oracle.c) is compiled with -ffp-contract=off and the HIP preprocess kernel likewise, so "bit-exact
 integers" means bit-exact against a NO-FMA evaluation of the reference's expressions.  The reference itself is built by nvcc with
@@ -94,7 +94,7 @@ def main():
                     "for nvcc -fmad=true of the reference build): counts of decisions / bit patterns that differ over the parity corpus",
                corpus=f"{n_fuzz} random scenes of tools/dev/fuzz_parity.py (seed 0) + cfg2 at 100k + cfg3 generator at 250k + cfg5 generator at 60k",
                totals=tot, large_cases=[c for c in per_case if not c["name"].startswith("fuzz")])
-    with open(os.path.join(ROOT, "profiles", "r02_fma_sensitivity.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "archive", "r02_fma_sensitivity.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(tot, indent=1))
 
