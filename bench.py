@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--async-frames", action="store_true", help="N = 1 rasterizer steps with the ASYNCHRONOUS forward (no instance-count read-back: Ex4dParams.instance_capacity)")
     ap.add_argument("--graph", action="store_true", help="N = 1: forward + backward (asynchronous forward, raw C-ABI mirror calls) captured into ONE hipGraph and replayed per step")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
+    ap.add_argument("--sync-forward", action="store_true", help="training-core steps: the trainer's rasterizer forward with the blocking instance-count read-back (default: asynchronous where the trainer can re-run a frame itself)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="tuning / A-B runs: any library option of ex4d_set_option, e.g. --set depth_sort_msd=0 (the 3-pass LSD depth sort)")
     args = ap.parse_args()
 
@@ -487,7 +488,8 @@ def main():
         if world == 1 and args.optimizer == "sharded":
             exchange = "sharded"
         tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if args.dense_keyframe_grads else None),
-                          lrs={n: 1e-7 for n in model.PARAM_NAMES})       # tiny learning rates: the synthetic scene stays put
+                          lrs={n: 1e-7 for n in model.PARAM_NAMES},       # tiny learning rates: the synthetic scene stays put
+                          async_forward=(False if args.sync_forward else None))
 
         def step(i):
             return tr.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)["render"]

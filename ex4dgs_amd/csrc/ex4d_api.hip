@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -16,7 +17,13 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 std::atomic<int> g_bwd_variant{4};
 std::atomic<int> g_tile_ids{0};
-std::atomic<int> g_depth_msd{2};     // "depth_sort_msd": MSD-first depth sort with the buckets finished in LDS (default) or the 3-pass LSD sort (0)
+// "depth_sort_msd": 0 (default) = the 3-pass LSD depth sort + gathering tile scan; 2 = the MSD-first depth sort of round 5 (one partition on the
+// top digit of the occupied key range, every bucket finished in LDS, tile scan fused in: 5 launches instead of 10, -22 us of kernel time at
+// 1.0 M Gaussians with well-spread depths); 1 = the same with the streaming tile-scan kernel.  NOT the default: its bucket kernel sorts a
+// bucket of more than 4096 / 8192 Gaussians with ONE workgroup through global memory -- a large surface at one depth (a fronto-parallel
+// wall: tens of thousands of Gaussians inside 0.3 % of the depth range) costs hundreds of microseconds there, and on the slower boxes of
+// the pool its five kernels lose to the LSD passes even on the bench scene ("Round 5")
+std::atomic<int> g_depth_msd{0};
 std::atomic<int> g_depth_local_cap{0};      // "depth_sort_local_cap": largest bucket the MSD depth sort finishes in LDS (0 = the kernel's capacity; tests force the through-memory path with a small value)
 std::atomic<int> g_depth_local_threads{0};  // "depth_sort_local_threads": 256 / 512 = workgroup size of the depth sort's bucket kernel, 0 = by Gaussian count
 std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
@@ -142,10 +149,11 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_vals_a = c.take<uint32_t>(P);
     g.rects4_b = c.take<uint32_t>(P);
     g.bucket_starts = c.take<uint32_t>((size_t)1 << EX4D_DLS_MSD_BITS);
+    g.key_ranges = c.take<uint2>(((size_t)P + 63) / 64);
     g.bucket_sums = c.take<uint32_t>((size_t)1 << EX4D_DLS_MSD_BITS);
     g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
-    g.total = c.take<uint32_t>(64);       // [1] prefilter violation flag, followed by the per-chunk instance counts
+    g.total = c.take<uint32_t>(EX4D_FLAG_WORDS);       // [1] prefilter violation flag, followed by the per-chunk instance counts
     g.block_totals = c.take<uint32_t>((P + 63) / 64);        // instance count of every 64-Gaussian chunk
     g.sh_dsums = c.take<float>(9 * (size_t)P);
     l.total = c.off;
@@ -272,18 +280,9 @@ static int forward_impl(
     }
     const bool packed_rects = gx <= 255 && gy <= 255;       // the tile scan gathers 32-bit packed rects (L2-resident) instead of the 8-byte ones
     // MSD-first depth sort (round 5; ex4d_binning.hip: depth_local_sort_kernel): applies when the rects travel packed and the key bits
-    // under the top digit fit its LDS word.  The invisible Gaussians get a key whose top digit is theirs alone -- one past the digit of
-    // the largest visible key (still behind every visible key: the order is the same)
-    bool msd_depth = g_depth_msd.load(std::memory_order_relaxed) != 0 && packed_rects && key_bits < 32;
-    uint32_t inv_digit = 0;
-    if (msd_depth) {
-        const uint32_t span = key_invisible - 1u;          // the largest visible key
-        int kb = key_bits, rem = ex4d_depth_sort_msd_rem(kb);
-        inv_digit = (span >> rem) + 1u;
-        if (inv_digit >= (1u << EX4D_DLS_MSD_BITS)) { kb++; rem = ex4d_depth_sort_msd_rem(kb); inv_digit = (span >> rem) + 1u; }
-        if (kb < 32 && ex4d_depth_sort_msd_applies((uint32_t)P, kb)) { key_bits = kb; key_invisible = inv_digit << rem; }
-        else msd_depth = false;
-    }
+    // under the top digit fit its LDS word.  Its top digit is cut from the key range the frame's visible Gaussians occupy (the
+    // per-Gaussian kernel leaves that range in the frame flags), the invisible key gets the last digit to itself
+    const bool msd_depth = g_depth_msd.load(std::memory_order_relaxed) != 0 && packed_rects && ex4d_depth_sort_msd_applies((uint32_t)P, key_bits);
     // the LSD sort ping-pongs between the (a) and (b) pairs and has to end in (a) = depth_order: start in (b) for an odd pass count
     const bool start_in_b = (ex4d_radix_passes((uint32_t)P, key_bits) & 1) != 0;
     uint32_t *keys0 = start_in_b ? g.sort_keys_b : g.sort_keys_a, *vals0 = start_in_b ? g.sort_vals_b : g.depth_order;
@@ -297,7 +296,8 @@ static int forward_impl(
     if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
-                                     keys0, vals0, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream), prm, stream);
+                                     keys0, vals0, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream,
+                                     msd_depth ? reinterpret_cast<uint32_t *>(g.key_ranges) : nullptr), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
@@ -314,8 +314,8 @@ static int forward_impl(
     // bucket sums; duplicate_kernel adds the bucket bases): no scan kernel at all.  1: the streaming scan kernel.
     const bool fused_scan = msd_depth && g_depth_msd.load(std::memory_order_relaxed) == 2;
     if (msd_depth) {
-        STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_bits, inv_digit,
-                                  g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
+        STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_invisible,
+                                  g.total, g.key_ranges, g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
                                   fused_scan ? g.sorted_offsets : nullptr, fused_scan ? g.bucket_sums : nullptr, T, fused_scan ? im.ranges : nullptr,
                                   g_depth_local_threads.load(std::memory_order_relaxed)), prm, stream);
         MARK(0, "depth_sort");
@@ -347,7 +347,15 @@ static int forward_impl(
         has_flow = prm->assume_no_flow == 0;
     } else {
         // 4. wait for the read-back only (not for the sort / scan kernels queued behind it)
-        HIP_TRY(hipEventSynchronize(g_readback.ev));
+        {   // (busy-wait on the event instead of a blocking synchronise: the copy lands while the depth sort runs, and every microsecond
+            // between its landing and the launches below is a microsecond the GPU may run dry)
+            static const bool spin = []{ const char *e = getenv("EX4D_READBACK_SPIN"); return e ? atoi(e) != 0 : true; }();
+            if (spin) {
+                hipError_t q;
+                while ((q = hipEventQuery(g_readback.ev)) == hipErrorNotReady) { }
+                HIP_TRY(q);
+            } else HIP_TRY(hipEventSynchronize(g_readback.ev));
+        }
         uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
         for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
         has_flow = g_readback.host[2] != 0u;      // frame flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
@@ -372,7 +380,7 @@ static int forward_impl(
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
         // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
         STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, b.tile_ids, b.vals_tmp, R, stream,
-                                    fused_scan ? g.sort_keys_b : nullptr, ex4d_depth_sort_msd_rem(key_bits), g.bucket_sums, g.total), prm, stream);
+                                    fused_scan ? g.sort_keys_b : nullptr, g.total + EX4D_FLAG_DPARAMS, g.bucket_sums, g.total), prm, stream);
         if (async && fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         MARK(0, "duplicate");
         STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
@@ -382,7 +390,7 @@ static int forward_impl(
     } else {
         if (R > 0) {
             STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, k0, v0, R, stream,
-                                        fused_scan ? g.sort_keys_b : nullptr, ex4d_depth_sort_msd_rem(key_bits), g.bucket_sums, g.total), prm, stream);
+                                        fused_scan ? g.sort_keys_b : nullptr, g.total + EX4D_FLAG_DPARAMS, g.bucket_sums, g.total), prm, stream);
             if (async && fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
             MARK(0, "duplicate");
             bool res_a = true;

@@ -113,6 +113,72 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t nblocks, uin
     if (threadIdx.x == 0) hist[(size_t)bins * nblocks + blockIdx.x] = carry_s;
 }
 
+// ---- top digit of the MSD depth sort (round 5).  The digit is cut from the key range the frame's visible Gaussians OCCUPY
+// (dparams = {kmin, shift, invisible key}: derived by dls_range_kernel from the per-wave ranges the per-Gaussian kernel left):
+//   digit(key) = (key - kmin) >> shift  in [0, BINS - 2]   for a visible Gaussian,   BINS - 1 for the invisible key
+// -- cut from the static [min_depth, max_depth] a scene inside a narrow depth band landed in a handful of buckets.
+struct DlsParams { uint32_t kmin, shift, inv_key; };
+__device__ __forceinline__ DlsParams dls_params(const uint32_t *__restrict__ dparams) { return { dparams[0], dparams[1], dparams[2] }; }
+__device__ __forceinline__ uint32_t dls_digit(uint32_t key, const DlsParams &q, uint32_t bins) { return key == q.inv_key ? bins - 1u : (key - q.kmin) >> q.shift; }
+
+// the frame's key range from the per-wave pairs the per-Gaussian kernel left -> dparams (one workgroup; P / 64 pairs = 125 KB at 1.0 M)
+__global__ __launch_bounds__(1024) void dls_range_kernel(const uint2 *__restrict__ wave_ranges, uint32_t nwaves, uint32_t inv_key, uint32_t bins,
+    uint32_t *__restrict__ dparams)
+{
+    __shared__ uint32_t s_max[16], s_nmin[16];
+    uint32_t kmax = 0u, nkmin = 0u;
+    for (uint32_t base = 0; base < nwaves; base += 16u * 1024u) {          // 16 loads in flight per thread: one memory round trip up to 1.0 M Gaussians
+        uint2 p[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const uint32_t i = base + j * 1024u + threadIdx.x; p[j] = i < nwaves ? wave_ranges[i] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int j = 0; j < 16; j++) { kmax = p[j].x > kmax ? p[j].x : kmax; nkmin = p[j].y > nkmin ? p[j].y : nkmin; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(nkmin, o, 64);
+        kmax = a > kmax ? a : kmax; nkmin = b > nkmin ? b : nkmin;
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = kmax; s_nmin[threadIdx.x >> 6] = nkmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; w++) { kmax = s_max[w] > kmax ? s_max[w] : kmax; nkmin = s_nmin[w] > nkmin ? s_nmin[w] : nkmin; }
+        uint32_t kmin = ~nkmin, shift = 0;
+        if (kmax == 0u) kmin = 0u;           // no visible Gaussian at all
+        else {
+            const uint32_t range = kmax - kmin;
+            while ((range >> shift) > bins - 2u) shift++;
+        }
+        dparams[0] = kmin; dparams[1] = shift; dparams[2] = inv_key; dparams[3] = 0u;
+    }
+}
+
+template <int ITEMS, int BINS>
+__global__ __launch_bounds__(RS_THREADS) void dls_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t nblocks,
+    uint32_t *__restrict__ hist, const uint32_t *__restrict__ dparams)
+{
+    __shared__ uint32_t h[BINS];
+    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) h[b] = 0;
+    __syncthreads();
+    const DlsParams q = dls_params(dparams);
+    const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
+    if (base < n) {
+        uint32_t k[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const uint32_t i = base + it * RS_THREADS + threadIdx.x;
+            k[it] = keys[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const uint32_t i = base + it * RS_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[dls_digit(k[it], q, BINS)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < BINS; b += RS_THREADS) hist[(size_t)b * nblocks + blockIdx.x] = h[b];
+}
+
 // Scatter pass.  A block owns RS_CHUNK consecutive items; wave w owns the w-th quarter of them and walks it in
 // rounds of 64 consecutive items, so the stable order inside the block is (wave, round, lane).
 //  phase 1  each wave ranks its items against its own running per-digit counters (wave-private LDS, wave64
@@ -167,7 +233,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
     int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges, const uint32_t *__restrict__ n_dev,
-    const uint32_t *__restrict__ rects_in = nullptr, uint32_t *__restrict__ rects_out = nullptr, uint32_t *__restrict__ bucket_starts = nullptr)
+    const uint32_t *__restrict__ rects_in = nullptr, uint32_t *__restrict__ rects_out = nullptr, uint32_t *__restrict__ bucket_starts = nullptr,
+    const uint32_t *__restrict__ dparams = nullptr)
 {
     if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }      // (see rs_histogram_kernel)
     if (MODE != 2 && blockIdx.x * (uint32_t)(RS_THREADS * ITEMS) >= n) return;      // behind the last item (uniform: the whole workgroup)
@@ -181,6 +248,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     if (NBITS > 0) nbits = NBITS;
     const uint32_t mask = (1u << nbits) - 1u;
     const int nbins = 1 << nbits;
+    // MODE 3: the digit of the MSD depth sort (dls_digit); every other mode: bits [shift, shift + nbits) of the key
+    DlsParams dq = { 0u, 0u, 0u };
+    if (MODE == 3) dq = dls_params(dparams);
+    auto digit_of = [&](uint32_t k) -> uint32_t { return MODE == 3 ? dls_digit(k, dq, (uint32_t)BINS) : ((k >> shift) & mask); };
     for (int i = lane; i < BINS; i += 64) wave_cnt[wave][i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -213,7 +284,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
         const bool valid = i < block_end;
-        const uint32_t d = (key[it] >> shift) & mask;
+        const uint32_t d = digit_of(key[it]);
         // lanes holding the same digit: per bit keep the ballot if my bit is set, its complement otherwise -- written as
         // ballot ^ (bit - 1) on 32-bit halves (plain xor/and; a select here compiles to the VOP2 v_cndmask that issues in ~24
         // cycles on gfx950 and made this loop the most expensive part of the pass)
@@ -304,7 +375,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * 64 + lane;
         if (i < block_end) {
-            const uint32_t d = (key[it] >> shift) & mask;
+            const uint32_t d = digit_of(key[it]);
             stage[wave_cnt[wave][d] + pos[it]] = make_uint2(key[it], val[it]);
             if constexpr (MODE == 3) stage_r[wave_cnt[wave][d] + pos[it]] = rct[it];
         }
@@ -314,7 +385,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 #pragma unroll 4
     for (uint32_t p = tid; p < count; p += RS_THREADS) {
         const uint2 kv = stage[p];
-        const uint32_t d = (kv.x >> shift) & mask;
+        const uint32_t d = digit_of(kv.x);
         const uint32_t dst = global_base[d] + (p - local_start[d]);
         if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; }
         if constexpr (MODE == 3) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; rects_out[dst] = stage_r[p]; }
@@ -468,7 +539,7 @@ __device__ __forceinline__ int dls_pass_bits(int rem, int lo, int npass, int pas
 // result has to end), Y = the same slice of the partition's input arrays
 template <int THREADS>
 __device__ __forceinline__ void dls_sort_through_memory(DlsLds<THREADS> &L, uint32_t *xk, uint32_t *xv, uint32_t *xr, uint32_t *yk, uint32_t *yv, uint32_t *yr,
-    uint32_t n, int rem)
+    uint32_t n, int rem, uint32_t kmin)
 {
     constexpr int DLS_WAVES = THREADS / 64, DLS_THREADS = THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -481,14 +552,14 @@ __device__ __forceinline__ void dls_sort_through_memory(DlsLds<THREADS> &L, uint
         const uint32_t mask = (1u << nbits) - 1u;
         for (int i = lane; i < 512; i += 64) L.cnt[wave][i] = 0;
         dls_wave_sync();
-        for (uint32_t i = wbase + lane; i < wend; i += 64) atomicAdd(&L.cnt[wave][(sk[i] >> lo) & mask], 1u);
+        for (uint32_t i = wbase + lane; i < wend; i += 64) atomicAdd(&L.cnt[wave][((sk[i] - kmin) >> lo) & mask], 1u);
         __syncthreads();
         dls_scan_counts(L, nbits);
         for (uint32_t base = wbase; base < wend; base += 64) {        // wave-uniform trip count, items in order
             const uint32_t i = base + lane;
             const bool valid = i < wend;
             const uint32_t k = valid ? sk[i] : 0u, v = valid ? sv[i] : 0u, r = valid ? sr[i] : 0u;
-            const uint32_t d = (k >> lo) & mask;
+            const uint32_t d = ((k - kmin) >> lo) & mask;
             const uint32_t dst = dls_rank<0>(L.cnt[wave], d, nbits, valid, lane);
             if (valid) { dk[dst] = k; dv[dst] = v; dr[dst] = r; }
         }
@@ -587,7 +658,7 @@ __device__ __forceinline__ void dls_lds_pass(DlsLds<THREADS> &L, uint32_t n, uin
 // grid resident at once); 512: <= 8192, 48 KB (more Gaussians per bucket: 2 M and up)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_sort_kernel(uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t *ka, uint32_t *va, uint32_t *ra,
-    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ totals, int rem, uint32_t inv_digit, uint32_t cap,
+    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ totals, const uint32_t *__restrict__ dparams, uint32_t cap,
     uint32_t *__restrict__ local_incl, uint32_t *__restrict__ bucket_sums, int T, uint2 *__restrict__ ranges)
 {
     constexpr int DLS_THREADS = THREADS, DLS_WAVES = THREADS / 64, DLS_CAP = THREADS * DLS_ITEMS, IDX_BITS = DlsLds<THREADS>::IDX_BITS;
@@ -597,13 +668,16 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_s
     // the zero-fill of the tile ranges (cudaMemset at CR/rasterizer_impl.cu:328) rides along here (it used to ride in the tile scan)
     if (ranges) for (int i = b * DLS_THREADS + tid; i < T; i += gridDim.x * DLS_THREADS) ranges[i] = make_uint2(0u, 0u);
     const uint32_t n = totals[b], s = starts[b];
+    const DlsParams dq = dls_params(dparams);
+    const int rem = (int)dq.shift;                        // key bits below the top digit: what is left to sort inside a bucket
+    const uint32_t inv_digit = gridDim.x - 1u;            // (one workgroup per digit)
     if (b == inv_digit || n == 0u) {                     // invisible Gaussians: already in id order, rect 0; nobody reads their offsets
         if (bucket_sums && tid == 0) bucket_sums[b] = 0u;
         return;
     }
     const bool sorted_already = n < 2u || rem == 0;      // (rem == 0: all keys of a bucket are equal, the partition was stable)
     if (sorted_already || n > cap) {
-        if (!sorted_already) { dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem); __threadfence(); __syncthreads(); }
+        if (!sorted_already) { dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem, dq.kmin); __threadfence(); __syncthreads(); }
         if (local_incl) {
             const uint32_t sum = dls_scan_from_memory(L, rb + s, local_incl + s, n);
             if (tid == 0) bucket_sums[b] = sum;
@@ -616,7 +690,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_s
 #pragma unroll
         for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; k[j] = p < n ? kb[s + p] : 0u; }
 #pragma unroll
-        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; if (p < n) L.buf[p] = ((k[j] & remmask) << IDX_BITS) | p; }
+        for (int j = 0; j < DLS_ITEMS; j++) { const uint32_t p = tid + j * DLS_THREADS; if (p < n) L.buf[p] = (((k[j] - dq.kmin) & remmask) << IDX_BITS) | p; }
     }
     __syncthreads();
     const int npass = (rem + 8) / 9;
@@ -744,13 +818,13 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
     const uint32_t *__restrict__ sorted_offsets, const uint32_t *__restrict__ block_sums,
     const uint2 *__restrict__ sorted_rects, const uint32_t *__restrict__ sorted_rects4,
     uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ vals, uint32_t cap,
-    const uint32_t *__restrict__ bucket_keys, int bucket_shift, const uint32_t *__restrict__ bucket_sums, int nbuckets, uint32_t *__restrict__ frame_total)
+    const uint32_t *__restrict__ bucket_keys, const uint32_t *__restrict__ dparams, const uint32_t *__restrict__ bucket_sums, int nbuckets, uint32_t *__restrict__ frame_total)
 {
     // cap: capacity of the output arrays -- the instance count itself (synchronous forward) or Ex4dParams.instance_capacity (an
     // instance count above it truncates the stream: the caller sees that in the frame status and re-runs the frame)
     // bucket_keys != nullptr (MSD depth sort with the scan fused into its bucket kernel, round 5): sorted_offsets holds the inclusive
     // scan INSIDE each depth bucket, bucket_sums the instance count of every bucket; the bucket of position k is the top digit of
-    // bucket_keys[k] (the partition's key output: all keys of a bucket's slice share it).  Every workgroup scans the <= 1024 bucket sums
+    // bucket_keys[k] (dls_digit; the partition's key output: all keys of a bucket's slice share it).  Every workgroup scans the <= 1024 bucket sums
     // itself (4 KB from L2) -- there is no tile-scan kernel on this path; workgroup 0 leaves the frame's instance count in frame_total.
     __shared__ DupRec s_rec[4][64];
     __shared__ uint32_t s_mark[4][64];
@@ -789,7 +863,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int gy, c
         // exclusive offset = inclusive scan value of the previous element (+ its scan chunk's base, below); bucket form: the bucket's
         // base + the Gaussian's own inclusive value - its count (no neighbour, no bucket-boundary case)
         if (!bucket_keys) off = (k == 0) ? 0u : sorted_offsets[k - 1];
-        else if (count != 0u) off = s_base[bucket_keys[k] >> bucket_shift] + sorted_offsets[k] - count;
+        else if (count != 0u) off = s_base[dls_digit(bucket_keys[k], dls_params(dparams), (uint32_t)nbuckets)] + sorted_offsets[k] - count;
     }
     // base of a scan chunk = sum of the chunk totals before it.  The (k-1) of a wave lie in at most two chunks; the wave sums
     // the few hundred totals itself instead of a one-workgroup scan kernel in between (one launch less)
@@ -911,40 +985,41 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
     return hipGetLastError();
 }
 
-// ---- MSD depth sort (depth_local_sort_kernel above): histogram / row scan / partition on the top DLS_MSD_BITS key bits, buckets in LDS.
+// ---- MSD depth sort (depth_local_sort_kernel above): histogram / row scan / partition on the top digit of (key - kmin), buckets in LDS.
 // (ka, va, ra): keys / ids / packed rects as the preprocess kernel wrote them (scratch afterwards); (kb, vb, rb): the result --
-// vb = Gaussian ids in depth order, rb = their packed rects in that order.  key_bits: significant bits of the keys; the invisible key
-// is inv_digit << (key_bits - DLS_MSD_BITS).  hist: ex4d_radix_hist_words(n) words; starts: 1 << DLS_MSD_BITS words.
-int ex4d_depth_sort_msd_rem(int key_bits) { return key_bits > EX4D_DLS_MSD_BITS ? key_bits - EX4D_DLS_MSD_BITS : 0; }
-bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits) { return n <= (1u << 26) && ex4d_depth_sort_msd_rem(key_bits) + DLS_IDX_BITS <= 32; }
-hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, int key_bits,
-    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
+// vb = Gaussian ids in depth order, rb = their packed rects in that order.  inv_key: the key of invisible Gaussians (above every
+// visible key); flags: the frame-flag words (the digit parameters land there); wave_ranges: the per-wave key ranges of the per-Gaussian kernel; hist: ex4d_radix_hist_words(n) words; starts: 1 << DLS_MSD_BITS words.
+// key_bits (host bound on the visible keys): the bits below the digit must fit the LDS word next to the arrival index
+bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits) { return n <= (1u << 26) && key_bits - (EX4D_DLS_MSD_BITS - 1) + DLS_IDX_BITS <= 32; }
+hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
+    uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
     uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads)
 {
     if (n == 0) return hipSuccess;
     constexpr int MB = EX4D_DLS_MSD_BITS, BINS = 1 << MB;
-    const int rem = ex4d_depth_sort_msd_rem(key_bits);
     const uint32_t nb = rs_blocks_for(n);
     const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
+    uint32_t *dparams = flags + EX4D_FLAG_DPARAMS;
+    hipLaunchKernelGGL(dls_range_kernel, dim3(1), dim3(1024), 0, stream, wave_ranges, (n + 63u) / 64u, inv_key, 1u << EX4D_DLS_MSD_BITS, dparams);
     if (local_threads != 256 && local_threads != 512) local_threads = n <= 1200000u ? 256 : 512;
     const uint32_t kcap = (uint32_t)local_threads * DLS_ITEMS;
     if (local_cap == 0 || local_cap > kcap) local_cap = kcap;
     if (small) {
-        hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, BINS, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, rem, (uint32_t)(BINS - 1), nb, hist, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL((dls_histogram_kernel<RS_SMALL_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, (const uint32_t *)dparams);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
-        hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, rem, MB, nb, hist,
-            0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts);
+        hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, 0, MB, nb, hist,
+            0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts, (const uint32_t *)dparams);
     } else {
-        hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, BINS, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, rem, (uint32_t)(BINS - 1), nb, hist, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL((dls_histogram_kernel<RS_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, (const uint32_t *)dparams);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
-        hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, rem, MB, nb, hist,
-            0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts);
+        hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, 0, MB, nb, hist,
+            0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts, (const uint32_t *)dparams);
     }
     if (local_threads == 256)
-        hipLaunchKernelGGL(depth_local_sort_kernel<256>, dim3(BINS), dim3(256), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, rem, inv_digit, local_cap,
+        hipLaunchKernelGGL(depth_local_sort_kernel<256>, dim3(BINS), dim3(256), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, (const uint32_t *)dparams, local_cap,
             local_incl, bucket_sums, T, ranges);
     else
-        hipLaunchKernelGGL(depth_local_sort_kernel<512>, dim3(BINS), dim3(512), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, rem, inv_digit, local_cap,
+        hipLaunchKernelGGL(depth_local_sort_kernel<512>, dim3(BINS), dim3(512), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, (const uint32_t *)dparams, local_cap,
             local_incl, bucket_sums, T, ranges);
     return hipGetLastError();
 }
@@ -996,11 +1071,11 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rec
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream,
-    const uint32_t *bucket_keys, int bucket_shift, const uint32_t *bucket_sums, uint32_t *frame_total)
+    const uint32_t *bucket_keys, const uint32_t *dparams, const uint32_t *bucket_sums, uint32_t *frame_total)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        sorted_rects, sorted_rects4, tile_keys, vals, cap, bucket_keys, bucket_shift, bucket_sums, 1 << EX4D_DLS_MSD_BITS, frame_total);
+        sorted_rects, sorted_rects4, tile_keys, vals, cap, bucket_keys, dparams, bucket_sums, 1 << EX4D_DLS_MSD_BITS, frame_total);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ struct GeomState {
     // scratch used only inside forward (not needed by backward)
     uint32_t *sort_keys_a, *sort_keys_b, *sort_vals_b;   // depth-sort ping-pong
     uint32_t *bucket_sums;                               // MSD depth sort with the fused tile scan: instance count of every depth bucket
+    uint2 *key_ranges;                                   // MSD depth sort: (max key, max ~key) of every 64-Gaussian chunk's visible Gaussians
     uint32_t *sort_vals_a, *rects4_b, *bucket_starts;    // MSD depth sort: the ids as preprocess wrote them, the packed rects in depth order, first position of every bucket
     uint32_t *scan_block_sums;                           // per-block totals of the tiles_touched scan
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
@@ -78,7 +79,8 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
-    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream);
+    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream,
+    uint32_t *key_range_slots = nullptr);      // key_range_slots: uint2[(P + 63) / 64] <- (max, max(~)) of every wave's visible depth keys (MSD depth sort)
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);
@@ -107,14 +109,16 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rec
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream,
-    const uint32_t *bucket_keys = nullptr, int bucket_shift = 0, const uint32_t *bucket_sums = nullptr, uint32_t *frame_total = nullptr);
+    const uint32_t *bucket_keys = nullptr, const uint32_t *dparams = nullptr, const uint32_t *bucket_sums = nullptr, uint32_t *frame_total = nullptr);
 
-// MSD-first depth sort (ex4d_binning.hip): one global partition on the top EX4D_DLS_MSD_BITS key bits, every bucket finished in LDS
+// MSD-first depth sort (ex4d_binning.hip): one global partition on the top digit of (key - smallest visible key), every bucket finished in LDS.
+// Frame-flag words used by it (GeomState::total): [EX4D_FLAG_DPARAMS ..+3] = {kmin, shift, invisible key, 0} written by its range kernel
 #define EX4D_DLS_MSD_BITS 10
-int ex4d_depth_sort_msd_rem(int key_bits);
+#define EX4D_FLAG_DPARAMS 8
+#define EX4D_FLAG_WORDS 64
 bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits);
-hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, int key_bits,
-    uint32_t inv_digit, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
+hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
+    uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
     uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads);       // local_incl / bucket_sums: the tile scan fused into the bucket kernel (nullptr = not)
 hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // ptr 16-byte aligned, bytes a multiple of 4 (a kernel, not hipMemsetAsync: ex4d_binning.hip)
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);

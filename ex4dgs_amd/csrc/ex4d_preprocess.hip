@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int32_t *__restrict__ radii, float4 *__restrict__ records, float *__restrict__ cov3Ds,
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
-    uint32_t *__restrict__ total_instances, const ShSplit sp_, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4)
+    uint32_t *__restrict__ total_instances, const ShSplit sp_, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4,
+    uint32_t *__restrict__ key_range_slots)
 {
     const int D = FAST ? 3 : D_, M = FAST ? 16 : M_;
     const float *__restrict__ cov3D_precomp = FAST ? nullptr : cov3D_precomp_;
@@ -565,6 +566,21 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         depth_key = __float_as_uint(p_view.z) - depth_key_base;
     } while (0);
 
+    // MSD depth sort (ex4d_binning.hip): the range [min, max] of the frame's VISIBLE depth keys, so that its top digit is cut from the
+    // range the frame occupies and not from [min_depth, max_depth] (a scene inside a narrow depth band would otherwise fall into a
+    // handful of buckets).  Every wave leaves (max key, max ~key) of its visible Gaussians, (0, 0) if it has none
+    if (key_range_slots) {
+        uint32_t kmax = visible ? depth_key : 0u, nkmin = visible ? ~depth_key : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(nkmin, o, 64);
+            kmax = a > kmax ? a : kmax; nkmin = b > nkmin ? b : nkmin;
+        }
+        // (one plain 8-byte store per wave; a one-workgroup kernel of the depth sort reduces the P / 64 pairs.  Measured instead, round 5:
+        // 2 atomics per wave into 2 x 64 slots +10 us on this kernel wherever they were issued; atomics only where a wave would raise
+        // its slot, the slot read first: +55 us -- the slot lines are a hot spot and every wave's first wait included them)
+        if (lane == 0) reinterpret_cast<uint2 *>(key_range_slots)[wc] = make_uint2(kmax, nkmin);
+    }
     // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
     float coefv[16][3];
     if (staged) {
@@ -1080,7 +1096,8 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *rotations, const float *opacities, const float *shs, const float *cov3D_precomp,
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
-    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream)
+    uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream,
+    uint32_t *key_range_slots)
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
@@ -1092,7 +1109,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation, \
         radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split, \
         (prm.prepare_backward && (shs != nullptr || is_split)) ? g.sh_dsums : (float *)nullptr, \
-        g_preprocess_tune.load(std::memory_order_relaxed), rects4
+        g_preprocess_tune.load(std::memory_order_relaxed), rects4, key_range_slots
     if (fast) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
 #undef PF_ARGS
