@@ -34,7 +34,7 @@ from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSetti
 from ex4dgs_amd.scene import CONFIGS, make_scene                                   # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
 SIMDS, CLOCK_HZ = 1024, 2.4e9        # 256 CUs x 4 SIMDs; a SIMD issues one wave64 VALU instruction per 4 cycles (MI355X_MICROARCH.md)
 RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
 

@@ -47,6 +47,7 @@ def parse_stats(path):
 ALIAS = [("composite_bwd_scan_kernel", "composite_bwd"), ("composite_bwd_kernel", "composite_bwd_per_pixel"), ("composite_fwd_kernel", "composite_fwd"),
          ("preprocess_geom_kernel", "preprocess_fwd"), ("preprocess_color_kernel", "preprocess_color"), ("preprocess_fwd_kernel", "preprocess_fwd"),
          ("preprocess_bwd_kernel", "preprocess_bwd"), ("duplicate_kernel", "duplicate"),
+         ("depth_local_sort_kernel", "depth_sort_bucket_pass"), ("dls_histogram_kernel", "depth_sort_msd_histogram"), ("dls_range_kernel", "depth_sort_key_range"),
          ("rs_scatter_kernel<16", "tile_sort_scatter_pass"), ("rs_scatter_kernel<8", "depth_sort_scatter_pass"),
          ("rs_histogram_kernel<16", "tile_sort_histogram_pass"), ("rs_histogram_kernel<8", "depth_sort_histogram_pass"),
          ("rs_scan_rows_kernel", "radix_row_scan"), ("tile_ranges_kernel", "tile_ranges"), ("scan_tiles_local_kernel", "scan_tiles"),
