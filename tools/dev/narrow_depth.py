@@ -28,8 +28,19 @@ def squeezed(P, z_lo, z_hi, seed=5):
 def main():
     build.build(); _C.load()
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    for name, z_lo, z_hi in (("bench range 4.5-80", 4.5, 80.0), ("8-12 m", 8.0, 12.0), ("5-5.5 m", 5.0, 5.5), ("one depth 7 m", 7.0, 7.0)):
+    for name, z_lo, z_hi in (("bench range 4.5-80", 4.5, 80.0), ("8-12 m", 8.0, 12.0), ("5-5.5 m", 5.0, 5.5), ("wall: 30 % at 10 m +- 1 cm", 4.5, 80.0), ("wall: 90 % at 6 m +- 2 mm", 4.5, 80.0),
+                             ("one depth 7 m", 7.0, 7.0)):
         ins, st = squeezed(P, z_lo, z_hi)
+        if name.startswith("wall"):
+            frac, zw, th = (0.3, 10.0, 0.01) if "30 %" in name else (0.9, 6.0, 0.002)
+            g = torch.Generator().manual_seed(3)
+            m = ins["means3D"].cpu()
+            on = torch.rand(P, generator=g) < frac
+            z = torch.where(on, zw + th * (2 * torch.rand(P, generator=g) - 1), m[:, 2])
+            sc = (z / m[:, 2]).unsqueeze(1)
+            m = m * sc; m[:, 2] = z
+            ins["means3D"] = m.contiguous().cuda()
+            ins["scales"] = (ins["scales"].cpu() * sc).contiguous().cuda()
         for mode in (2, 0):
             _C.set_option("depth_sort_msd", mode)
             for _ in range(3):
@@ -44,7 +55,7 @@ def main():
                     agg[k] = agg.get(k, 0.0) + ms / n
             _C.profile_enable(False)
             R = int(f[0])
-            print(f"{name:22s} P={P} R={R:9d} depth sort {'MSD (adaptive digit)' if mode == 2 else 'LSD 3 passes      '}: depth_sort {agg['depth_sort'] * 1e3:7.1f} us  scan_tiles {agg['scan_tiles'] * 1e3:6.1f} us  "
+            print(f"{name:28s} P={P} R={R:9d} depth sort {'MSD (adaptive digit)' if mode == 2 else 'LSD 3 passes      '}: depth_sort {agg['depth_sort'] * 1e3:7.1f} us  scan_tiles {agg['scan_tiles'] * 1e3:6.1f} us  "
                   f"forward {sum(agg.values()) * 1e3:7.1f} us", flush=True)
     _C.set_option("depth_sort_msd", 2)
 
