@@ -190,7 +190,11 @@ int ex4d_backward_split_sh(
 int ex4d_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                       float min_depth, float max_depth, uint8_t *present, void *stream);
 
-/* Sizes the allocation callbacks will be asked for (rasterizer_impl.h required<T>(N) equivalent). */
+/* Sizes the allocation callbacks will be asked for (rasterizer_impl.h required<T>(N) equivalent).
+ * Footprints: geometry ~180 B per Gaussian; binning 48 B per (Gaussian, tile) instance + histograms -- 16 B of sort arrays and 32 B of
+ * CAPACITY for the per-quadrant compacted lists the forward leaves for the backward (uint2[4 * num_rendered]: every entry of a tile list could
+ * survive the cull of each of its four quadrants; ~6 % is touched).  1.0 M Gaussians, 1352x1014, 7.5 M instances: 370 MB; the deep-overlap
+ * configuration (2048x1088, 31.5 M instances): 1.5 GB; with Ex4dParams.instance_capacity the capacity takes the place of num_rendered. */
 size_t ex4d_geom_bytes(int32_t P);
 size_t ex4d_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
 size_t ex4d_img_bytes(int32_t W, int32_t H);
@@ -205,7 +209,7 @@ typedef struct Ex4dGeomLayout {
     size_t clamped;         /* uint8[P]            bit c set <=> channel c clamped at 0 (forward.cu:67-69) */
     size_t tiles_touched;   /* uint32[P]           with option "geom_debug_arrays" = 1 only */
     size_t depth_order;     /* uint32[P]           Gaussian ids, stable-sorted by depth key (visible first) */
-    size_t sorted_offsets;  /* uint32[P]           block-local inclusive scan of tiles_touched in depth order */
+    size_t sorted_offsets;  /* uint32[P]           block-local inclusive scan of tiles_touched in depth order (option "depth_sort_msd" = 2: local to the depth bucket) */
     size_t rects;           /* uint2[P]            tile rect (getRect, auxiliary.h:46-56): .x = x0 | y0 << 16, .y = w | h << 16;
                                                    w * h == tiles_touched; defined for visible Gaussians */
     size_t total;
@@ -250,6 +254,19 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *   "geom_debug_arrays"      1 = also write Ex4dGeomLayout.cov3D and .tiles_touched; 0 (default) = those regions stay untouched: the
  *                            backward recomputes the covariance from scale / rotation (same function, same bits), the tile rect carries
  *                            the count.
+ *   "preprocess_fast_path"   1 (default) = frames with one [P,16,3] SH tensor at degree 3 and scale + rotation (no precomputed colours or
+ *                            covariances) take the per-Gaussian forward kernel specialised for exactly that; 0 = always the generic one.
+ *                            Bit-identical results.
+ *   "depth_sort_msd"         0 (default) = the Gaussians are ordered by depth with a 3-pass LSD radix sort, the tile scan gathers their rects;
+ *                            2 = MSD-first depth sort: one partition on the top digit of the key range the frame occupies, every bucket finished
+ *                            in LDS, the tile scan fused into that kernel (5 launches instead of 10; ~13 us per frame faster at 1.0 M Gaussians
+ *                            spread in depth); 1 = the same with the tile scan as a kernel of its own.  Identical results.  NOT the default: a
+ *                            bucket of more than 4096 (8192 beyond 1.2 M Gaussians) is sorted by one workgroup through global memory -- a
+ *                            fronto-parallel wall holding a third of the Gaussians costs 1.4 ms there ("Round 5").  Needs
+ *                            0 <= min_depth < max_depth with at most 28 significant key bits and an image of at most 255 x 255 tiles; falls back
+ *                            to the default otherwise.
+ *   "depth_sort_local_cap"   tests: largest bucket (0 = the kernel's capacity) the MSD depth sort finishes in LDS.
+ *   "depth_sort_local_threads" 0 (default: by Gaussian count) / 256 / 512 = workgroup size of the MSD depth sort's bucket kernel.
  * Returns EX4D_OK / the value, or an error / -1. */
 int ex4d_set_option(const char *name, int value);
 int ex4d_get_option(const char *name);
