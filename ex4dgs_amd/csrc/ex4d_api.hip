@@ -296,7 +296,7 @@ static int forward_impl(
     if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
-                                     keys0, vals0, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream,
+                                     keys0, (uint32_t *)nullptr, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream,
                                      msd_depth ? reinterpret_cast<uint32_t *>(g.key_ranges) : nullptr), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
@@ -325,7 +325,8 @@ static int forward_impl(
         MARK(0, "scan_tiles");
     } else {
         bool in_first = true;
-        STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream), prm, stream);
+        // (the ids the sort starts from are 0 .. P-1: its first pass generates them instead of reading an array the per-Gaussian kernel would have to write)
+        STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream, nullptr, true), prm, stream);
         if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
         MARK(0, "depth_sort");
         // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)

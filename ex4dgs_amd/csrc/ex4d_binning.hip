@@ -277,7 +277,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         const uint32_t i = base + it * 64 + lane;
         const uint32_t ic = i < block_end ? i : block_end - 1;
         key[it] = keys_in[ic];
-        val[it] = (MODE == 2) ? 0u : vals_in[ic];
+        val[it] = (MODE == 2) ? 0u : (vals_in ? vals_in[ic] : ic);        // vals_in == nullptr: the values are the item indices (first pass of the depth sort)
         if constexpr (MODE == 3) rct[it] = rects_in[ic];
     }
 #pragma unroll
@@ -954,13 +954,14 @@ size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)1024 * rs_blocks_for(n
 int ex4d_radix_passes(uint32_t n, int end_bit) { const int mb = rs_max_bits_for(n); return (end_bit + mb - 1) / mb; }
 
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev)
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev, bool iota_values)
 {
     *result_in_a = true;
     if (n == 0) return hipSuccess;
     const uint32_t nb = rs_blocks_for(n);
     const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
-    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    uint32_t *kin = keys_a, *vin = iota_values ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
+    uint32_t *vnext = vals_a;          // (ping-pong partner of vals_b after the first pass)
     // balanced digits (13 bits -> 7 + 6, not 8 + 5): a pass with fewer bins writes longer runs per digit and workgroup
     const int npass = ex4d_radix_passes(n, end_bit);
     for (int pass = 0, shift = 0; pass < npass; pass++) {
@@ -978,7 +979,7 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
             hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr, n_dev);
         }
         uint32_t *t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
+        t = (pass == 0) ? vnext : vin; vin = vout; vout = t;
         *result_in_a = !*result_in_a;
         shift += nbits;
     }
@@ -986,7 +987,8 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
 }
 
 // ---- MSD depth sort (depth_local_sort_kernel above): histogram / row scan / partition on the top digit of (key - kmin), buckets in LDS.
-// (ka, va, ra): keys / ids / packed rects as the preprocess kernel wrote them (scratch afterwards); (kb, vb, rb): the result --
+// (ka, va, ra): keys / ids / packed rects as the preprocess kernel wrote them (the ids are NOT read: they are 0 .. n-1, the partition
+// generates them; all three arrays are scratch of the bucket kernel afterwards); (kb, vb, rb): the result --
 // vb = Gaussian ids in depth order, rb = their packed rects in that order.  inv_key: the key of invisible Gaussians (above every
 // visible key); flags: the frame-flag words (the digit parameters land there); wave_ranges: the per-wave key ranges of the per-Gaussian kernel; hist: ex4d_radix_hist_words(n) words; starts: 1 << DLS_MSD_BITS words.
 // key_bits (host bound on the visible keys): the bits below the digit must fit the LDS word next to the arrival index
@@ -1007,12 +1009,12 @@ hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_
     if (small) {
         hipLaunchKernelGGL((dls_histogram_kernel<RS_SMALL_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, (const uint32_t *)dparams);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
-        hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, 0, MB, nb, hist,
+        hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, (const uint32_t *)nullptr, kb, vb, n, 0, MB, nb, hist,
             0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts, (const uint32_t *)dparams);
     } else {
         hipLaunchKernelGGL((dls_histogram_kernel<RS_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, (const uint32_t *)dparams);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
-        hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n, 0, MB, nb, hist,
+        hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, (const uint32_t *)nullptr, kb, vb, n, 0, MB, nb, hist,
             0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts, (const uint32_t *)dparams);
     }
     if (local_threads == 256)

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         rects[idx] = rect;
         if (rects4) rects4[idx] = (rect.x & 0xFFu) | ((rect.x >> 16) << 8) | ((rect.y & 0xFFu) << 16) | ((rect.y >> 16) << 24);      // (<= 255 x 255 tiles)
         depth_keys[idx] = depth_key;
-        depth_vals[idx] = (uint32_t)idx;
+        if (depth_vals) depth_vals[idx] = (uint32_t)idx;          // (nullptr: the depth sort's first pass takes the index itself)
     }
     // number of tile instances (the reference's num_rendered = last element of the inclusive scan,
     // CR/rasterizer_impl.cu:295-299): it does not depend on the depth order, so it is summed here and read back by the
