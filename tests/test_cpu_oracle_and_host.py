@@ -658,6 +658,64 @@ __global__ void k(float *out, const float *in, unsigned *mask)
     assert seen["dpp"] > 2000 and seen["trans"] > 200 and seen["valu_sgpr_writes"] > 1000 and seen["instructions"] > 50000, seen
 
 
+def test_msd_depth_sort_index_arithmetic_restated_with_numpy():
+    """The optional MSD depth sort (ex4d_binning.hip: dls_range_kernel / dls_digit / depth_local_sort_kernel, duplicate_kernel's bucket
+    form) restated with numpy, so that a mistake in its arithmetic shows up without a GPU: the top digit cut from the occupied key range
+    (invisible key -> last digit), a stable partition by digit, every bucket ordered by sorting the words `low key bits << 12 | arrival
+    index`, the tile scan as bucket-local inclusive scans + bucket sums -- against a stable argsort of the keys and a plain exclusive
+    scan in sorted order.  Key distributions: spread, a narrow band, heavy ties, no visible Gaussian, one Gaussian."""
+    rng = np.random.default_rng(5)
+    BINS, IDX_BITS = 1024, 12
+
+    def run(keys, counts, inv_key):
+        keys = keys.astype(np.uint64); n = len(keys)
+        vis = keys != inv_key
+        kmax = int(keys[vis].max()) if vis.any() else 0
+        kmin = int(keys[vis].min()) if vis.any() else 0
+        shift = 0
+        while ((kmax - kmin) >> shift) > BINS - 2:
+            shift += 1
+        digit = np.where(vis, (keys - kmin) >> shift, BINS - 1).astype(np.int64)
+        assert digit[vis].max(initial=0) <= BINS - 2
+        order = np.argsort(digit, kind="stable")                  # the partition (stable: ties keep ascending ids)
+        starts = np.concatenate([[0], np.cumsum(np.bincount(digit, minlength=BINS))])
+        ids = order.copy()
+        local_incl = np.zeros(n, np.int64); sums = np.zeros(BINS, np.int64)
+        for b in range(BINS - 1):                                 # (the invisible bucket is left as the partition wrote it)
+            s0, s1 = starts[b], starts[b + 1]
+            if s1 - s0 == 0:
+                continue
+            assert s1 - s0 <= 1 << IDX_BITS
+            kb = keys[order[s0:s1]]
+            words = (((kb - kmin) & ((1 << shift) - 1)) << IDX_BITS) | np.arange(s1 - s0, dtype=np.uint64)
+            assert int(words.max()) < 1 << 32
+            perm = np.argsort(words >> IDX_BITS, kind="stable")   # the LSD passes sort on the key bits, stably
+            assert np.array_equal(perm, np.argsort(words))        # ... which is the order of the whole words (the index breaks ties)
+            ids[s0:s1] = order[s0:s1][(words[perm] & ((1 << IDX_BITS) - 1)).astype(np.int64)]
+            c = counts[ids[s0:s1]]
+            local_incl[s0:s1] = np.cumsum(c); sums[b] = c.sum()
+        ref = np.argsort(keys, kind="stable")
+        assert np.array_equal(ids, ref)
+        base = np.concatenate([[0], np.cumsum(sums)])[:-1]
+        c_sorted = counts[ids]
+        d_sorted = digit[ids]
+        off = base[d_sorted] + local_incl - c_sorted              # duplicate_kernel: bucket base + own inclusive value - own count
+        ref_off = np.concatenate([[0], np.cumsum(c_sorted)])[:-1]
+        live = c_sorted > 0
+        assert np.array_equal(off[live], ref_off[live]) and int(sums.sum()) == int(counts.sum())
+
+    inv = (1 << 26) + 5
+    for n, lo, hi, ties in ((20000, 1, 1 << 26, 0), (20000, 5_000_000, 5_000_900, 0), (30000, 1000, 40_000_000, 3000), (500, 1, 1 << 26, 0), (1, 7, 8, 0)):
+        keys = rng.integers(lo, hi, n).astype(np.uint64)
+        if ties:                                                   # thousands of exactly equal keys (one bucket, still inside its LDS capacity)
+            keys[rng.permutation(n)[:ties]] = np.uint64((lo + hi) // 2)
+        invisible = rng.random(n) < 0.2
+        keys[invisible] = inv
+        counts = np.where(invisible, 0, rng.integers(1, 40, n)).astype(np.int64)
+        run(keys, counts, inv)
+    run(np.full(300, inv, np.uint64), np.zeros(300, np.int64), inv)            # nothing visible
+
+
 def test_machine_code_checks_fail_closed(tmp_path, monkeypatch):
     """the checks must not turn into a silent pass when they cannot be made -- an object the tools cannot read, a kernel
     whose register metadata the parser does not find, LLVM tools that are not where ROCm keeps them: each raises IsaCheckError (the
