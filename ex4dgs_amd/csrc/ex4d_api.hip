@@ -17,13 +17,61 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 std::atomic<int> g_bwd_variant{4};
 std::atomic<int> g_tile_ids{0};
-// "depth_sort_msd": 0 (default) = the 3-pass LSD depth sort + gathering tile scan; 2 = the MSD-first depth sort of round 5 (one partition on the
+// "depth_sort_msd": 0 = the 3-pass LSD depth sort + gathering tile scan; 2 = the MSD-first depth sort of round 5 (one partition on the
 // top digit of the occupied key range, every bucket finished in LDS, tile scan fused in: 5 launches instead of 10, -22 us of kernel time at
-// 1.0 M Gaussians with well-spread depths); 1 = the same with the streaming tile-scan kernel.  NOT the default: its bucket kernel sorts a
-// bucket of more than 4096 / 8192 Gaussians with ONE workgroup through global memory -- a large surface at one depth (a fronto-parallel
-// wall: tens of thousands of Gaussians inside 0.3 % of the depth range) costs hundreds of microseconds there, and on the slower boxes of
-// the pool its five kernels lose to the LSD passes even on the bench scene ("Round 5")
-std::atomic<int> g_depth_msd{0};
+// 1.0 M Gaussians with well-spread depths); 1 = the same with the streaming tile-scan kernel; 3 (default) = "auto": the MSD sort until
+// one of its buckets does not fit the LDS, then the LSD sort for a while.  The MSD sort's bucket kernel sorts a bucket of more than
+// 4096 / 8192 Gaussians with ONE workgroup through global memory -- a large surface at one depth (a fronto-parallel wall: tens of
+// thousands of Gaussians inside 0.3 % of the depth range) costs hundreds of microseconds there, the LSD sort does not care (DESIGN.md
+// section 4, "Round 5").  Both sorts give the same order bit for bit, so which one ran shows in the frame time only.
+std::atomic<int> g_depth_msd{3};
+// auto mode: the bucket kernel sets `word` (pinned host memory) when it met an oversize bucket; the next forward that sees it orders
+// `backoff` frames with the LSD sort and doubles `backoff` (never reset: over a run of F frames at most log2(F) frames pay the slow
+// path, whatever the scene does).  Process-wide: a conservative signal shared by every stream and thread.
+struct DepthSortWatch {
+    std::mutex mu;
+    uint32_t *word = nullptr;
+    bool tried = false;
+    std::atomic<int> hold{0}, backoff{64}, trips{0};
+    uint32_t *get()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!tried) {
+            tried = true;
+            if (hipHostMalloc((void **)&word, 64, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); word = nullptr; }
+            else memset(word, 0, 64);
+        }
+        return word;
+    }
+    void reset()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        hold.store(0); backoff.store(64); trips.store(0);
+        if (word) __atomic_store_n(word, 0u, __ATOMIC_RELAXED);
+    }
+} g_depth_watch;
+// does this frame use the MSD sort in auto mode?  (*watch: the word its bucket kernel reports to)
+bool depth_sort_auto_msd(hipStream_t stream, bool async, uint32_t **watch)
+{
+    *watch = nullptr;
+    if (async) {    // a call being recorded into a graph replays without the host: no way to switch afterwards
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (st != hipStreamCaptureStatusNone) return false;
+    }
+    uint32_t *w = g_depth_watch.get();
+    if (!w) return false;
+    if (__atomic_load_n(w, __ATOMIC_RELAXED) != 0u) {
+        __atomic_store_n(w, 0u, __ATOMIC_RELAXED);
+        const int b = g_depth_watch.backoff.load();
+        g_depth_watch.hold.store(b);
+        g_depth_watch.backoff.store(b < (1 << 20) ? 2 * b : b);
+        g_depth_watch.trips.fetch_add(1);
+    }
+    if (g_depth_watch.hold.load() > 0) { g_depth_watch.hold.fetch_sub(1); return false; }
+    *watch = w;
+    return true;
+}
 std::atomic<int> g_depth_local_cap{0};      // "depth_sort_local_cap": largest bucket the MSD depth sort finishes in LDS (0 = the kernel's capacity; tests force the through-memory path with a small value)
 std::atomic<int> g_depth_local_threads{0};  // "depth_sort_local_threads": 256 / 512 = workgroup size of the depth sort's bucket kernel, 0 = by Gaussian count
 std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
@@ -282,7 +330,11 @@ static int forward_impl(
     // MSD-first depth sort (round 5; ex4d_binning.hip: depth_local_sort_kernel): applies when the rects travel packed and the key bits
     // under the top digit fit its LDS word.  Its top digit is cut from the key range the frame's visible Gaussians occupy (the
     // per-Gaussian kernel leaves that range in the frame flags), the invisible key gets the last digit to itself
-    const bool msd_depth = g_depth_msd.load(std::memory_order_relaxed) != 0 && packed_rects && ex4d_depth_sort_msd_applies((uint32_t)P, key_bits);
+    int msd_mode = g_depth_msd.load(std::memory_order_relaxed);
+    uint32_t *msd_watch = nullptr;
+    if (!(packed_rects && ex4d_depth_sort_msd_applies((uint32_t)P, key_bits))) msd_mode = 0;
+    else if (msd_mode == 3) msd_mode = depth_sort_auto_msd(stream, async, &msd_watch) ? 2 : 0;
+    const bool msd_depth = msd_mode != 0;
     // the LSD sort ping-pongs between the (a) and (b) pairs and has to end in (a) = depth_order: start in (b) for an odd pass count
     const bool start_in_b = (ex4d_radix_passes((uint32_t)P, key_bits) & 1) != 0;
     uint32_t *keys0 = start_in_b ? g.sort_keys_b : g.sort_keys_a, *vals0 = start_in_b ? g.sort_vals_b : g.depth_order;
@@ -310,14 +362,14 @@ static int forward_impl(
         HIP_TRY(hipEventRecord(g_readback.ev, stream));
     }
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
-    // depth_sort_msd == 2 (default): the tile scan is fused into the bucket kernel of the depth sort (bucket-local inclusive scans +
+    // depth_sort_msd == 2 (and auto): the tile scan is fused into the bucket kernel of the depth sort (bucket-local inclusive scans +
     // bucket sums; duplicate_kernel adds the bucket bases): no scan kernel at all.  1: the streaming scan kernel.
-    const bool fused_scan = msd_depth && g_depth_msd.load(std::memory_order_relaxed) == 2;
+    const bool fused_scan = msd_mode == 2;
     if (msd_depth) {
         STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_invisible,
                                   g.total, g.key_ranges, g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
                                   fused_scan ? g.sorted_offsets : nullptr, fused_scan ? g.bucket_sums : nullptr, T, fused_scan ? im.ranges : nullptr,
-                                  g_depth_local_threads.load(std::memory_order_relaxed)), prm, stream);
+                                  g_depth_local_threads.load(std::memory_order_relaxed), msd_watch), prm, stream);
         MARK(0, "depth_sort");
         // 3. instance offsets in depth order + total: the rects arrive in depth order (rects4_b), nothing to gather
         if (!fused_scan)
@@ -546,7 +598,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_fast_path") && (value == 0 || value == 1)) { ex4d_set_preprocess_fast(value); return EX4D_OK; }
-    if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 2) { g_depth_msd.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 3) { g_depth_msd.store(value); g_depth_watch.reset(); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_cap") && value >= 0 && value <= 8192) { g_depth_local_cap.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_threads") && (value == 0 || value == 256 || value == 512)) { g_depth_local_threads.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
@@ -564,6 +616,8 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     if (name && !strcmp(name, "preprocess_fast_path")) return ex4d_get_preprocess_fast();
     if (name && !strcmp(name, "depth_sort_msd")) return g_depth_msd.load();
+    if (name && !strcmp(name, "depth_sort_hold")) return g_depth_watch.hold.load();        // (read-only) auto mode: frames left on the LSD sort
+    if (name && !strcmp(name, "depth_sort_trips")) return g_depth_watch.trips.load();      // (read-only) auto mode: oversize buckets seen since the option was set
     if (name && !strcmp(name, "depth_sort_local_cap")) return g_depth_local_cap.load();
     if (name && !strcmp(name, "depth_sort_local_threads")) return g_depth_local_threads.load();
     return -1;

@@ -659,7 +659,7 @@ __device__ __forceinline__ void dls_lds_pass(DlsLds<THREADS> &L, uint32_t n, uin
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_sort_kernel(uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t *ka, uint32_t *va, uint32_t *ra,
     const uint32_t *__restrict__ starts, const uint32_t *__restrict__ totals, const uint32_t *__restrict__ dparams, uint32_t cap,
-    uint32_t *__restrict__ local_incl, uint32_t *__restrict__ bucket_sums, int T, uint2 *__restrict__ ranges)
+    uint32_t *__restrict__ local_incl, uint32_t *__restrict__ bucket_sums, int T, uint2 *__restrict__ ranges, uint32_t *__restrict__ watch)
 {
     constexpr int DLS_THREADS = THREADS, DLS_WAVES = THREADS / 64, DLS_CAP = THREADS * DLS_ITEMS, IDX_BITS = DlsLds<THREADS>::IDX_BITS;
     __shared__ DlsLds<THREADS> L;
@@ -677,7 +677,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_s
     }
     const bool sorted_already = n < 2u || rem == 0;      // (rem == 0: all keys of a bucket are equal, the partition was stable)
     if (sorted_already || n > cap) {
-        if (!sorted_already) { dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem, dq.kmin); __threadfence(); __syncthreads(); }
+        if (!sorted_already) {
+            // a bucket beyond the LDS capacity: one workgroup sorts it through global memory -- correct, and slow (hundreds of microseconds
+            // for a wall of Gaussians at one depth).  `watch` (pinned host word, optional) tells the host it happened: in its "auto" mode
+            // the library then orders the following frames with the LSD sort, which does not care (ex4d_api.hip: depth_sort_plan)
+            if (watch && tid == 0) __hip_atomic_store(watch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem, dq.kmin); __threadfence(); __syncthreads();
+        }
         if (local_incl) {
             const uint32_t sum = dls_scan_from_memory(L, rb + s, local_incl + s, n);
             if (tid == 0) bucket_sums[b] = sum;
@@ -995,7 +1001,7 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
 bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits) { return n <= (1u << 26) && key_bits - (EX4D_DLS_MSD_BITS - 1) + DLS_IDX_BITS <= 32; }
 hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
     uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
-    uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads)
+    uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads, uint32_t *watch)
 {
     if (n == 0) return hipSuccess;
     constexpr int MB = EX4D_DLS_MSD_BITS, BINS = 1 << MB;
@@ -1019,10 +1025,10 @@ hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_
     }
     if (local_threads == 256)
         hipLaunchKernelGGL(depth_local_sort_kernel<256>, dim3(BINS), dim3(256), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, (const uint32_t *)dparams, local_cap,
-            local_incl, bucket_sums, T, ranges);
+            local_incl, bucket_sums, T, ranges, watch);
     else
         hipLaunchKernelGGL(depth_local_sort_kernel<512>, dim3(BINS), dim3(512), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, (const uint32_t *)dparams, local_cap,
-            local_incl, bucket_sums, T, ranges);
+            local_incl, bucket_sums, T, ranges, watch);
     return hipGetLastError();
 }
 

@@ -257,14 +257,18 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *   "preprocess_fast_path"   1 (default) = frames with one [P,16,3] SH tensor at degree 3 and scale + rotation (no precomputed colours or
  *                            covariances) take the per-Gaussian forward kernel specialised for exactly that; 0 = always the generic one.
  *                            Bit-identical results.
- *   "depth_sort_msd"         0 (default) = the Gaussians are ordered by depth with a 3-pass LSD radix sort, the tile scan gathers their rects;
+ *   "depth_sort_msd"         0 = the Gaussians are ordered by depth with a 3-pass LSD radix sort, the tile scan gathers their rects;
  *                            2 = MSD-first depth sort: one partition on the top digit of the key range the frame occupies, every bucket finished
  *                            in LDS, the tile scan fused into that kernel (5 launches instead of 10; ~13 us per frame faster at 1.0 M Gaussians
- *                            spread in depth); 1 = the same with the tile scan as a kernel of its own.  Identical results.  NOT the default: a
- *                            bucket of more than 4096 (8192 beyond 1.2 M Gaussians) is sorted by one workgroup through global memory -- a
- *                            fronto-parallel wall holding a third of the Gaussians costs 1.4 ms there ("Round 5").  Needs
- *                            0 <= min_depth < max_depth with at most 28 significant key bits and an image of at most 255 x 255 tiles; falls back
- *                            to the default otherwise.
+ *                            spread in depth); 1 = the same with the tile scan as a kernel of its own.  Identical results.  A bucket of more
+ *                            than 4096 (8192 beyond 1.2 M Gaussians) is sorted by one workgroup through global memory -- a fronto-parallel
+ *                            wall holding a third of the Gaussians costs 1.4 ms there ("Round 5").  Hence
+ *                            3 (default) = auto: the MSD sort, until its bucket kernel reports an oversize bucket (a word in pinned host
+ *                            memory); the following 64 frames then take the LSD sort, and every further report doubles that hold (so that
+ *                            of F frames at most log2 F pay the slow path).  Calls being recorded into a graph take the LSD sort.  Setting
+ *                            the option resets the hold; "depth_sort_hold" / "depth_sort_trips" (read-only) show frames left on the LSD
+ *                            sort / reports seen.  The MSD sort needs 0 <= min_depth < max_depth with at most 28 significant key bits and
+ *                            an image of at most 255 x 255 tiles; other frames take the LSD sort whatever the option says.
  *   "depth_sort_local_cap"   tests: largest bucket (0 = the kernel's capacity) the MSD depth sort finishes in LDS.
  *   "depth_sort_local_threads" 0 (default: by Gaussian count) / 256 / 512 = workgroup size of the MSD depth sort's bucket kernel.
  * Returns EX4D_OK / the value, or an error / -1. */

@@ -792,6 +792,16 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     assert l.ex4d_binning_bytes(0, 64, 64) > 0 and l.ex4d_img_bytes(1352, 1014) >= 1352 * 1014 * 8 + 5440 * 8
     assert l.ex4d_backward_scratch_bytes(P) >= P * 64
     assert ctypes.sizeof(_C.Ex4dParams) == 17 * 4
+    # library options are host state: the depth sort's default is "auto" (3), values beyond it and unknown names are refused
+    assert _C.get_option("depth_sort_msd") == 3 and _C.get_option("depth_sort_hold") == 0 and _C.get_option("depth_sort_trips") == 0
+    for v in (0, 1, 2, 3):
+        _C.set_option("depth_sort_msd", v)
+        assert _C.get_option("depth_sort_msd") == v
+    with pytest.raises(RuntimeError):
+        _C.set_option("depth_sort_msd", 4)
+    with pytest.raises(RuntimeError):
+        _C.set_option("depth_sort_hold", 1)              # read-only
+    assert _C.get_option("no_such_option") == -1
     # the kernels are gfx950 code objects
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={lib}"], capture_output=True, text=True)
     if out.returncode == 0 and out.stdout.strip():

@@ -52,7 +52,7 @@ SCENES = [("cfg2", 20000, 0), ("cfg3", 12000, 137), ("cfg5", 6000, 0), ("cfg1", 
 
 @pytest.mark.parametrize("cfg,P,t", SCENES)
 def test_msd_depth_sort_equals_the_lsd_sort_and_a_host_sort(hip_lib, cfg, P, t):
-    """depth_order / point_list / ranges / the image: bit-equal between the MSD-first depth sort (default), the same with every bucket
+    """depth_order / point_list / ranges / the image: bit-equal between the MSD-first depth sort (what the default, auto, runs on such scenes), the same with every bucket
     forced through global memory (local capacity 1: the path of oversize buckets), the variant that keeps the tile scan as a kernel of
     its own (depth_sort_msd = 1), and the 3-pass LSD sort; depth_order equal to a stable host sort of the depth bits."""
     ins, st = h.scene_inputs(cfg, P=P, t=t)
@@ -99,6 +99,38 @@ def test_msd_depth_sort_oversize_buckets_and_ties(hip_lib, P, z_lo, z_hi, ties):
     _same(_frame(ins, st, depth_sort_msd=1, depth_sort_local_threads=512), lsd, "msd with the scan kernel vs lsd")
     vis = int((lsd["radii"] > 0).sum())
     assert vis > P // 2
+
+
+def test_depth_sort_auto_mode_leaves_the_msd_sort_after_an_oversize_bucket(hip_lib):
+    """depth_sort_msd = 3 (the default): frames take the MSD sort until its bucket kernel reports a bucket beyond the LDS capacity (a pinned
+    host word); the next forward sees the report and orders the following 64 frames with the LSD sort, the hold doubling with every
+    further report.  The frames themselves are bit-equal whichever sort ran."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("depth_sort_msd") == 3, "auto is the library default"
+    spread, st = h.scene_inputs("cfg2", P=20000)
+    spread = {k: v.cuda() for k, v in spread.items()}
+    wall, st_w = _squeezed(30000, 6.0, 6.4, 9000)            # 9000 Gaussians at one depth: one bucket of > 4096
+    ref_spread = _frame(spread, st, depth_sort_msd=0)
+    ref_wall = _frame(wall, st_w, depth_sort_msd=0)
+    try:
+        _C.set_option("depth_sort_msd", 3)                    # (setting the option resets the hold and the counters)
+        for _ in range(3):
+            _same(_frame(spread, st), ref_spread, "auto on a spread scene")
+        assert _C.get_option("depth_sort_trips") == 0 and _C.get_option("depth_sort_hold") == 0
+        _same(_frame(wall, st_w), ref_wall, "auto, first wall frame (MSD, the oversize bucket through memory)")
+        assert _C.get_option("depth_sort_trips") == 0        # the host has not looked yet
+        _same(_frame(wall, st_w), ref_wall, "auto, second wall frame (LSD)")
+        assert _C.get_option("depth_sort_trips") == 1 and _C.get_option("depth_sort_hold") == 63
+        for _ in range(63):
+            _frame(wall, st_w)
+        assert _C.get_option("depth_sort_hold") == 0 and _C.get_option("depth_sort_trips") == 1
+        _same(_frame(wall, st_w), ref_wall, "auto, probe frame after the hold (MSD again)")
+        _same(_frame(spread, st), ref_spread, "auto, the frame that sees the second report")
+        assert _C.get_option("depth_sort_trips") == 2 and _C.get_option("depth_sort_hold") == 127
+        _C.set_option("depth_sort_msd", 3)
+        assert _C.get_option("depth_sort_hold") == 0 and _C.get_option("depth_sort_trips") == 0
+    finally:
+        _C.set_option("depth_sort_msd", 3)
 
 
 def test_msd_depth_sort_full_size_1M(hip_lib):
