@@ -15,11 +15,11 @@ timeout 400 python bench.py --config cfg4 $B --steps 30 --optimizer none > $out/
 timeout 300 python bench.py --config cfg5 --forward-only $B > $out/${tag}_bench_cfg5_forward_only.json 2> $out/${tag}_bench_cfg5_forward_only.err
 timeout 300 python bench.py --train-core $B > $out/${tag}_bench_cfg3_train_core.json 2> $out/${tag}_bench_cfg3_train_core.err
 timeout 300 python bench.py --train-core --optimizer sharded $B > $out/${tag}_bench_cfg3_train_core_sharded.json 2> $out/${tag}_bench_cfg3_train_core_sharded.err
-timeout 300 python bench.py $B --set depth_sort_msd=2 > $out/${tag}_bench_cfg3_msd_depth_sort.json 2> $out/${tag}_bench_cfg3_msd_depth_sort.err
+timeout 300 python bench.py $B --set depth_sort_msd=0 > $out/${tag}_bench_cfg3_lsd_depth_sort.json 2> $out/${tag}_bench_cfg3_lsd_depth_sort.err
 timeout 300 python bench.py $B --set depth_sort_msd=2 --graph > $out/${tag}_bench_cfg3_msd_depth_sort_graph.json 2> $out/${tag}_bench_cfg3_msd_depth_sort_graph.err
 timeout 300 python bench.py --config cfg2 $B --async-frames > $out/${tag}_bench_cfg2_async.json 2> $out/${tag}_bench_cfg2_async.err
 timeout 400 python bench.py --gpus 2 --share-device --backend gloo --steps 10 --warmup 3 $B > $out/${tag}_bench_2ranks_one_gpu_gloo.json 2> $out/${tag}_bench_2ranks_one_gpu_gloo.err
-for f in cfg2 cfg2_graph cfg2_async cfg3_graph cfg3_msd_depth_sort cfg3_msd_depth_sort_graph cfg4 cfg4_no_optimizer cfg5_forward_only cfg3_train_core cfg3_train_core_sharded 2ranks_one_gpu_gloo; do
+for f in cfg2 cfg2_graph cfg2_async cfg3_graph cfg3_lsd_depth_sort cfg3_msd_depth_sort_graph cfg4 cfg4_no_optimizer cfg5_forward_only cfg3_train_core cfg3_train_core_sharded 2ranks_one_gpu_gloo; do
 python - <<PY
 import json
 try:
