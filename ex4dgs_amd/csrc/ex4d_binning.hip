@@ -677,11 +677,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 5) void depth_local_s
     }
     const bool sorted_already = n < 2u || rem == 0;      // (rem == 0: all keys of a bucket are equal, the partition was stable)
     if (sorted_already || n > cap) {
+        // a bucket beyond the LDS capacity: one workgroup sorts it through global memory (or, all its keys being equal, only scans it from
+        // there) -- correct, and slow (hundreds of microseconds for a wall of Gaussians at one depth).  `watch` (pinned host word, optional)
+        // tells the host it happened: in its "auto" mode the library then orders the following frames with the LSD sort, which does not
+        // care (ex4d_api.hip: depth_sort_auto_msd)
+        if (n > cap && watch && tid == 0) __hip_atomic_store(watch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!sorted_already) {
-            // a bucket beyond the LDS capacity: one workgroup sorts it through global memory -- correct, and slow (hundreds of microseconds
-            // for a wall of Gaussians at one depth).  `watch` (pinned host word, optional) tells the host it happened: in its "auto" mode
-            // the library then orders the following frames with the LSD sort, which does not care (ex4d_api.hip: depth_sort_plan)
-            if (watch && tid == 0) __hip_atomic_store(watch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             dls_sort_through_memory(L, kb + s, vb + s, rb + s, ka + s, va + s, ra + s, n, rem, dq.kmin); __threadfence(); __syncthreads();
         }
         if (local_incl) {

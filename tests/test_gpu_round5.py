@@ -129,6 +129,13 @@ def test_depth_sort_auto_mode_leaves_the_msd_sort_after_an_oversize_bucket(hip_l
         assert _C.get_option("depth_sort_trips") == 2 and _C.get_option("depth_sort_hold") == 127
         _C.set_option("depth_sort_msd", 3)
         assert _C.get_option("depth_sort_hold") == 0 and _C.get_option("depth_sort_trips") == 0
+        # every depth equal: nothing to sort inside the one bucket, but one workgroup scans all of it -- reported like an oversize sort
+        flat, st_f = _squeezed(12000, 5.0, 5.0, 0)
+        ref_flat = _frame(flat, st_f, depth_sort_msd=0)
+        _C.set_option("depth_sort_msd", 3)
+        _same(_frame(flat, st_f), ref_flat, "auto, all depths equal (MSD)")
+        _same(_frame(flat, st_f), ref_flat, "auto, all depths equal (LSD)")
+        assert _C.get_option("depth_sort_trips") == 1 and _C.get_option("depth_sort_hold") == 63
     finally:
         _C.set_option("depth_sort_msd", 3)
 

@@ -57,8 +57,24 @@ def main():
             R = int(f[0])
             print(f"{name:28s} P={P} R={R:9d} depth sort {'MSD (adaptive digit)' if mode == 2 else 'LSD 3 passes      '}: depth_sort {agg['depth_sort'] * 1e3:7.1f} us  scan_tiles {agg['scan_tiles'] * 1e3:6.1f} us  "
                   f"forward {sum(agg.values()) * 1e3:7.1f} us", flush=True)
-    _C.set_option("depth_sort_msd", 2)
+        # the default (auto): mean forward time over a run of frames from a cold start -- the slow frames it pays (one per doubling hold) included
+        line = f"{name:28s} forward, mean of {RUN} frames:"
+        for mode, label in ((3, "auto"), (0, "LSD"), (2, "MSD forced")):
+            _C.set_option("depth_sort_msd", mode)        # (resets the auto mode's hold)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(RUN if not (mode == 2 and name.startswith(("wall", "one"))) else RUN // 10):
+                _raw_forward(ins, st)
+            e1.record(); torch.cuda.synchronize()
+            n = RUN if not (mode == 2 and name.startswith(("wall", "one"))) else RUN // 10
+            line += f"  {label} {e0.elapsed_time(e1) / n * 1e3:7.1f} us"
+            if mode == 3:
+                line += f" ({_C.get_option('depth_sort_trips')} reports)"
+        print(line, flush=True)
+    _C.set_option("depth_sort_msd", 3)
 
 
+RUN = 1000
 if __name__ == "__main__":
     main()
