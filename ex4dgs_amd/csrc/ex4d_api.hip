@@ -68,7 +68,8 @@ bool depth_sort_auto_msd(hipStream_t stream, bool async, uint32_t **watch)
         g_depth_watch.backoff.store(b < (1 << 20) ? 2 * b : b);
         g_depth_watch.trips.fetch_add(1);
     }
-    if (g_depth_watch.hold.load() > 0) { g_depth_watch.hold.fetch_sub(1); return false; }
+    for (int h = g_depth_watch.hold.load(); h > 0; )       // (threads share the hold: take one frame of it, never below zero)
+        if (g_depth_watch.hold.compare_exchange_weak(h, h - 1)) return false;
     *watch = w;
     return true;
 }
