@@ -22,6 +22,7 @@ ARCH = "gfx950"
 SOURCES = {
     "ex4d_preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "ex4d_binning.hip": [],
+    "ex4d_rowsort.hip": [],
     "ex4d_composite.hip": ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"],
     "ex4d_api.hip": [],
     "ex4d_attributes.hip": ["-ffp-contract=off"],

@@ -17,6 +17,9 @@ std::atomic<bool> g_prof_on{false};
 // tuning knobs (ex4d_set_option): which compositing-backward kernel runs (ex4d_composite.hip: ex4d_launch_composite_bwd)
 std::atomic<int> g_bwd_variant{4};
 std::atomic<int> g_tile_ids{0};
+// "tile_sort_rows": 1 (default) = the tile lists come from the row-segment sort of round 6 (ex4d_rowsort.hip: no duplication kernel, no
+// instance offsets); 0 = duplication + the MSD-first pair sort of rounds 2-5.  Same point_list / ranges bit for bit.
+std::atomic<int> g_tile_rows{1};
 // "depth_sort_msd": 0 = the 3-pass LSD depth sort + gathering tile scan; 2 = the MSD-first depth sort of round 5 (one partition on the
 // top digit of the occupied key range, every bucket finished in LDS, tile scan fused in: 5 launches instead of 10, -22 us of kernel time at
 // 1.0 M Gaussians with well-spread depths); 1 = the same with the streaming tile-scan kernel; 3 (default) = "auto": the MSD sort until
@@ -204,6 +207,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
     g.total = c.take<uint32_t>(EX4D_FLAG_WORDS);       // [1] prefilter violation flag, followed by the per-chunk instance counts
     g.block_totals = c.take<uint32_t>((P + 63) / 64);        // instance count of every 64-Gaussian chunk
+    g.row_hist = c.take<uint32_t>(ex4d_tile_sort_rows_geom_words((uint32_t)P));
     g.sh_dsums = c.take<float>(9 * (size_t)P);
     l.total = c.off;
     if (lay) *lay = l;
@@ -228,12 +232,17 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     Ex4dBinningLayout l;
     const size_t n = R ? R : 1;
     l.point_list = c.off; b.point_list = c.take<uint32_t>(n);
-    l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(n);
-    b.vals_tmp = c.take<uint32_t>(n);
-    b.keys_tmp = c.take<uint32_t>(n);
+    // (one area: three arrays of n words for the pair sorts, n 8-byte row segments for the row-segment sort)
+    const size_t n_al = ex4d_align_up(n * sizeof(uint32_t)) / sizeof(uint32_t);
+    l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(3 * n_al);
+    b.vals_tmp = b.tile_ids ? b.tile_ids + n_al : nullptr;
+    b.keys_tmp = b.tile_ids ? b.tile_ids + 2 * n_al : nullptr;
     const int tb = tile_bits(T);
+    const int cgx = (W + EX4D_TILE - 1) / EX4D_TILE, cgy = (H + EX4D_TILE - 1) / EX4D_TILE;
     const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
-    b.sort_hist = c.take<uint32_t>(hw > hw2 ? hw : hw2);
+    const size_t hw3 = (cgx <= 255 && cgy <= 255) ? ex4d_tile_sort_rows_hist_words(R, cgx, cgy) : 0;
+    const size_t hwm = hw > hw2 ? hw : hw2;
+    b.sort_hist = c.take<uint32_t>(hwm > hw3 ? hwm : hw3);
     l.qlist = c.off;  b.qlist = c.take<uint2>(4 * n);
     l.qcount = c.off; b.qcount = c.take<uint32_t>(4 * (size_t)T);
     l.total = c.off;
@@ -365,17 +374,20 @@ static int forward_impl(
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
     // depth_sort_msd == 2 (and auto): the tile scan is fused into the bucket kernel of the depth sort (bucket-local inclusive scans +
     // bucket sums; duplicate_kernel adds the bucket bases): no scan kernel at all.  1: the streaming scan kernel.
-    const bool fused_scan = msd_mode == 2;
+    // tile lists by the row-segment sort (round 6): it reads the rects in depth order and nothing else -- no instance offsets
+    const bool rows_sort = g_tile_rows.load(std::memory_order_relaxed) != 0 && ex4d_tile_sort_rows_applies(P, gx, gy);
+    const bool fused_scan = msd_mode == 2 && !rows_sort;
     if (msd_depth) {
         STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_invisible,
                                   g.total, g.key_ranges, g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
-                                  fused_scan ? g.sorted_offsets : nullptr, fused_scan ? g.bucket_sums : nullptr, T, fused_scan ? im.ranges : nullptr,
+                                  fused_scan ? g.sorted_offsets : nullptr, fused_scan ? g.bucket_sums : nullptr, T, (fused_scan || rows_sort) ? im.ranges : nullptr,
                                   g_depth_local_threads.load(std::memory_order_relaxed), msd_watch), prm, stream);
         MARK(0, "depth_sort");
         // 3. instance offsets in depth order + total: the rects arrive in depth order (rects4_b), nothing to gather
-        if (!fused_scan)
+        if (!fused_scan && !rows_sort) {
             STAGE(ex4d_launch_scan_tiles(P, nullptr, g.rects4_b, nullptr, nullptr, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
-        MARK(0, "scan_tiles");
+            MARK(0, "scan_tiles");
+        }
     } else {
         bool in_first = true;
         // (the ids the sort starts from are 0 .. P-1: its first pass generates them instead of reading an array the per-Gaussian kernel would have to write)
@@ -395,7 +407,9 @@ static int forward_impl(
         static_assert(sizeof(Ex4dFrameStatus) == 8 * sizeof(uint32_t), "Ex4dFrameStatus mirrors the first eight frame-flag words");
         // (hipMemcpyDefault: the status may live in pinned host memory or -- e.g. for calls recorded into a graph -- in device memory)
         // (fused scan: the instance count is written by the duplication kernel -- the copy follows it, below)
-        if (!fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
+        // (row-segment sort behind the MSD depth sort: its first kernel sums the instance count -- the copy follows it, below)
+        const bool count_later = fused_scan || (rows_sort && msd_depth);
+        if (!count_later) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         R = (uint32_t)prm->instance_capacity;
         n_dev = g.total;
         has_flow = prm->assume_no_flow == 0;
@@ -430,7 +444,16 @@ static int forward_impl(
     uint32_t *v0 = (passes % 2 == 0) ? b.point_list : b.vals_tmp;
     uint32_t *k1 = (passes % 2 == 0) ? b.keys_tmp : b.tile_ids;
     uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
-    if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
+    if (rows_sort) {
+        if (R > 0) {
+            // (the segments live in the second and third array of the pair area; the first takes the sorted tile ids when they are asked for)
+            STAGE(ex4d_tile_sort_rows(P, gx, gy, g.depth_order, dup_rects4, dup_rects, reinterpret_cast<uint2 *>(b.vals_tmp), b.point_list,
+                                      g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr, R, g.row_hist, b.sort_hist, im.ranges,
+                                      (async && msd_depth) ? g.total : nullptr, stream), prm, stream);
+        }
+        if (async && msd_depth) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
+        MARK(0, "tile_sort");
+    } else if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
         // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
         STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, b.tile_ids, b.vals_tmp, R, stream,
@@ -596,6 +619,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "composite_fwd_asm") && (value == 0 || value == 1)) { ex4d_set_fwd_asm(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "tile_sort_rows") && (value == 0 || value == 1)) { g_tile_rows.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_fast_path") && (value == 0 || value == 1)) { ex4d_set_preprocess_fast(value); return EX4D_OK; }
@@ -613,6 +637,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "composite_fwd_asm")) return ex4d_get_fwd_asm();
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
+    if (name && !strcmp(name, "tile_sort_rows")) return g_tile_rows.load();
     if (name && !strcmp(name, "preprocess_sh_predicate")) return ex4d_get_preprocess_tune();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     if (name && !strcmp(name, "preprocess_fast_path")) return ex4d_get_preprocess_fast();

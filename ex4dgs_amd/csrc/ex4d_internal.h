@@ -39,12 +39,13 @@ struct GeomState {
     uint32_t *sort_hist;                                 // radix histogram table for the depth sort
     uint32_t *total;                                     // frame flags (Ex4dFrameStatus): [0] instance count (summed by the tile scan), [1] prefilter violation, [2] some visible Gaussian has dir3D != 0, [3] EX4D_DSUMS_MARK when sh_dsums was written
     uint32_t *block_totals;                              // instance counts of preprocess_fwd per chunk of 64 Gaussians (summed on the host)
+    uint32_t *row_hist;                                  // row-segment tile sort (ex4d_rowsort.hip): histogram of its pass A' (sized by P)
     float *sh_dsums;                                     // [P][9] d(colour)/d(direction) sums of the SH backward, left by the forward per-Gaussian kernel on request (Ex4dParams.prepare_backward)
 };
 struct BinState {
     uint32_t *point_list;     // final sorted Gaussian ids
     uint32_t *tile_ids;       // final sorted tile ids
-    uint32_t *vals_tmp, *keys_tmp;   // ping-pong
+    uint32_t *vals_tmp, *keys_tmp;   // ping-pong (tile_ids, vals_tmp, keys_tmp are one area: also the row segments of ex4d_rowsort.hip, 8 bytes each)
     uint32_t *sort_hist;
     // The forward compositing kernel leaves, per (tile, quadrant), the COMPACTED list of the entries that survived its quadrant cull and
     // were composited: (Gaussian id, position in the tile list), in list order.  The backward streams these lists back to front
@@ -104,6 +105,14 @@ bool ex4d_tile_sort_msd_applies(int P, int tile_bits);
 size_t ex4d_tile_sort_hist_words(uint32_t R, int tile_bits);
 hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32_t *packed, uint32_t *point_list, uint32_t *tile_ids_out,
     uint32_t R, int tile_bits, uint32_t *hist, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
+
+// Tile sort at row-segment granularity (ex4d_rowsort.hip, round 6): point_list + tile ranges straight from the rects in depth order --
+// no instance offsets, no (tile, id) pairs.  Images of at most 255 x 255 tiles, P <= 2^24.
+bool ex4d_tile_sort_rows_applies(int P, int gx, int gy);
+size_t ex4d_tile_sort_rows_geom_words(uint32_t P);                      // histogram of pass A' (geometry buffer)
+size_t ex4d_tile_sort_rows_hist_words(uint32_t R, int gx, int gy);      // histogram of pass B' (binning buffer)
+hipError_t ex4d_tile_sort_rows(int P, int gx, int gy, const uint32_t *order, const uint32_t *r4, const uint2 *r8, uint2 *segs,
+    uint32_t *point_list, uint32_t *tile_ids_out, uint32_t cap, uint32_t *histA, uint32_t *histB, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rects4, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);

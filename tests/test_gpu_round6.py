@@ -1,0 +1,42 @@
+"""GPU tests of round 6: the tile sort at row-segment granularity (ex4d_rowsort.hip: point_list and the tile ranges straight from the
+rects in depth order) against the duplication + pair sort of rounds 2-5 it replaces, behind both depth sorts."""
+import pytest
+import torch
+
+from tests import helpers as h
+from tests.test_gpu_round5 import _frame, _same, _squeezed
+
+pytestmark = pytest.mark.gpu
+
+SCENES = [("cfg2", 20000, 0), ("cfg3", 12000, 137), ("cfg5", 6000, 0), ("cfg1", None, 0), ("cfg2", 1, 0), ("cfg2", 2049, 0), ("cfg5", 40000, 0)]
+
+
+@pytest.mark.parametrize("cfg,P,t", SCENES)
+def test_row_segment_tile_sort_equals_the_pair_sort(hip_lib, cfg, P, t):
+    """point_list / ranges / the image: bit-equal between the row-segment sort (default) and duplication + MSD pair sort, behind the MSD
+    depth sort and behind the LSD depth sort (whose scan kernel hands the rects over in the 8-byte form)."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("tile_sort_rows") == 1, "the row-segment sort is the library default"
+    ins, st = h.scene_inputs(cfg, P=P, t=t)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    ref = _frame(ins, st, tile_sort_rows=0, depth_sort_msd=0)
+    _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=2), ref, "rows behind the MSD depth sort")
+    _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=0), ref, "rows behind the LSD depth sort")
+    _same(_frame(ins, st, tile_sort_rows=0, depth_sort_msd=2), ref, "pairs behind the MSD depth sort")
+
+
+def test_row_segment_tile_sort_giant_gaussians(hip_lib):
+    """Rects of hundreds of tiles (scales x 30): blocks whose segments / instances exceed the LDS stage take the unstaged write path."""
+    ins, st = h.scene_inputs("cfg2", P=6000)
+    ins["scales"] = ins["scales"] * 30.0
+    ins = {k: v.cuda() for k, v in ins.items()}
+    ref = _frame(ins, st, tile_sort_rows=0, depth_sort_msd=0)
+    assert ref["R"] > 200 * 6000 * 0.5, "the scene is meant to have rects of hundreds of tiles"
+    _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=2), ref, "rows, giant rects")
+    _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=0), ref, "rows, giant rects, LSD depth sort")
+
+
+def test_row_segment_tile_sort_depth_ties(hip_lib):
+    ins, st = _squeezed(30000, 6.0, 6.4, 9000)
+    ref = _frame(ins, st, tile_sort_rows=0, depth_sort_msd=0)
+    _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=2), ref, "rows, depth ties")
