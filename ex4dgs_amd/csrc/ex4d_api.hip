@@ -206,7 +206,7 @@ GeomState carve_geom(void *buf, int P, Ex4dGeomLayout *lay, size_t *total)
     g.scan_block_sums = c.take<uint32_t>((P + SCAN_CHUNK - 1) / SCAN_CHUNK + 1);
     g.sort_hist = c.take<uint32_t>(ex4d_radix_hist_words((uint32_t)P));
     g.total = c.take<uint32_t>(EX4D_FLAG_WORDS);       // [1] prefilter violation flag, followed by the per-chunk instance counts
-    g.block_totals = c.take<uint32_t>((P + 63) / 64);        // instance count of every 64-Gaussian chunk
+    g.block_totals = c.take<uint32_t>(2 * (((size_t)P + 63) / 64));        // (instance count, tile-row segment count) of every 64-Gaussian chunk
     g.row_hist = c.take<uint32_t>(ex4d_tile_sort_rows_geom_words((uint32_t)P));
     g.sh_dsums = c.take<float>(9 * (size_t)P);
     l.total = c.off;
@@ -232,15 +232,13 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     Ex4dBinningLayout l;
     const size_t n = R ? R : 1;
     l.point_list = c.off; b.point_list = c.take<uint32_t>(n);
-    // (one area: three arrays of n words for the pair sorts, n 8-byte row segments for the row-segment sort)
-    const size_t n_al = ex4d_align_up(n * sizeof(uint32_t)) / sizeof(uint32_t);
-    l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(3 * n_al);
-    b.vals_tmp = b.tile_ids ? b.tile_ids + n_al : nullptr;
-    b.keys_tmp = b.tile_ids ? b.tile_ids + 2 * n_al : nullptr;
+    l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(n);
+    b.vals_tmp = c.take<uint32_t>(n);
+    b.keys_tmp = c.take<uint32_t>(n);
     const int tb = tile_bits(T);
     const int cgx = (W + EX4D_TILE - 1) / EX4D_TILE, cgy = (H + EX4D_TILE - 1) / EX4D_TILE;
     const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
-    const size_t hw3 = (cgx <= 255 && cgy <= 255) ? ex4d_tile_sort_rows_hist_words(R, cgx, cgy) : 0;
+    const size_t hw3 = (cgx <= 255 && cgy <= 255) ? ex4d_tile_sort_rows_hist_words(R) : 0;
     const size_t hwm = hw > hw2 ? hw : hw2;
     b.sort_hist = c.take<uint32_t>(hwm > hw3 ? hwm : hw3);
     l.qlist = c.off;  b.qlist = c.take<uint2>(4 * n);
@@ -365,7 +363,7 @@ static int forward_impl(
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
     // (g.total[0..63] and the per-chunk counts are adjacent in the geometry buffer: one copy)
     const size_t nblk = (size_t)(P + 63) / 64;
-    const size_t rb_words = (size_t)(g.block_totals - g.total) + nblk;
+    const size_t rb_words = (size_t)(g.block_totals - g.total) + 2 * nblk;
     if (!async) {
         if (!g_readback.init(rb_words)) return fail(EX4D_ERR_HIP, "pinned read-back buffer allocation failed");
         HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -401,6 +399,7 @@ static int forward_impl(
     const uint2 *dup_rects = msd_depth ? nullptr : g.sorted_rects;
     const uint32_t *dup_rects4 = msd_depth ? g.rects4_b : nullptr;
     uint32_t R = 0;                      // instance count (synchronous) or capacity (asynchronous): sizes the binning buffer and the grids
+    uint32_t segment_sum = 0;            // tile-row segments of the frame (synchronous forward; asynchronous: bounded by the capacity)
     const uint32_t *n_dev = nullptr;     // asynchronous: the kernels read the actual count here
     bool has_flow;
     if (async) {
@@ -411,6 +410,7 @@ static int forward_impl(
         const bool count_later = fused_scan || (rows_sort && msd_depth);
         if (!count_later) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         R = (uint32_t)prm->instance_capacity;
+        segment_sum = R;
         n_dev = g.total;
         has_flow = prm->assume_no_flow == 0;
     } else {
@@ -425,7 +425,10 @@ static int forward_impl(
             } else HIP_TRY(hipEventSynchronize(g_readback.ev));
         }
         uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
-        for (size_t i = 0; i < nblk; i++) instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + i];
+        for (size_t i = 0; i < nblk; i++) {
+            instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + 2 * i];
+            segment_sum += g_readback.host[(size_t)(g.block_totals - g.total) + 2 * i + 1];
+        }
         has_flow = g_readback.host[2] != 0u;      // frame flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
         if (prm->prefiltered && g_readback.host[1])
             return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
@@ -446,9 +449,8 @@ static int forward_impl(
     uint32_t *v1 = (passes % 2 == 0) ? b.vals_tmp : b.point_list;
     if (rows_sort) {
         if (R > 0) {
-            // (the segments live in the second and third array of the pair area; the first takes the sorted tile ids when they are asked for)
-            STAGE(ex4d_tile_sort_rows(P, gx, gy, g.depth_order, dup_rects4, dup_rects, reinterpret_cast<uint2 *>(b.vals_tmp), b.point_list,
-                                      g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr, R, g.row_hist, b.sort_hist, im.ranges,
+            STAGE(ex4d_tile_sort_rows(P, gx, gy, g.depth_order, dup_rects4, dup_rects, b.keys_tmp, b.point_list,
+                                      g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr, R, segment_sum, g.row_hist, b.sort_hist, im.ranges,
                                       (async && msd_depth) ? g.total : nullptr, stream), prm, stream);
         }
         if (async && msd_depth) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
@@ -620,6 +622,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "composite_fwd_asm") && (value == 0 || value == 1)) { ex4d_set_fwd_asm(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "tile_sort_rows") && (value == 0 || value == 1)) { g_tile_rows.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "rows_probe")) { ex4d_set_rows_probe(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_fast_path") && (value == 0 || value == 1)) { ex4d_set_preprocess_fast(value); return EX4D_OK; }
@@ -630,6 +633,7 @@ int ex4d_set_option(const char *name, int value)
 }
 
 int ex4d_debug_bwd_stats(unsigned long long *out8, int reset) { return ex4d_bwd_stats(out8, 8, reset) == hipSuccess ? EX4D_OK : EX4D_ERR_HIP; }
+int ex4d_debug_rows_prof(unsigned long long *out8, int reset) { return ex4d_rows_prof(out8, reset) == hipSuccess ? EX4D_OK : EX4D_ERR_HIP; }
 int ex4d_debug_bwd_stats16(unsigned long long *out16, int reset) { return ex4d_bwd_stats(out16, 16, reset) == hipSuccess ? EX4D_OK : EX4D_ERR_HIP; }
 
 int ex4d_get_option(const char *name)

@@ -234,8 +234,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
     int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges, const uint32_t *__restrict__ n_dev,
     const uint32_t *__restrict__ rects_in = nullptr, uint32_t *__restrict__ rects_out = nullptr, uint32_t *__restrict__ bucket_starts = nullptr,
-    const uint32_t *__restrict__ dparams = nullptr)
+    const uint32_t *__restrict__ dparams = nullptr, uint32_t range_stride = 0, uint32_t out_cap = 0xFFFFFFFFu)
 {
+    // MODE 2 only: range_stride = tile ids per bucket (0: 1 << nbits, the binary split of the pair sort; the row-segment sort of round 6
+    // has bucket = tile row, digit = tile column: the image's tiles per row); out_cap = capacity of the packed / output arrays (an
+    // asynchronous frame whose instance count exceeds it is re-run by the caller: nothing may be touched behind it)
     if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }      // (see rs_histogram_kernel)
     if (MODE != 2 && blockIdx.x * (uint32_t)(RS_THREADS * ITEMS) >= n) return;      // behind the last item (uniform: the whole workgroup)
     __shared__ uint32_t wave_cnt[4][BINS];        // per-wave digit counts -> exclusive block-local offsets
@@ -266,6 +269,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         __syncthreads();                            // every thread has its copy before the area is reused
         if (tb.count == 0) return;                  // past the last block (uniform: the whole workgroup)
         block_first = tb.start; block_end = tb.start + tb.count; bucket = tb.bucket;
+        if (block_first >= out_cap) return;         // (uniform)
+        if (block_end > out_cap) block_end = out_cap;
     }
     const uint32_t base = block_first + wave * (CHUNK / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -363,7 +368,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
                 local_start[d] = ls;
                 global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x] - pf[k];
                 // tile (bucket, d) occupies [gb, gb + gtot): identifyTileRanges (CR/rasterizer_impl.cu:118-140) without reading the keys
-                if (MODE == 2 && blockIdx.x == tb.fb_first && gtot[k] != 0u) ranges[((size_t)bucket << nbits) + d] = make_uint2(gb, gb + gtot[k]);
+                if (MODE == 2 && blockIdx.x == tb.fb_first && gtot[k] != 0u) {
+                    const uint32_t e = gb + gtot[k];
+                    ranges[(size_t)bucket * (range_stride ? range_stride : (1u << nbits)) + d] = make_uint2(gb < out_cap ? gb : out_cap, e < out_cap ? e : out_cap);
+                }
                 if (MODE == 3 && blockIdx.x == 0) bucket_starts[d] = gb;            // first output position of digit d
                 wave_cnt[0][d] = ls; wave_cnt[1][d] = ls + c[k][0]; wave_cnt[2][d] = ls + c[k][0] + c[k][1]; wave_cnt[3][d] = ls + c[k][0] + c[k][1] + c[k][2];
             }
@@ -390,9 +398,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; }
         if constexpr (MODE == 3) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; rects_out[dst] = stage_r[p]; }
         if (MODE == 1) keys_out[dst] = ((kv.x & ((1u << low_bits) - 1u)) << (32 - low_bits)) | kv.y;
-        if (MODE == 2) {
+        if (MODE == 2 && dst < out_cap) {
             vals_out[dst] = kv.x & (0xFFFFFFFFu >> nbits);
-            if (keys_out) keys_out[dst] = (bucket << nbits) | d;        // the sorted tile ids, on request only
+            if (keys_out) keys_out[dst] = bucket * (range_stride ? range_stride : (1u << nbits)) + d;        // the sorted tile ids, on request only
         }
     }
 }
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 // bucket = stable by the whole tile id.  HBM traffic per instance: 8 written by the duplication + (4 + 8 + 4) + (4 + 4 + 4) = 36 bytes
 // instead of 8 + 2 x (4 + 8 + 8) + 4 = 52.
 __global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ bucket_totals,
-    int nbuckets, int shift, uint32_t nblocks, uint32_t *__restrict__ hist)
+    int nbuckets, int shift, uint32_t nblocks, uint32_t *__restrict__ hist, uint32_t cap = 0xFFFFFFFFu)
 {
     __shared__ uint32_t h[256];
     __shared__ TsLocateLds loc;
@@ -419,12 +427,13 @@ __global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t
 #pragma unroll
         for (int it = 0; it < RS_ITEMS; it++) {
             const uint32_t i = it * RS_THREADS + threadIdx.x;
-            k[it] = words[tb.start + (i < tb.count ? i : tb.count - 1)];
+            const uint32_t gi = tb.start + (i < tb.count ? i : tb.count - 1);
+            k[it] = words[gi < cap ? gi : cap - 1];
         }
 #pragma unroll
         for (int it = 0; it < RS_ITEMS; it++) {
             const uint32_t i = it * RS_THREADS + threadIdx.x;
-            if (i < tb.count) atomicAdd(&h[k[it] >> shift], 1u);
+            if (i < tb.count && tb.start + i < cap) atomicAdd(&h[k[it] >> shift], 1u);
         }
     }
     __syncthreads();
@@ -1065,6 +1074,25 @@ hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, histB, 256u);
 #define TS_SCATTER_B(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2, NB>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list, \
         R, 32 - low_bits, low_bits, nbB, histB, low_bits, totals, 1 << high_bits, ranges, (const uint32_t *)nullptr)
+    if (low_bits == 7) TS_SCATTER_B(7); else if (low_bits == 8) TS_SCATTER_B(8); else TS_SCATTER_B(0);
+#undef TS_SCATTER_B
+    return hipGetLastError();
+}
+
+// Pass B of the MSD tile sort on its own (round 6: behind the row-segment partition of ex4d_rowsort.hip): `packed` holds, bucket after
+// bucket (bucket = tile row, `totals[nbuckets]` instances each, in depth order inside a bucket), one word per instance,
+// column << (32 - low_bits) | Gaussian id.  Writes point_list, the tile ranges (tile = bucket * stride + column) and, on request, the tile ids.
+size_t ex4d_tile_sort_pass_b_hist_words(uint32_t R) { return (size_t)256 * (rs_num_blocks(R) + 258); }
+hipError_t ex4d_tile_sort_pass_b(const uint32_t *packed, const uint32_t *totals, int nbuckets, int low_bits, uint32_t stride, uint32_t R, uint32_t cap,
+    uint32_t *histB, uint32_t *point_list, uint32_t *tile_ids_out, uint2 *ranges, hipStream_t stream)
+{
+    if (R == 0) return hipSuccess;
+    const uint32_t nbB = rs_num_blocks(R) + (uint32_t)nbuckets + 1u;
+    hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, totals, nbuckets, 32 - low_bits, nbB, histB, cap);
+    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, histB, 256u);
+#define TS_SCATTER_B(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2, NB>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list, \
+        R, 32 - low_bits, low_bits, nbB, histB, low_bits, totals, nbuckets, ranges, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, \
+        (const uint32_t *)nullptr, stride, cap)
     if (low_bits == 7) TS_SCATTER_B(7); else if (low_bits == 8) TS_SCATTER_B(8); else TS_SCATTER_B(0);
 #undef TS_SCATTER_B
     return hipGetLastError();

@@ -45,7 +45,7 @@ struct GeomState {
 struct BinState {
     uint32_t *point_list;     // final sorted Gaussian ids
     uint32_t *tile_ids;       // final sorted tile ids
-    uint32_t *vals_tmp, *keys_tmp;   // ping-pong (tile_ids, vals_tmp, keys_tmp are one area: also the row segments of ex4d_rowsort.hip, 8 bytes each)
+    uint32_t *vals_tmp, *keys_tmp;   // ping-pong (keys_tmp: the instance words between the two passes of the tile sort)
     uint32_t *sort_hist;
     // The forward compositing kernel leaves, per (tile, quadrant), the COMPACTED list of the entries that survived its quadrant cull and
     // were composited: (Gaussian id, position in the tile list), in list order.  The backward streams these lists back to front
@@ -110,9 +110,11 @@ hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32
 // no instance offsets, no (tile, id) pairs.  Images of at most 255 x 255 tiles, P <= 2^24.
 bool ex4d_tile_sort_rows_applies(int P, int gx, int gy);
 size_t ex4d_tile_sort_rows_geom_words(uint32_t P);                      // histogram of pass A' (geometry buffer)
-size_t ex4d_tile_sort_rows_hist_words(uint32_t R, int gx, int gy);      // histogram of pass B' (binning buffer)
-hipError_t ex4d_tile_sort_rows(int P, int gx, int gy, const uint32_t *order, const uint32_t *r4, const uint2 *r8, uint2 *segs,
-    uint32_t *point_list, uint32_t *tile_ids_out, uint32_t cap, uint32_t *histA, uint32_t *histB, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
+size_t ex4d_tile_sort_rows_hist_words(uint32_t R);                      // histogram of pass B (binning buffer)
+void ex4d_set_rows_probe(int v);      // developer profile of pass A' (cycles per phase)
+hipError_t ex4d_rows_prof(unsigned long long *out8, int reset);
+hipError_t ex4d_tile_sort_rows(int P, int gx, int gy, const uint32_t *order, const uint32_t *r4, const uint2 *r8, uint32_t *words,
+    uint32_t *point_list, uint32_t *tile_ids_out, uint32_t cap, uint32_t S, uint32_t *histA, uint32_t *histB, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 
 hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rects4, const uint32_t *order, uint2 *sorted_rects, uint32_t *sorted_offsets,
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);

@@ -723,10 +723,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // host WHILE the depth sort runs -- the blocking read-back no longer leaves the GPU idle.
     // (one plain store per chunk of 64 Gaussians; the host adds the partial sums -- a single atomic counter would
     // serialise ~12 ns per arrival)
-    uint32_t wave_sum = out_tiles;
+    // (round 6: and the number of tile-row segments -- rect heights -- which sizes the grids of the row-segment tile sort, ex4d_rowsort.hip)
+    uint32_t wave_sum = out_tiles, wave_seg = visible ? (rect.y >> 16) : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wave_sum += __shfl_xor(wave_sum, o, 64);
-    if (lane == 0) total_instances[wc] = wave_sum;        // one count per 64-Gaussian chunk
+    for (int o = 32; o > 0; o >>= 1) { wave_sum += __shfl_xor(wave_sum, o, 64); wave_seg += __shfl_xor(wave_seg, o, 64); }
+    if (lane == 0) reinterpret_cast<uint2 *>(total_instances)[wc] = make_uint2(wave_sum, wave_seg);        // one pair per 64-Gaussian chunk
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,

@@ -281,6 +281,9 @@ int ex4d_debug_bwd_stats(unsigned long long *out8, int reset);
  * quadrant only / the bottom four only / both, [10] / [11] steps run in the top / bottom half, [12] / [13] batches whose top / bottom
  * half has no contributing pair, [14..15] spare */
 int ex4d_debug_bwd_stats16(unsigned long long *out16, int reset);
+/* developer profile of the row-segment partition (option "rows_probe" = 1): shader-clock cycles per phase of its scatter kernel summed over
+ * workgroups ([0] loads + count, [1] barrier scan, [2] placement, [3] width scan, [4] expansion, [5] write-out), [7] = workgroups */
+int ex4d_debug_rows_prof(unsigned long long *out8, int reset);
 
 /* Optional per-stage timing (hipEvents on the caller's stream, single host thread; used by bench.py).
  * ex4d_profile_read(which = 0 forward / 1 backward) waits for the last recorded call of that kind and
