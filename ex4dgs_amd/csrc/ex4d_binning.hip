@@ -121,54 +121,55 @@ struct DlsParams { uint32_t kmin, shift, inv_key; };
 __device__ __forceinline__ DlsParams dls_params(const uint32_t *__restrict__ dparams) { return { dparams[0], dparams[1], dparams[2] }; }
 __device__ __forceinline__ uint32_t dls_digit(uint32_t key, const DlsParams &q, uint32_t bins) { return key == q.inv_key ? bins - 1u : (key - q.kmin) >> q.shift; }
 
-// the frame's key range from the per-wave pairs the per-Gaussian kernel left -> dparams (one workgroup; P / 64 pairs = 125 KB at 1.0 M)
-__global__ __launch_bounds__(1024) void dls_range_kernel(const uint2 *__restrict__ wave_ranges, uint32_t nwaves, uint32_t inv_key, uint32_t bins,
-    uint32_t *__restrict__ dparams)
+// Round 6: every workgroup of the histogram kernel derives dparams itself from the per-WORKGROUP key ranges the per-Gaussian kernel left
+// (P / 256 pairs = 31 KB at 1.0 M, from L2) -- the one-workgroup range kernel and its launch in front of the sort are gone; workgroup 0
+// leaves dparams in the frame flags for the partition and the bucket kernel.
+__device__ __forceinline__ DlsParams dls_reduce_ranges(const uint2 *__restrict__ ranges, uint32_t nranges, uint32_t inv_key, uint32_t bins, uint32_t *s_red /* 8 words */)
 {
-    __shared__ uint32_t s_max[16], s_nmin[16];
     uint32_t kmax = 0u, nkmin = 0u;
-    for (uint32_t base = 0; base < nwaves; base += 16u * 1024u) {          // 16 loads in flight per thread: one memory round trip up to 1.0 M Gaussians
-        uint2 p[16];
+    for (uint32_t base = 0; base < nranges; base += 8u * RS_THREADS) {          // 8 loads in flight per thread
+        uint2 p[8];
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const uint32_t i = base + j * 1024u + threadIdx.x; p[j] = i < nwaves ? wave_ranges[i] : make_uint2(0u, 0u); }
+        for (int j = 0; j < 8; j++) { const uint32_t i = base + j * RS_THREADS + threadIdx.x; p[j] = i < nranges ? ranges[i] : make_uint2(0u, 0u); }
 #pragma unroll
-        for (int j = 0; j < 16; j++) { kmax = p[j].x > kmax ? p[j].x : kmax; nkmin = p[j].y > nkmin ? p[j].y : nkmin; }
+        for (int j = 0; j < 8; j++) { kmax = p[j].x > kmax ? p[j].x : kmax; nkmin = p[j].y > nkmin ? p[j].y : nkmin; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(nkmin, o, 64);
         kmax = a > kmax ? a : kmax; nkmin = b > nkmin ? b : nkmin;
     }
-    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = kmax; s_nmin[threadIdx.x >> 6] = nkmin; }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = kmax; s_red[4 + (threadIdx.x >> 6)] = nkmin; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 0; w < 16; w++) { kmax = s_max[w] > kmax ? s_max[w] : kmax; nkmin = s_nmin[w] > nkmin ? s_nmin[w] : nkmin; }
-        uint32_t kmin = ~nkmin, shift = 0;
-        if (kmax == 0u) kmin = 0u;           // no visible Gaussian at all
-        else {
-            const uint32_t range = kmax - kmin;
-            while ((range >> shift) > bins - 2u) shift++;
-        }
-        dparams[0] = kmin; dparams[1] = shift; dparams[2] = inv_key; dparams[3] = 0u;
+    for (int w = 0; w < RS_THREADS / 64; w++) { kmax = s_red[w] > kmax ? s_red[w] : kmax; nkmin = s_red[4 + w] > nkmin ? s_red[4 + w] : nkmin; }
+    uint32_t kmin = ~nkmin, shift = 0;
+    if (kmax == 0u) kmin = 0u;           // no visible Gaussian at all
+    else {
+        const uint32_t range = kmax - kmin;
+        while ((range >> shift) > bins - 2u) shift++;
     }
+    return { kmin, shift, inv_key };
 }
 
 template <int ITEMS, int BINS>
 __global__ __launch_bounds__(RS_THREADS) void dls_histogram_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t nblocks,
-    uint32_t *__restrict__ hist, const uint32_t *__restrict__ dparams)
+    uint32_t *__restrict__ hist, uint32_t *__restrict__ dparams, const uint2 *__restrict__ ranges, uint32_t nranges, uint32_t inv_key)
 {
     __shared__ uint32_t h[BINS];
+    __shared__ uint32_t s_red[8];
     for (int b = threadIdx.x; b < BINS; b += RS_THREADS) h[b] = 0;
-    __syncthreads();
-    const DlsParams q = dls_params(dparams);
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
+    uint32_t k[ITEMS];
     if (base < n) {
-        uint32_t k[ITEMS];
 #pragma unroll
         for (int it = 0; it < ITEMS; it++) {
             const uint32_t i = base + it * RS_THREADS + threadIdx.x;
             k[it] = keys[i < n ? i : n - 1];
         }
+    }
+    const DlsParams q = dls_reduce_ranges(ranges, nranges, inv_key, (uint32_t)BINS, s_red);      // (its barrier publishes h = 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dparams[0] = q.kmin; dparams[1] = q.shift; dparams[2] = q.inv_key; dparams[3] = 0u; }
+    if (base < n) {
 #pragma unroll
         for (int it = 0; it < ITEMS; it++) {
             const uint32_t i = base + it * RS_THREADS + threadIdx.x;
@@ -1018,17 +1019,17 @@ hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_
     const uint32_t nb = rs_blocks_for(n);
     const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
     uint32_t *dparams = flags + EX4D_FLAG_DPARAMS;
-    hipLaunchKernelGGL(dls_range_kernel, dim3(1), dim3(1024), 0, stream, wave_ranges, (n + 63u) / 64u, inv_key, 1u << EX4D_DLS_MSD_BITS, dparams);
+    const uint32_t nranges = (n + 255u) / 256u;          // one (max key, max ~key) pair per workgroup of the per-Gaussian kernel
     if (local_threads != 256 && local_threads != 512) local_threads = n <= 1200000u ? 256 : 512;
     const uint32_t kcap = (uint32_t)local_threads * DLS_ITEMS;
     if (local_cap == 0 || local_cap > kcap) local_cap = kcap;
     if (small) {
-        hipLaunchKernelGGL((dls_histogram_kernel<RS_SMALL_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, (const uint32_t *)dparams);
+        hipLaunchKernelGGL((dls_histogram_kernel<RS_SMALL_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, dparams, wave_ranges, nranges, inv_key);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
         hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, (const uint32_t *)nullptr, kb, vb, n, 0, MB, nb, hist,
             0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts, (const uint32_t *)dparams);
     } else {
-        hipLaunchKernelGGL((dls_histogram_kernel<RS_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, (const uint32_t *)dparams);
+        hipLaunchKernelGGL((dls_histogram_kernel<RS_ITEMS, BINS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n, nb, hist, dparams, wave_ranges, nranges, inv_key);
         hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(BINS), dim3(256), 0, stream, nb, hist, (uint32_t)BINS);
         hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, BINS, 3, MB>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, (const uint32_t *)nullptr, kb, vb, n, 0, MB, nb, hist,
             0, (const uint32_t *)nullptr, 0, (uint2 *)nullptr, (const uint32_t *)nullptr, ra, rb, starts, (const uint32_t *)dparams);

@@ -442,6 +442,14 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // kernel's time is made of (tools/dev/pre_probe.py, 1.0 M Gaussians): 49 us with precomputed colours (no SH path at all), +24 us for
     // the SH staging and evaluation at degree 0 (16 of 192 bytes of SH read per Gaussian), +10 us for the other 176 bytes at degree 3,
     // +10 us for the direction sums left for the backward (which saves 31 us there): it does not follow its bytes.
+    // MSD depth sort: the workgroup's key range is collected in LDS (round 6: one pair per workgroup instead of one per wave, so that the
+    // depth sort's histogram kernel can reduce the pairs itself and the one-workgroup range kernel in front of it is gone).  The only
+    // barrier of the kernel, at its very start; afterwards every wave is on its own.
+    __shared__ uint32_t s_kr[4];
+    if (key_range_slots) {
+        if (threadIdx.x < 4) s_kr[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const int wc = (int)blockIdx.x * 4 + wave;
     if (wc >= ((P + 63) >> 6)) return;
     const int idx = wc * 64 + lane;
@@ -579,7 +587,15 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         // (one plain 8-byte store per wave; a one-workgroup kernel of the depth sort reduces the P / 64 pairs.  Measured instead, round 5:
         // 2 atomics per wave into 2 x 64 slots +10 us on this kernel wherever they were issued; atomics only where a wave would raise
         // its slot, the slot read first: +55 us -- the slot lines are a hot spot and every wave's first wait included them)
-        if (lane == 0) reinterpret_cast<uint2 *>(key_range_slots)[wc] = make_uint2(kmax, nkmin);
+        if (lane == 0) {
+            // (LDS atomics of one wave arrive in order, the last wave's ticket behind everybody's maxima)
+            atomicMax(&s_kr[0], kmax); atomicMax(&s_kr[1], nkmin);
+            const int nchunks = (P + 63) >> 6, mine = nchunks - (int)blockIdx.x * 4;
+            const uint32_t t = atomicAdd(&s_kr[2], 1u);
+            if ((int)t == (mine < 4 ? mine : 4) - 1)
+                reinterpret_cast<uint2 *>(key_range_slots)[blockIdx.x] = make_uint2(__hip_atomic_load(&s_kr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                                                                                    __hip_atomic_load(&s_kr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
     }
     // ---- colour: SH -> RGB (CR/forward.cu:20-71) or precomputed
     float coefv[16][3];

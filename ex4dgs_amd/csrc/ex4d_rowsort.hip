@@ -351,14 +351,29 @@ __global__ __launch_bounds__(ROW_THREADS) void rows_seg_scatter_kernel(uint32_t 
     int sh = 3;
     while (((nwords - 1u) >> sh) >= ROWA_HINTS) sh++;
     // word q of the block belongs to the last segment p with winc[p] <= q: at most 2^sh - 1 segments behind hint[q >> sh]
-#pragma unroll 2
-    for (uint32_t q = tid; q < nwords; q += ROW_THREADS) {
-        uint32_t p = hint[q >> sh];
-        for (uint32_t step = 1u << (sh - 1); step > 0; step >>= 1) if (winc[p + step] <= q) p += step;
-        const uint2 seg = stage[p];
-        const uint32_t x0 = seg.y & 0xFFu, ty = seg.y >> 16;
-        const uint32_t dst = inst_base[ty] + (q - row_word[ty]);
-        if (dst < cap) words[dst] = ((x0 + (q - winc[p])) << shift) | seg.x;
+    // (four words per thread and trip: four independent chains of dependent LDS reads in flight)
+    for (uint32_t q0 = tid; q0 < nwords; q0 += 4 * ROW_THREADS) {
+        uint32_t q[4], p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { q[u] = q0 + u * ROW_THREADS; p[u] = hint[(q[u] < nwords ? q[u] : q0) >> sh]; }
+        for (uint32_t step = 1u << (sh - 1); step > 0; step >>= 1) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) wv[u] = winc[p[u] + step];
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (wv[u] <= q[u]) p[u] += step;
+        }
+        uint2 seg[4]; uint32_t w0[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { seg[u] = stage[p[u]]; w0[u] = winc[p[u]]; }
+        uint32_t ib[4], rw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t ty = seg[u].y >> 16; ib[u] = inst_base[ty]; rw[u] = row_word[ty]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t dst = ib[u] + (q[u] - rw[u]);
+            if (q[u] < nwords && dst < cap) words[dst] = (((seg[u].y & 0xFFu) + (q[u] - w0[u])) << shift) | seg[u].x;
+        }
     }
     ROWS_TS(6);
     if (probe && tid == 0) { for (int i = 0; i < 6; i++) atomicAdd(&g_rows_prof[i], ts[i + 1] - ts[i]); atomicAdd(&g_rows_prof[7], 1ull); }
