@@ -205,7 +205,9 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
 // One staged entry of the hand-scheduled walk (see composite_fwd_body): CUR0 / CUR1 = the register quads holding this entry's test
 // operands (mean.x mean.y a' b' | c' w tauq blue), NXT0 / NXT1 = the quads the NEXT entry's operands are requested into; this entry's
 // (red, green, depth, 1) is requested into CUR0 as soon as the mean and the conic have been consumed; v60-v63 temporaries.  Branch targets carry the statement's unique id (%=) and the set's letter.
-#define EX4D_FWD_ENTRY(S, CUR0, CX, CY, CA, CB, CC, CW, CT, CBLUE, NXT0, NXT1, G2RG, G2DA) \
+#define EX4D_FWD_CLAMP "v_min_f32 v60, 0x3f7d70a4, v60\n\t"              /* alpha = min(0.99, w G) */
+#define EX4D_FWD_NOCLAMP ""                                            /* w <= 0.99 and G <= 1 in range: w G <= 0.99 already */
+#define EX4D_FWD_ENTRY(S, CLAMP, CUR0, CX, CY, CA, CB, CC, CW, CT, CBLUE, NXT0, NXT1, G2RG, G2DA) \
     "ds_read_b128 " NXT0 ", %[va] offset:16\n\t" \
     "ds_read_b128 " NXT1 ", %[va] offset:1040\n\t" \
     "s_waitcnt lgkmcnt(2)\n\t"                                   /* this entry's operands (requested one entry earlier) have arrived */ \
@@ -222,7 +224,7 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
     "s_and_b64 %[ok], %[ok], %[live]\n\t" \
     "s_cbranch_scc0 Lskip" S "_%=\n\t"                           /* no live lane in range: nothing to do for this entry */ \
     "v_mul_f32 v60, " CW ", v60\n\t" \
-    "v_min_f32 v60, 0x3f7d70a4, v60\n\t"                         /* alpha = min(0.99, w G) */ \
+    CLAMP \
     "v_fma_f32 v61, -%[T], v60, %[T]\n\t"                        /* test_T = T (1 - alpha), CR/forward.cu:383 */ \
     "v_cmp_gt_f32_e64 %[stop], %[thr], v61\n\t" \
     "s_and_b64 %[stop], %[stop], %[ok]\n\t" \
@@ -243,14 +245,44 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
     "s_add_i32 %[jkey], %[jkey], -1\n\t" \
     "v_add_u32 %[va], 16, %[va]\n\t" \
     "s_cmp_lg_u32 %[jkey], %[jend]\n\t"
-#define EX4D_FWD_RARE(S) \
+#define EX4D_FWD_RARE(S, V) \
     "Lrare" S "_%=:\n\t" \
     "s_andn2_b64 %[live], %[live], %[stop]\n\t" \
     "s_andn2_b64 %[ok], %[ok], %[stop]\n\t"                      /* the lanes that still add */ \
     "s_cbranch_scc1 Ladd" S "_%=\n\t" \
     "s_cmp_eq_u64 %[live], 0\n\t" \
-    "s_cbranch_scc1 Ldead_%=\n\t" \
+    "s_cbranch_scc1 Ldead" V "_%=\n\t" \
     "s_branch Lskip" S "_%=\n"
+
+// the walk over the staged entries of a chunk (labels carry the variant tag V: both variants live in ONE asm statement -- two statements in
+// the arms of an if made the compiler carry the lane masks in vector registers)
+#define EX4D_FWD_WALK_BODY(V, CLAMP) \
+                    "Lgroup" V "_%=:\n\t" \
+                    "s_sub_i32 %[jend], 15, %[rem]\n\t" \
+                    "s_max_i32 %[jend], %[jend], -1\n\t" \
+                    "s_mov_b32 %[jkey], 15\n" \
+                    "Lloop" V "_%=:\n\t" \
+                    EX4D_FWD_ENTRY("a" V, CLAMP, "v[40:43]", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[48:51]", "v[52:55]", "v[40:41]", "v[42:43]") \
+                    "s_cbranch_scc0 Lgdone" V "_%=\n\t" \
+                    EX4D_FWD_ENTRY("b" V, CLAMP, "v[48:51]", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[40:43]", "v[44:47]", "v[48:49]", "v[50:51]") \
+                    "s_cbranch_scc1 Lloop" V "_%=\n" \
+                    "Lgdone" V "_%=:\n\t" \
+                    "v_or_b32 v60, 15, %[dkey]\n\t" \
+                    "v_cmp_gt_u32_e64 %[ok], %[best], v60\n\t" \
+                    "s_add_i32 %[rem], %[rem], -16\n\t" \
+                    "s_nop 1\n\t" \
+                    "v_cndmask_b32_e64 %[dkey], %[dkey], %[best], %[ok]\n\t" \
+                    "v_cndmask_b32_e64 %[dloc], %[dloc], %[va], %[ok]\n\t" \
+                    "v_mov_b32 %[best], 0\n\t" \
+                    "s_cmp_gt_i32 %[rem], 0\n\t" \
+                    "s_cbranch_scc1 Lgroup" V "_%=\n\t" \
+                    "s_branch Ldone_%=\n" \
+                    EX4D_FWD_RARE("a" V, V) \
+                    EX4D_FWD_RARE("b" V, V) \
+                    "Ldead" V "_%=:\n\t" \
+                    "v_add_u32 %[va], 16, %[va]\n\t" \
+                    "s_mov_b32 %[rem], 0\n\t" \
+                    "s_branch Lgdone" V "_%=\n"
 
 template <bool FLOW, bool ASMLOOP>
 __device__ __forceinline__ void composite_fwd_body(
@@ -300,11 +332,13 @@ __device__ __forceinline__ void composite_fwd_body(
         }
         const uint64_t mask = __ballot(keep);
         const int cnt = __popcll(mask);
+        bool sat = false;
         if (keep) {
             const int slot = __popcll(mask & lt);
             const float4 *r = records + 4 * (size_t)id;
             const float4 q2 = r[2];
             const float4 q3 = r[3];
+            sat = !(q3.w <= 0.99f);
             // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
             L.q0[slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
             L.q1[slot] = make_float4(q1.x * kHalfLog2e, q3.w, __uint_as_float(tauq_bits_of(q3.w)), q2.w);
@@ -315,6 +349,7 @@ __device__ __forceinline__ void composite_fwd_body(
             my_list[consumed + slot] = item;          // 8 bytes per survivor, coalesced
         }
         consumed += cnt;
+        const lanemask any_sat = LANES(sat);      // some staged entry can reach the clamp of alpha (rare: opacity x coefficient > 0.99)
         wave_lds_sync();
         // The walk over the staged entries keeps the entry's LDS address in a VGPR that the compiler cannot prove uniform (a uniform
         // index lives in an SGPR and costs a v_mov per ds_read): one v_add per two entries, every read at an immediate offset, and the
@@ -337,43 +372,24 @@ __device__ __forceinline__ void composite_fwd_body(
                 lanemask ok_m, stop_m;
                 int last_addr = -1;
                 uint32_t best_key = 0, dom_loc = 0;
+                // Round 6: alpha = min(0.99, w G) needs its v_min only for entries with w > 0.99 (G <= 1 for every lane in range, and the
+                // product of w <= 0.99 with a factor <= 1 rounds to at most w): chunks without such an entry -- all but a few per cent --
+                // walk without it (one of 22 VALU instructions per entry and lane; same bits).
                 asm volatile(
                     "s_waitcnt lgkmcnt(0)\n\t"                      // nothing of the compiler's in flight: the counts below are this block's own
                     "ds_read_b128 v[40:43], %[va]\n\t"
-                    "ds_read_b128 v[44:47], %[va] offset:1024\n"
-                    "Lgroup_%=:\n\t"
-                    "s_sub_i32 %[jend], 15, %[rem]\n\t"
-                    "s_max_i32 %[jend], %[jend], -1\n\t"            // the group's last key - 1: -1 for a full group
-                    "s_mov_b32 %[jkey], 15\n"
-                    "Lloop_%=:\n\t"
-                    EX4D_FWD_ENTRY("a", "v[40:43]", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[48:51]", "v[52:55]", "v[40:41]", "v[42:43]")
-                    "s_cbranch_scc0 Lgdone_%=\n\t"
-                    EX4D_FWD_ENTRY("b", "v[48:51]", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[40:43]", "v[44:47]", "v[48:49]", "v[50:51]")
-                    "s_cbranch_scc1 Lloop_%=\n"
-                    "Lgdone_%=:\n\t"                                // fold the group's best into the pixel's: strict > on the 28 weight bits
-                    "v_or_b32 v60, 15, %[dkey]\n\t"
-                    "v_cmp_gt_u32_e64 %[ok], %[best], v60\n\t"
-                    "s_add_i32 %[rem], %[rem], -16\n\t"
-                    "s_nop 1\n\t"                                   // VALU-written SGPR pair read as a lane mask: 2 wait states
-                    "v_cndmask_b32_e64 %[dkey], %[dkey], %[best], %[ok]\n\t"
-                    "v_cndmask_b32_e64 %[dloc], %[dloc], %[va], %[ok]\n\t"      // (va: the address behind the group's last entry)
-                    "v_mov_b32 %[best], 0\n\t"
-                    "s_cmp_gt_i32 %[rem], 0\n\t"
-                    "s_cbranch_scc1 Lgroup_%=\n\t"
-                    "s_branch Ldone_%=\n"
-                    EX4D_FWD_RARE("a")
-                    EX4D_FWD_RARE("b")
-                    "Ldead_%=:\n\t"                                 // no live lane left: fold what the group has, then leave
-                    "v_add_u32 %[va], 16, %[va]\n\t"
-                    "s_mov_b32 %[rem], 0\n\t"
-                    "s_branch Lgdone_%=\n"
+                    "ds_read_b128 v[44:47], %[va] offset:1024\n\t"
+                    "s_cmp_lg_u64 %[sat], 0\n\t"
+                    "s_cbranch_scc1 Lgroup1_%=\n"
+                    EX4D_FWD_WALK_BODY("0", EX4D_FWD_NOCLAMP)
+                    EX4D_FWD_WALK_BODY("1", EX4D_FWD_CLAMP)
                     "Ldone_%=:\n\t"
                     "s_mov_b64 exec, -1\n\t"
                     "s_waitcnt lgkmcnt(0)"
                     : [T] "+v"(T), [crg] "+v"(Crg), [dacc] "+v"(Dacc), [c2] "+v"(C2), [best] "+v"(best_key), [last] "+v"(last_addr),
                       [dkey] "+v"(dom_key), [dloc] "+v"(dom_loc), [va] "+v"(va), [live] "+s"(live), [rem] "+s"(rem),
                       [jkey] "=&s"(jkey), [jend] "=&s"(jend), [ok] "=&s"(ok_m), [stop] "=&s"(stop_m)
-                    : [fx] "v"(p.fx), [fy] "v"(p.fy), [thr] "s"(0.0001f)
+                    : [fx] "v"(p.fx), [fy] "v"(p.fy), [thr] "s"(0.0001f), [sat] "s"(any_sat)
                     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
                       "v60", "v61", "v62", "v63", "vcc", "scc", "memory");
                 last_even = last_addr;
@@ -620,7 +636,9 @@ __device__ __forceinline__ float row_scan_add_with_sums_extra(float e, f32x2 &c7
 // NOLAST = true: the batch is full and all of its entries lie in front of every pixel's last contributor (wave-uniform, decided
 // by the caller from the first = deepest entry): the per-pair test `list position < last contributor` is dropped
 // GACC = true: some pixel of the quadrant has an upstream dL_dacc (a third scan per step and its carry)
-template <bool STATS, bool EXTRA, bool SEP, bool NOLAST, bool GACC>
+// CLAMP = false (round 6): no entry of the batch has w > 0.99, so alpha = w G <= 0.99 without the min (G <= 1 for every pair in range,
+// the product of w <= 0.99 with a factor <= 1 rounds to at most w; pairs out of range carry G = 0): one VALU instruction per step less
+template <bool STATS, bool EXTRA, bool SEP, bool NOLAST, bool GACC, bool CLAMP = true>
 __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nvalid, float ox, float oy, float min_depth,
                                           float *__restrict__ acc16)
 {
@@ -692,7 +710,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         // G and alpha of the contributing lanes, exact zeros elsewhere (one select: w is finite, so w * 0 = 0)
         const float G_m = select_f(ok, __builtin_amdgcn_exp2f(-q2), 0.f);
-        const float alpha_m = fminf(0.99f, w * G_m);
+        const float alpha_m = CLAMP ? fminf(0.99f, w * G_m) : w * G_m;
         const float inv = __builtin_amdgcn_rcpf(1.f - alpha_m);
         // T_i = T_carry * prod_{j <= i} inv_j   (the carry is row-uniform: every lane of the row read it from LDS)
         // (the colour dot product c . dL_dpixel is evaluated in the wait states of the product scan)
@@ -913,15 +931,21 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
                 // first entry of the batch = its deepest: wave-uniform read of its list position
                 const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(L.ring[2][head].w));
                 const bool nolast = nb == 16 && kfirst < min_last;
+                // can alpha reach its clamp in this batch?  (opacity x coefficient > 0.99: a few per cent of the batches)
+                const bool clamp = LANES((lane & 15) < nb && !(L.ring[1][ring_wrap<RING>(head + (lane & 15))].y <= 0.99f)) != 0;
 #define BATCH(E, S, N, G) bwd_batch<STATS, E, S, N, G>(L, head, nb, ox, oy, min_depth, acc16)
+#define BATCH_NC(E, N) bwd_batch<STATS, E, true, N, false, false>(L, head, nb, ox, oy, min_depth, acc16)
                 // (quadrants with sub-pixel offsets take the general variant: all scans, all sums)
                 if (!sep) BATCH(true, false, false, true);
                 else if (use_extra) {
                     if (use_gacc) { if (nolast) BATCH(true, true, true, true); else BATCH(true, true, false, true); }
-                    else { if (nolast) BATCH(true, true, true, false); else BATCH(true, true, false, false); }
+                    else if (clamp) { if (nolast) BATCH(true, true, true, false); else BATCH(true, true, false, false); }
+                    else { if (nolast) BATCH_NC(true, true); else BATCH_NC(true, false); }
                 } else if (use_gacc) { if (nolast) BATCH(false, true, true, true); else BATCH(false, true, false, true); }
-                else { if (nolast) BATCH(false, true, true, false); else BATCH(false, true, false, false); }
+                else if (clamp) { if (nolast) BATCH(false, true, true, false); else BATCH(false, true, false, false); }
+                else { if (nolast) BATCH_NC(false, true); else BATCH_NC(false, false); }
 #undef BATCH
+#undef BATCH_NC
                 head = ring_wrap<RING>(head + nb);
                 count -= nb;
                 wave_lds_sync();
