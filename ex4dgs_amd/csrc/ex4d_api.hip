@@ -621,6 +621,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "composite_bwd_variant") && (value == 4 || value == 8)) { g_bwd_variant.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "composite_fwd_asm") && (value == 0 || value == 1)) { ex4d_set_fwd_asm(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "composite_clamp_always") && (value == 0 || value == 1)) { ex4d_set_clamp_always(value); return EX4D_OK; }
     if (name && !strcmp(name, "tile_sort_rows") && (value == 0 || value == 1)) { g_tile_rows.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "rows_probe")) { ex4d_set_rows_probe(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
@@ -641,6 +642,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "composite_bwd_variant")) return g_bwd_variant.load();
     if (name && !strcmp(name, "composite_fwd_asm")) return ex4d_get_fwd_asm();
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
+    if (name && !strcmp(name, "composite_clamp_always")) return ex4d_get_clamp_always();
     if (name && !strcmp(name, "tile_sort_rows")) return g_tile_rows.load();
     if (name && !strcmp(name, "preprocess_sh_predicate")) return ex4d_get_preprocess_tune();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();

@@ -189,7 +189,8 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 // running best is one v_lshl_or_b32 + v_max_u32 per contributing pair; at the end of every group the group's best is folded into the
 // pixel's running (key, location) with the strict compare `key > (best_key | 15)` -- 4 VALU per 16 entries.
 // Every chunk's survivors are appended to the quadrant's compacted list (BinState::qlist) -- all the backward reads of the tile list.
-std::atomic<int> g_fwd_asm{1};      // compositing forward: hand-scheduled walk (1, default) or the compiler's (0)
+std::atomic<int> g_fwd_asm{1};
+std::atomic<int> g_alpha_clamp_always{0};      // "composite_clamp_always" = 1: every chunk / batch evaluates min(0.99, w G) (rounds 1-5; A/B runs)      // compositing forward: hand-scheduled walk (1, default) or the compiler's (0)
 
 struct FwdLds {                  // per wave: the survivors of one 64-entry chunk (4.5 KB; the kernel's VGPRs, not LDS, bound its occupancy)
     float4 q0[64];               // mean.x, mean.y, a', b'
@@ -293,7 +294,7 @@ __device__ __forceinline__ void composite_fwd_body(
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
     float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
-    FwdLds &L)
+    FwdLds &L, int clamp_always)
 {
     const int lane = threadIdx.x & 63;
     const uint2 range = ranges[tile];
@@ -338,7 +339,7 @@ __device__ __forceinline__ void composite_fwd_body(
             const float4 *r = records + 4 * (size_t)id;
             const float4 q2 = r[2];
             const float4 q3 = r[3];
-            sat = !(q3.w <= 0.99f);
+            sat = clamp_always || !(q3.w <= 0.99f);
             // alpha = w exp(power) = w exp2(dx (a' dx + b' dy) + c' dy^2): fold -1/2 and log2(e) once per Gaussian
             L.q0[slot] = make_float4(q0.x, q0.y, q0.z * kHalfLog2e, q0.w * kNegLog2e);
             L.q1[slot] = make_float4(q1.x * kHalfLog2e, q3.w, __uint_as_float(tauq_bits_of(q3.w)), q2.w);
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount)
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount, int clamp_always)
 {
     __shared__ FwdLds lds;
     int tile, quad;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     if (tile >= num_tiles) return;
     const PixelGeom p = pixel_of_lane(tile, quad, gx, W, H, subpixel_offset);
     composite_fwd_body<FLOW, ASMLOOP>(W, H, gx, tile, quad, p, ranges, point_list, records, bg, max_depth, final_T, n_contrib, out_color, out_depth, out_acc,
-                             out_flow, out_idx, qlist, qcount, lds);
+                             out_flow, out_idx, qlist, qcount, lds, clamp_always);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,9 +637,9 @@ __device__ __forceinline__ float row_scan_add_with_sums_extra(float e, f32x2 &c7
 // NOLAST = true: the batch is full and all of its entries lie in front of every pixel's last contributor (wave-uniform, decided
 // by the caller from the first = deepest entry): the per-pair test `list position < last contributor` is dropped
 // GACC = true: some pixel of the quadrant has an upstream dL_dacc (a third scan per step and its carry)
-// CLAMP = false (round 6): no entry of the batch has w > 0.99, so alpha = w G <= 0.99 without the min (G <= 1 for every pair in range,
-// the product of w <= 0.99 with a factor <= 1 rounds to at most w; pairs out of range carry G = 0): one VALU instruction per step less
-template <bool STATS, bool EXTRA, bool SEP, bool NOLAST, bool GACC, bool CLAMP = true>
+// (Round 6, measured and dropped: batches without an entry of w > 0.99 running a variant without the min of alpha = min(0.99, w G) --
+// one VALU instruction per step less, the same bits; same-box A/B 0.2433 vs 0.2420 ms: nothing.  The forward keeps its version of it.)
+template <bool STATS, bool EXTRA, bool SEP, bool NOLAST, bool GACC>
 __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nvalid, float ox, float oy, float min_depth,
                                           float *__restrict__ acc16)
 {
@@ -710,7 +711,7 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         if (ok == 0) continue;                 // nothing changes: T, E, gacc carries stay, the sums get zeros
         // G and alpha of the contributing lanes, exact zeros elsewhere (one select: w is finite, so w * 0 = 0)
         const float G_m = select_f(ok, __builtin_amdgcn_exp2f(-q2), 0.f);
-        const float alpha_m = CLAMP ? fminf(0.99f, w * G_m) : w * G_m;
+        const float alpha_m = fminf(0.99f, w * G_m);
         const float inv = __builtin_amdgcn_rcpf(1.f - alpha_m);
         // T_i = T_carry * prod_{j <= i} inv_j   (the carry is row-uniform: every lane of the row read it from LDS)
         // (the colour dot product c . dL_dpixel is evaluated in the wait states of the product scan)
@@ -931,21 +932,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
                 // first entry of the batch = its deepest: wave-uniform read of its list position
                 const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(L.ring[2][head].w));
                 const bool nolast = nb == 16 && kfirst < min_last;
-                // can alpha reach its clamp in this batch?  (opacity x coefficient > 0.99: a few per cent of the batches)
-                const bool clamp = LANES((lane & 15) < nb && !(L.ring[1][ring_wrap<RING>(head + (lane & 15))].y <= 0.99f)) != 0;
 #define BATCH(E, S, N, G) bwd_batch<STATS, E, S, N, G>(L, head, nb, ox, oy, min_depth, acc16)
-#define BATCH_NC(E, N) bwd_batch<STATS, E, true, N, false, false>(L, head, nb, ox, oy, min_depth, acc16)
                 // (quadrants with sub-pixel offsets take the general variant: all scans, all sums)
                 if (!sep) BATCH(true, false, false, true);
                 else if (use_extra) {
                     if (use_gacc) { if (nolast) BATCH(true, true, true, true); else BATCH(true, true, false, true); }
-                    else if (clamp) { if (nolast) BATCH(true, true, true, false); else BATCH(true, true, false, false); }
-                    else { if (nolast) BATCH_NC(true, true); else BATCH_NC(true, false); }
+                    else { if (nolast) BATCH(true, true, true, false); else BATCH(true, true, false, false); }
                 } else if (use_gacc) { if (nolast) BATCH(false, true, true, true); else BATCH(false, true, false, true); }
-                else if (clamp) { if (nolast) BATCH(false, true, true, false); else BATCH(false, true, false, false); }
-                else { if (nolast) BATCH_NC(false, true); else BATCH_NC(false, false); }
+                else { if (nolast) BATCH(false, true, true, false); else BATCH(false, true, false, false); }
 #undef BATCH
-#undef BATCH_NC
                 head = ring_wrap<RING>(head + nb);
                 count -= nb;
                 wave_lds_sync();
@@ -957,6 +952,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 }  // namespace
 
 void ex4d_set_fwd_asm(int on) { g_fwd_asm.store(on); }
+void ex4d_set_clamp_always(int on) { g_alpha_clamp_always.store(on); }
+int ex4d_get_clamp_always() { return g_alpha_clamp_always.load(); }
 int ex4d_get_fwd_asm() { return g_fwd_asm.load(); }
 
 hipError_t ex4d_bwd_stats(unsigned long long *out, int count, int reset)
@@ -977,7 +974,7 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
     const int slots = 8 * ((T + 7) / 8);
 #define FWD_LAUNCH(FLOW) hipLaunchKernelGGL((composite_fwd_kernel<FLOW, ASM>), dim3(4 * slots), dim3(64), 0, stream, \
         prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, records, bg, \
-        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, qlist, qcount)
+        prm.max_depth, final_T, n_contrib, out_color, out_depth, out_acc, out_flow, out_idx, qlist, qcount, g_alpha_clamp_always.load(std::memory_order_relaxed))
     if (has_flow) { constexpr bool ASM = false; FWD_LAUNCH(true); }
     else if (g_fwd_asm.load(std::memory_order_relaxed)) { constexpr bool ASM = true; FWD_LAUNCH(false); }
     else { constexpr bool ASM = false; FWD_LAUNCH(false); }

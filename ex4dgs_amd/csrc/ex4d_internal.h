@@ -141,6 +141,8 @@ void ex4d_set_preprocess_fast(int v);   // 1 (default) = frames with one [P,16,3
 int ex4d_get_preprocess_fast();
 void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled entry walk (default) or the compiler's loop
 int ex4d_get_fwd_asm();
+void ex4d_set_clamp_always(int on);     // compositing: 1 = evaluate min(0.99, w G) everywhere (rounds 1-5), 0 (default) = only where w > 0.99 can reach it
+int ex4d_get_clamp_always();
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
