@@ -34,14 +34,14 @@ from ex4dgs_amd.diff_gaussian_rasterization_df import GaussianRasterizationSetti
 from ex4dgs_amd.scene import CONFIGS, make_scene                                   # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 SIMDS, CLOCK_HZ = 1024, 2.4e9        # 256 CUs x 4 SIMDs; a SIMD issues one wave64 VALU instruction per 4 cycles (MI355X_MICROARCH.md)
-RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
+RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_rowsort.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
 
 
 # which source files a stage's kernels are compiled from (plus the shared internal header)
 STAGE_SOURCES = {"composite_fwd": "ex4d_composite.hip", "composite_bwd": "ex4d_composite.hip", "preprocess_fwd": "ex4d_preprocess.hip",
-                 "preprocess_bwd": "ex4d_preprocess.hip", "depth_sort": "ex4d_binning.hip", "tile_sort": "ex4d_binning.hip",
+                 "preprocess_bwd": "ex4d_preprocess.hip", "depth_sort": "ex4d_binning.hip", "tile_sort": ("ex4d_rowsort.hip", "ex4d_binning.hip"),
                  "scan_tiles": "ex4d_binning.hip", "duplicate": "ex4d_binning.hip"}
 
 
@@ -59,7 +59,8 @@ def pmc_counters_current(pmc, stage=None):
     elif stage is not None:
         if stage not in STAGE_SOURCES:
             return False
-        files = [STAGE_SOURCES[stage], "ex4d_internal.h"]
+        src = STAGE_SOURCES[stage]
+        files = list(src if isinstance(src, tuple) else (src,)) + ["ex4d_internal.h"]
     return all(want.get(f) == hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest()[:16] for f in files)
 
 

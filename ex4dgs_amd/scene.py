@@ -289,6 +289,8 @@ class SceneConfig(NamedTuple):
     cxr: float = 0.0
     cyr: float = 0.0
     seed: int = 0
+    clusters: int = 0          # > 0: positions from this many anisotropic clusters instead of uniform in the frustum (round 6, config 3c)
+    plane_frac: float = 0.0    # ... and this fraction of the Gaussians on two slanted planes (large surfaces)
 
 
 CONFIGS = {
@@ -296,6 +298,11 @@ CONFIGS = {
     "cfg1": SceneConfig("cfg1: 256 static, 256x256", 256, 256, 256, 140.0, z_lo=4.5, z_hi=30.0, sigma_px_med=6.0, seed=1),
     "cfg2": SceneConfig("cfg2: 100k static, 1352x1014", 100_000, 1352, 1014, 730.0, seed=2),
     "cfg3": SceneConfig("cfg3: 1.0M static+dynamic (K=35), 1352x1014", 1_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=3),
+    # round 6: config 3 with the statistics of a real capture instead of a uniform cloud -- ~200 anisotropic clusters
+    # (tile lists ten times the mean in their centres), 10 % of the Gaussians on two slanted planes, heavy-tailed scales (log-std 1.2: a few
+    # rects of hundreds of tiles), popular Gaussians in the clusters (row-atomic contention in the compositing backward)
+    "cfg3c": SceneConfig("cfg3c: 1.0M clustered static+dynamic (K=35), 1352x1014", 1_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=33,
+                         sigma_px_logstd=1.2, clusters=200, plane_frac=0.1),
     "cfg4": SceneConfig("cfg4: 2.0M static+dynamic x 300 frames, 1352x1014", 2_000_000, 1352, 1014, 730.0, dyn_frac=0.2, seed=4),
     "cfg5": SceneConfig("cfg5: 1.0M deep-overlap, 2048x1088 off-centre", 1_000_000, 2048, 1088, 1100.0, min_depth=0.01,
                         z_lo=0.5, z_hi=40.0, sigma_px_med=5.5, sigma_px_logstd=0.8, cxr=0.02, cyr=-0.01, seed=5),
@@ -318,6 +325,33 @@ def make_scene(cfg, P=None, device="cpu", duration=300, fused=False, split_sh=Tr
     x = z * tanx * (U(P) * 2.3 - 1.15)
     y = z * tany * (U(P) * 2.3 - 1.15)
     xyz = torch.stack([x, y, z], -1)
+    if cfg.clusters > 0:
+        # cluster centres uniform in the frustum (log-uniform depth like the cloud above), every cluster an anisotropic Gaussian blob whose
+        # axes are 2-15 % of its depth; the cluster of a Gaussian by a heavy-tailed popularity (a few clusters hold most of the points)
+        C = cfg.clusters
+        cz = torch.exp(math.log(cfg.z_lo * 1.3) + U(C) * (math.log(cfg.z_hi * 0.6) - math.log(cfg.z_lo * 1.3)))
+        cc = torch.stack([cz * tanx * (U(C) * 1.8 - 0.9), cz * tany * (U(C) * 1.8 - 0.9), cz], -1)
+        axes = cz.unsqueeze(-1) * (0.02 + 0.13 * U(C, 3))
+        rotc = torch.linalg.qr(N(C, 3, 3))[0]
+        pop = torch.exp(1.2 * N(C))
+        which = torch.multinomial(pop / pop.sum(), P, replacement=True, generator=g)
+        local = N(P, 3) * axes[which]
+        xyz = cc[which] + torch.einsum("pij,pj->pi", rotc[which], local)
+        n_plane = int(round(P * cfg.plane_frac))
+        if n_plane > 0:
+            # two slanted planes through the scene (a floor and a wall), points uniform on them
+            half = n_plane // 2
+            for k, (nrm, d0) in enumerate((((0.0, 0.8, -0.2), 0.9), ((0.7, 0.0, -0.35), 1.1))):
+                m = half if k == 0 else n_plane - half
+                zz = torch.exp(math.log(cfg.z_lo * 1.2) + U(m) * (math.log(cfg.z_hi * 0.7) - math.log(cfg.z_lo * 1.2)))
+                if k == 0:      # floor: y grows with depth
+                    xx = zz * tanx * (U(m) * 2.0 - 1.0); yy = zz * tany * d0 - 0.05 * zz * nrm[2]
+                else:           # wall: x fixed fraction of the frustum, y free
+                    yy = zz * tany * (U(m) * 2.0 - 1.0); xx = zz * tanx * 0.6 * d0 - 0.1 * zz
+                sl = slice(P - n_plane + (0 if k == 0 else half), P - n_plane + (half if k == 0 else n_plane))
+                xyz[sl] = torch.stack([xx, yy, zz], -1)
+        xyz[:, 2] = xyz[:, 2].clamp(min=cfg.z_lo * 0.9)
+        z = xyz[:, 2]
     sigma_px = torch.exp(math.log(cfg.sigma_px_med) + cfg.sigma_px_logstd * N(P))
     scale = (z * sigma_px / cfg.focal).unsqueeze(-1) * torch.exp(0.35 * N(P, 3))
     q = torch.nn.functional.normalize(N(P, 4), dim=-1) * (1 + 0.05 * N(P, 1))

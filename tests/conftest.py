@@ -49,6 +49,19 @@ def hip_lib_defaults(hip_lib):
     _C.set_option("geom_debug_arrays", 1)
 
 
+@pytest.fixture(params=["test_options", "library_defaults"])
+def hip_lib_both(request, hip_lib):
+    """The cheap edge cases run twice: with the arrays the oracle comparison wants materialised (`hip_lib`) and on the library exactly as
+    bench.py times it (lean geometry path, covariance recomputed in the backward, no sorted tile ids) -- VERDICT r05 weak #2."""
+    from ex4dgs_amd import _C
+    if request.param == "library_defaults":
+        _C.set_option("binning_tile_ids", 0)
+        _C.set_option("geom_debug_arrays", 0)
+    yield hip_lib
+    _C.set_option("binning_tile_ids", 1)
+    _C.set_option("geom_debug_arrays", 1)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Parity numbers of the run (achieved max-abs / relative errors per gradient tensor, fragile-pixel counts) -> gpurun_out/parity_report.json,
     so that "1e-5" is a number in a file and not only an assertion that passed."""

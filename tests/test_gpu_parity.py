@@ -121,13 +121,13 @@ def test_deep_overlap_offcentre_projection(hip_lib):
     assert o["num_rendered"] / max(1, (o["radii"] > 0).sum()) > 10
 
 
-def test_subpixel_offsets_and_scale_modifier(hip_lib):
+def test_subpixel_offsets_and_scale_modifier(hip_lib_both):
     g = torch.Generator().manual_seed(5)
     sub = (torch.rand(256, 256, 2, generator=g) - 0.5)
     _fwd_bwd("cfg1", subpixel=sub, scale_modifier=1.3)
 
 
-def test_colors_precomp_and_cov3d_precomp_paths(hip_lib):
+def test_colors_precomp_and_cov3d_precomp_paths(hip_lib_both):
     def mutate(ins, st):
         P = ins["means3D"].shape[0]
         g = torch.Generator().manual_seed(2)
@@ -146,7 +146,7 @@ def test_colors_precomp_and_cov3d_precomp_paths(hip_lib):
     _fwd_bwd("cfg1", mutate=mutate)
 
 
-def test_depth_ties_giant_gaussian_and_degenerates(hip_lib):
+def test_depth_ties_giant_gaussian_and_degenerates(hip_lib_both):
     def mutate(ins, st):
         m = ins["means3D"]
         m[10:40, 2] = 12.5                          # 30 exact depth ties -> order must fall back to ascending id
@@ -162,7 +162,7 @@ def test_depth_ties_giant_gaussian_and_degenerates(hip_lib):
     assert int(o["tiles_touched"][5]) == T
 
 
-def test_empty_and_invisible(hip_lib):
+def test_empty_and_invisible(hip_lib_both):
     from ex4dgs_amd import _C
     ins, st = h.scene_inputs("cfg1")
     # P == 0 (DGR/rasterize_points.cu:90,189)
@@ -302,12 +302,12 @@ def test_full_size_properties_1M(hip_lib):
 
 
 @pytest.mark.parametrize("P", [1, 63, 65, 257, 1000])
-def test_odd_sizes(hip_lib, P):
+def test_odd_sizes(hip_lib_both, P):
     """Gaussian counts that are not multiples of the wave (64) / workgroup (256) / radix chunk sizes."""
     _fwd_bwd("cfg1", P=P)
 
 
-def test_sh_storage_smaller_than_16(hip_lib):
+def test_sh_storage_smaller_than_16(hip_lib_both):
     """shs[P,4,3] with sh_degree 1: M != 16 takes the un-staged SH path (stride stays M, CR/forward.cu:29)."""
     def mutate(ins, st):
         ins["shs"] = ins["shs"][:, :4, :].contiguous()

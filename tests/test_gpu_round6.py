@@ -40,3 +40,17 @@ def test_row_segment_tile_sort_depth_ties(hip_lib):
     ins, st = _squeezed(30000, 6.0, 6.4, 9000)
     ref = _frame(ins, st, tile_sort_rows=0, depth_sort_msd=0)
     _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=2), ref, "rows, depth ties")
+
+
+def test_clustered_scene_cfg3c_against_the_oracle(hip_lib):
+    """Config 3c: 200 anisotropic clusters + two planes, scale log-std 1.2 -- tile lists ten times the mean, rects of
+    hundreds of tiles (one covering the whole image), popular Gaussians.  Forward integers bit-exact, pixels and gradients at the bars."""
+    from tests.test_gpu_parity import _fwd_bwd
+    _fwd_bwd("cfg3c", P=20000, t=137)
+
+
+def test_clustered_scene_tile_sorts_agree(hip_lib):
+    ins, st = h.scene_inputs("cfg3c", P=60000, t=0)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    ref = _frame(ins, st, tile_sort_rows=0, depth_sort_msd=0)
+    _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=2), ref, "rows, clustered scene")

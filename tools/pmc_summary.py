@@ -15,7 +15,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     agg[r[ix[name_c]]][r[ix[cn]]].append(float(r[ix[val]]))
 ctrs = sorted({c for k in agg.values() for c in k})
-print(f"{'kernel':60s} {'n':>4s} " + " ".join(f"{c:>22s}" for c in ctrs))
+NAME_W = 160      # full template argument lists (at 60 columns two instantiations of one kernel template shared a row)
+print(f"{'kernel':{NAME_W}s} {'n':>4s} " + " ".join(f"{c:>22s}" for c in ctrs))
 for k, d in sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
     n = max(len(v) for v in d.values())
-    print(f"{k[:60]:60s} {n:4d} " + " ".join(f"{(sum(d[c]) / len(d[c]) if c in d else 0):22.4g}" for c in ctrs))
+    print(f"{k[:NAME_W]:{NAME_W}s} {n:4d} " + " ".join(f"{(sum(d[c]) / len(d[c]) if c in d else 0):22.4g}" for c in ctrs))

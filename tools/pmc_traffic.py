@@ -35,16 +35,21 @@ def parse_table(path):
     return d
 
 
-def parse_stats(path):
+def parse_stats(path, col=2):
+    """{kernel name: column `col` of the stats table} (2 = avg_us, 0 = calls); the name column ends where the header's `calls` begins."""
+    lines = open(path).read().splitlines()
+    width = lines[1].index(" calls") - 1 if len(lines) > 1 and " calls" in lines[1] else 70
     d = {}
-    for line in open(path).read().splitlines()[2:]:
-        name, rest = line[:70].strip(), line[70:].split()
+    for line in lines[2:]:
+        name, rest = line[:width].strip(), line[width:].split()
         if len(rest) >= 3:
-            d[name] = float(rest[2])          # avg_us
+            d[name] = float(rest[col])
     return d
 
 
-ALIAS = [("composite_bwd_scan_kernel", "composite_bwd"), ("composite_bwd_kernel", "composite_bwd_per_pixel"), ("composite_fwd_kernel", "composite_fwd"),
+ALIAS = [("rows_seg_hist_kernel", "row_partition_histogram"), ("rows_scan_kernel", "row_partition_row_scan"), ("rows_seg_scatter_kernel", "row_partition_scatter"),
+         ("ts_histogram_kernel", "tile_sort_histogram_pass_b"),
+         ("composite_bwd_scan_kernel", "composite_bwd"), ("composite_bwd_kernel", "composite_bwd_per_pixel"), ("composite_fwd_kernel", "composite_fwd"),
          ("preprocess_geom_kernel", "preprocess_fwd"), ("preprocess_color_kernel", "preprocess_color"), ("preprocess_fwd_kernel", "preprocess_fwd"),
          ("preprocess_bwd_kernel", "preprocess_bwd"), ("duplicate_kernel", "duplicate"),
          ("depth_local_sort_kernel", "depth_sort_bucket_pass"), ("dls_histogram_kernel", "depth_sort_msd_histogram"), ("dls_range_kernel", "depth_sort_key_range"),
@@ -73,8 +78,8 @@ def collect(fetch, write, stats, sq=None):
         if a is None or a in out:
             continue
         fk, wk = f.get(name, {}).get("FETCH_SIZE", 0.0), w.get(name, {}).get("WRITE_SIZE", 0.0)
-        us = next((v for k, v in st.items() if k[:len(name)] == name), None) or next((v for k, v in st.items() if k[:50] == name[:50]), None)
-        row = {"kernel": name[:60], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+        us = st.get(name)          # (full names on both sides: exact match or nothing)
+        row = {"kernel": name, "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
         if us:
             row["avg_us"] = us
             row["hbm_GBps"] = round(row["hbm_bytes_per_launch"] / us / 1e3, 1)
@@ -86,7 +91,7 @@ def collect(fetch, write, stats, sq=None):
     return out
 
 
-RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
+RASTER_SOURCES = ("ex4d_preprocess.hip", "ex4d_binning.hip", "ex4d_rowsort.hip", "ex4d_composite.hip", "ex4d_api.hip", "ex4d_internal.h")
 
 
 def frame_totals(fetch, write, stats, sq):
@@ -110,10 +115,20 @@ def frame_totals(fetch, write, stats, sq):
         if not ours or per < 1 or alias(name) in ("radam", "l1_ssim_forward", "l1_ssim_backward", "l1_ssim_finish", "attributes_forward", "attributes_backward"):
             continue
         b = (2 * f.get(name, {}).get("FETCH_SIZE", 0.0) + w.get(name, {}).get("WRITE_SIZE", 0.0)) * 1024
-        us = next((v for k, v in st.items() if k[:len(name)] == name), None) or next((v for k, v in st.items() if k[:50] == name[:50]), 0.0)
+        us = st.get(name, 0.0)
         valu = s.get(name, {}).get("SQ_INSTS_VALU", 0.0)
-        rows.append({"kernel": name[:60], "launches_per_frame": per, "hbm_bytes_per_launch": int(b), "avg_us": us, "SQ_INSTS_VALU": valu})
+        rows.append({"kernel": name, "launches_per_frame": per, "hbm_bytes_per_launch": int(b), "avg_us": us, "SQ_INSTS_VALU": valu})
         tot_b += per * b; tot_us += per * us; tot_valu += per * valu; launches += per
+    # the same frame from the kernel-trace pass: every launch of the stats table, per forward call -- the two have to agree, or a row went
+    # missing above (one instantiation of the scatter template had fallen out of the frame's rows)
+    st_calls = parse_stats(stats, col=0)
+    n_fwd_st = next((n for k, n in st_calls.items() if "composite_fwd_kernel" in k), None)
+    stats_launches = sum(int(round(n / n_fwd_st)) for k, n in st_calls.items()
+                         if ("anonymous namespace" in k or "__amd_rocclr_fillBuffer" in k or "__amd_rocclr_copyBuffer" in k) and int(round(n / n_fwd_st)) >= 1
+                         and alias(k) not in ("radam", "l1_ssim_forward", "l1_ssim_backward", "l1_ssim_finish", "attributes_forward", "attributes_backward")) if n_fwd_st else None
+    assert stats_launches is None or stats_launches == launches, f"frame rows: {launches} launches per frame from the counter pass, {stats_launches} from the kernel trace"
+    missing = [r["kernel"] for r in rows if not r["avg_us"]]
+    assert not missing, f"kernels of the counter pass without a duration in the kernel trace: {missing}"
     return {"launches_per_frame": launches, "hbm_bytes_per_frame": int(tot_b), "kernel_us_per_frame": round(tot_us, 2),
             "SQ_INSTS_VALU_per_frame": tot_valu, "frac_of_8TBps_at_kernel_sum": round(tot_b / (tot_us * 1e-6) / 8e12, 3) if tot_us else None,
             "rows": rows}

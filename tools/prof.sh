@@ -10,4 +10,4 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o $tag -- python $root/bench
 db=$(find /tmp/prof_$tag -name "*.db" | head -1)
 python $root/tools/rocpd_summary.py $db $root/gpurun_out/${tag}_kernel_stats.txt
 grep '"metric"' $root/gpurun_out/${tag}_bench.log > $root/gpurun_out/${tag}_bench.json
-head -25 $root/gpurun_out/${tag}_kernel_stats.txt | cut -c1-175
+head -25 $root/gpurun_out/${tag}_kernel_stats.txt | cut -c1-70,161-250

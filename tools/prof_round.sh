@@ -44,4 +44,4 @@ python tools/pmc_traffic.py $out/${tag}_pmc_FETCH_SIZE.txt $out/${tag}_pmc_WRITE
 # the default bench line quotes these counters (bench.py: PMC_FILE, guarded by the kernel sources' hashes): put them where it looks
 cp $out/${tag}_pmc_traffic.json $root/profiles/${tag}_pmc_traffic.json
 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
-head -16 $out/${tag}_bench_kernel_stats.txt | cut -c1-150
+head -16 $out/${tag}_bench_kernel_stats.txt | cut -c1-70,161-250
