@@ -499,7 +499,7 @@ def binning_views(binningBuffer, R, W, H):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(point_list=b[lay.point_list: lay.point_list + 4 * R].view(torch.int32),
                 tile_ids=b[lay.tile_ids: lay.tile_ids + 4 * R].view(torch.int32),
-                qlist=b[lay.qlist: lay.qlist + 32 * max(R, 1)].view(torch.int32).view(-1, 2),
+                qlist=b[lay.qlist: lay.qlist + 16 * max(R, 1)].view(torch.int32),
                 qcount=b[lay.qcount: lay.qcount + 16 * T].view(torch.int32).view(T, 4))
 
 

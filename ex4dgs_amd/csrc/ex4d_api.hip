@@ -233,15 +233,17 @@ BinState carve_binning(void *buf, uint32_t R, int W, int H, Ex4dBinningLayout *l
     const size_t n = R ? R : 1;
     l.point_list = c.off; b.point_list = c.take<uint32_t>(n);
     l.tile_ids = c.off;   b.tile_ids = c.take<uint32_t>(n);
-    b.vals_tmp = c.take<uint32_t>(n);
-    b.keys_tmp = c.take<uint32_t>(n);
     const int tb = tile_bits(T);
     const int cgx = (W + EX4D_TILE - 1) / EX4D_TILE, cgy = (H + EX4D_TILE - 1) / EX4D_TILE;
     const size_t hw = ex4d_radix_hist_words(R), hw2 = ex4d_tile_sort_hist_words(R, tb);
     const size_t hw3 = (cgx <= 255 && cgy <= 255) ? ex4d_tile_sort_rows_hist_words(R) : 0;
     const size_t hwm = hw > hw2 ? hw : hw2;
     b.sort_hist = c.take<uint32_t>(hwm > hw3 ? hwm : hw3);
-    l.qlist = c.off;  b.qlist = c.take<uint2>(4 * n);
+    l.qlist = c.off;  b.qlist = c.take<uint32_t>(4 * n);
+    // (round 6) the two scratch arrays of the tile sort live INSIDE the compacted-list region: the sort is over before the compositing
+    // forward writes its first list entry (8 of the 16 bytes per instance the lists reserve)
+    b.vals_tmp = b.qlist;
+    b.keys_tmp = b.qlist ? b.vals_tmp + ex4d_align_up(n * sizeof(uint32_t)) / sizeof(uint32_t) : nullptr;
     l.qcount = c.off; b.qcount = c.take<uint32_t>(4 * (size_t)T);
     l.total = c.off;
     if (lay) *lay = l;

@@ -293,7 +293,7 @@ __device__ __forceinline__ void composite_fwd_body(
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount,
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint32_t *__restrict__ qlist, uint32_t *__restrict__ qcount,
     FwdLds &L, int clamp_always)
 {
     const int lane = threadIdx.x & 63;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void composite_fwd_body(
     const float bx0 = wave_min(p.fx), bx1 = wave_max(p.fx), by0 = wave_min(p.fy), by1 = wave_max(p.fy);
     const uint64_t lt = (1ull << lane) - 1ull;
     // this quadrant's compacted list for the backward pass (ex4d_internal.h: BinState::qlist)
-    uint2 *const my_list = qlist + 4 * (size_t)range.x + (size_t)wave * (size_t)n;
+    uint32_t *const my_list = qlist + 4 * (size_t)range.x + (size_t)wave * (size_t)n;
     int consumed = 0;
 
     lanemask live = LANES(p.inside);          // lanes still compositing (CR/forward.cu: !done)
@@ -347,7 +347,7 @@ __device__ __forceinline__ void composite_fwd_body(
             if (FLOW) L.f[slot] = q3;
             const uint2 item = make_uint2(id, (uint32_t)k);
             L.it[slot] = item;
-            my_list[consumed + slot] = item;          // 8 bytes per survivor, coalesced
+            my_list[consumed + slot] = (uint32_t)k;   // the survivor's position in the tile list: 4 bytes, coalesced (round 6; rounds 3-5: 8 with the id)
         }
         consumed += cnt;
         const lanemask any_sat = LANES(sat);      // some staged entry can reach the clamp of alpha (rare: opacity x coefficient > 0.99)
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const float *__restrict__ bg, float max_depth,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_acc,
-    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint2 *__restrict__ qlist, uint32_t *__restrict__ qcount, int clamp_always)
+    float *__restrict__ out_flow, int32_t *__restrict__ out_idx, uint32_t *__restrict__ qlist, uint32_t *__restrict__ qcount, int clamp_always)
 {
     __shared__ FwdLds lds;
     int tile, quad;
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpixels, const float *__restrict__ dL_ddepths,
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
-    float *__restrict__ acc16, const uint2 *__restrict__ qlist, const uint32_t *__restrict__ qcount)
+    float *__restrict__ acc16, const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount)
 {
     constexpr int RING = BWD_RING;
     __shared__ BwdLdsT<RING> lds[WPB];
@@ -904,16 +904,23 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
         // order.  Entries at or behind the quadrant's deepest contributor touch no pixel and are dropped (they form the tail of the list).
         const uint32_t qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcount[4 * tile + quad]);
         const uint32_t list_len = range.y - range.x;
-        const uint2 *ql = qlist + 4 * (size_t)range.x + (size_t)quad * (size_t)list_len;
+        const uint32_t *ql = qlist + 4 * (size_t)range.x + (size_t)quad * (size_t)list_len;
+        const uint32_t *pl = point_list + range.x;
         const int nchunks = (int)((qn + 63u) >> 6);
         const int b = 63 - lane;
         const uint64_t lt = (1ull << lane) - 1ull;
-        // the entries of chunk c - 1 are requested while chunk c is processed: a chunk waits for ONE memory round trip (its records)
-        uint2 it_n = make_uint2(0u, 0xFFFFFFFFu);
-        if (nchunks > 0) { const uint32_t e = 64u * (uint32_t)(nchunks - 1) + (uint32_t)b; if (e < qn) it_n = ql[e]; }
+        // Round 6: the list holds positions only (16 instead of 32 bytes of capacity per instance); the Gaussian id is point_list[position].
+        // Two stages run ahead of the chunk being processed -- the positions of chunk c - 2 and the ids of chunk c - 1 are requested while
+        // chunk c is processed -- so a chunk still waits for ONE memory round trip (its records).
+        uint32_t pos_n = 0xFFFFFFFFu, pos_n2 = 0xFFFFFFFFu, id_n = 0u;       // (entries past the end carry position 0xFFFFFFFF)
+        if (nchunks > 0) { const uint32_t e = 64u * (uint32_t)(nchunks - 1) + (uint32_t)b; if (e < qn) pos_n = ql[e]; }
+        if (nchunks > 1) pos_n2 = ql[64u * (uint32_t)(nchunks - 2) + (uint32_t)b];          // chunk c - 1 lies wholly inside the list
+        if (pos_n != 0xFFFFFFFFu) id_n = pl[pos_n];
         for (int c = nchunks - 1; c >= 0; c--) {
-            const uint2 it = it_n;
-            if (c > 0) it_n = ql[64u * (uint32_t)(c - 1) + (uint32_t)b];          // chunk c - 1 lies wholly inside the list
+            const uint2 it = make_uint2(id_n, pos_n);
+            pos_n = pos_n2;
+            if (c > 0) id_n = pl[pos_n];
+            if (c > 1) pos_n2 = ql[64u * (uint32_t)(c - 2) + (uint32_t)b];
             const bool valid = it.y < deepest;                    // (entries past the end carry position 0xFFFFFFFF)
             const uint64_t mask = __ballot(valid);
             if (valid) {
@@ -966,7 +973,7 @@ hipError_t ex4d_bwd_stats(unsigned long long *out, int count, int reset)
 
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint32_t *qlist, uint32_t *qcount,
     bool has_flow, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;
@@ -987,7 +994,7 @@ hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges,
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount,
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint32_t *qlist, const uint32_t *qcount,
     int variant, hipStream_t stream)
 {
     const int gx = (prm.W + EX4D_TILE - 1) / EX4D_TILE, gy = (prm.H + EX4D_TILE - 1) / EX4D_TILE;

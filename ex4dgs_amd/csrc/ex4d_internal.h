@@ -53,7 +53,7 @@ struct BinState {
     // backward still paid a load + compaction round per chunk for ~4 survivors).
     // Quadrant q of a tile whose range is [r0, r1) owns qlist[4 r0 + q (r1 - r0) ...) (capacity = the list length: every entry could
     // survive); qcount[4 tile + q] entries of it are valid.  Only the valid prefix is ever touched (~6 % of 4 R entries).
-    uint2 *qlist;
+    uint32_t *qlist;          // (round 6: list positions only -- the id is point_list[range.x + position])
     uint32_t *qcount;
 };
 struct ImgState {
@@ -146,13 +146,13 @@ void ex4d_set_clamp_always(int on);     // compositing: 1 = evaluate min(0.99, w
 int ex4d_get_clamp_always();
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
-    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint2 *qlist, uint32_t *qcount,
+    float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint32_t *qlist, uint32_t *qcount,
     bool has_flow, hipStream_t stream);
 
 hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float *bg, const float4 *records, const float *out_depth, const float *out_acc,
     const float *final_T, const uint32_t *n_contrib, const float *dL_dpix, const float *dL_ddepth,
-    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint2 *qlist, const uint32_t *qcount,
+    const float *dL_dflow, const float *dL_dacc, float *acc16, const uint32_t *qlist, const uint32_t *qcount,
     int variant, hipStream_t stream);
 
 // developer statistics of the scan compositing backward (variant 8)

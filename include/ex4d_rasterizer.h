@@ -191,10 +191,12 @@ int ex4d_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, 
                       float min_depth, float max_depth, uint8_t *present, void *stream);
 
 /* Sizes the allocation callbacks will be asked for (rasterizer_impl.h required<T>(N) equivalent).
- * Footprints: geometry ~180 B per Gaussian; binning 48 B per (Gaussian, tile) instance + histograms -- 16 B of sort arrays and 32 B of
- * CAPACITY for the per-quadrant compacted lists the forward leaves for the backward (uint2[4 * num_rendered]: every entry of a tile list could
- * survive the cull of each of its four quadrants; ~6 % is touched).  1.0 M Gaussians, 1352x1014, 7.5 M instances: 370 MB; the deep-overlap
- * configuration (2048x1088, 31.5 M instances): 1.5 GB; with Ex4dParams.instance_capacity the capacity takes the place of num_rendered. */
+ * Footprints: geometry ~190 B per Gaussian; binning 24 B per (Gaussian, tile) instance + histograms (rounds 3-5: 48) -- point_list, the
+ * sorted tile ids, and 16 B of CAPACITY for the per-quadrant compacted lists the forward leaves for the backward (uint32[4 * num_rendered]:
+ * every entry of a tile list could survive the cull of each of its four quadrants; ~6 % is touched); the tile sort's two scratch arrays
+ * live inside that region (the sort is over before the first list entry is written).  1.0 M Gaussians, 1352x1014, 7.5 M instances:
+ * 190 MB; the deep-overlap configuration (2048x1088, 31.5 M instances): 0.78 GB; with Ex4dParams.instance_capacity the capacity takes
+ * the place of num_rendered. */
 size_t ex4d_geom_bytes(int32_t P);
 size_t ex4d_binning_bytes(int32_t num_rendered, int32_t W, int32_t H);
 size_t ex4d_img_bytes(int32_t W, int32_t H);
@@ -218,9 +220,9 @@ typedef struct Ex4dBinningLayout {
     size_t point_list;      /* uint32[R]           Gaussian ids sorted by (tile, depth, id): == reference point_list */
     size_t tile_ids;        /* uint32[R]           tile id of every sorted instance (high word of the reference key); with option
                                                    "binning_tile_ids" = 1 only, see ex4d_set_option */
-    size_t qlist;           /* uint2[4 R]          per (tile, 8x8 quadrant) the compacted list the forward compositing kernel leaves for the
-                                                   backward: (Gaussian id, position in the tile list) of the entries that survived its
-                                                   quadrant cull, in list order; quadrant q of a tile with range [r0, r1) owns
+    size_t qlist;           /* uint32[4 R]         per (tile, 8x8 quadrant) the compacted list the forward compositing kernel leaves for the
+                                                   backward: the positions in the tile list of the entries that survived its quadrant
+                                                   cull, ascending (the id is point_list[r0 + position]); quadrant q of a tile with range [r0, r1) owns
                                                    [4 r0 + q (r1 - r0), ...), qcount[4 tile + q] entries are valid */
     size_t qcount;          /* uint32[4 T] */
     size_t total;

@@ -440,8 +440,8 @@ def test_compiled_host_path_learning_rate_and_sh_degree_setters(hip_lib):
 
 def test_compacted_quadrant_lists_left_for_the_backward(hip_lib):
     """The forward compositing kernel leaves, per (tile, 8x8 quadrant), the compacted list the backward streams (include/ex4d_rasterizer.h:
-    Ex4dBinningLayout.qlist / .qcount): entries are (Gaussian id, position in the tile list) in ascending position, ids agree with the
-    sorted point_list, and every quadrant's list reaches its deepest contributor (max n_contrib over its pixels)."""
+    Ex4dBinningLayout.qlist / .qcount): entries are positions in the tile list, ascending (round 6: the position alone -- the Gaussian id is
+    point_list[range start + position]), and every quadrant's list reaches its deepest contributor (max n_contrib over its pixels)."""
     ins, st = h.scene_inputs("cfg2", P=20000, dir_scale=0.0)
     g = h.gpu_forward_raw(ins, st)
     H, W = st["image_height"], st["image_width"]
@@ -459,12 +459,12 @@ def test_compacted_quadrant_lists_left_for_the_backward(hip_lib):
             ent = ql[4 * r0 + q * n: 4 * r0 + q * n + qn]
             total += qn
             if qn:
-                k = ent[:, 1]
-                assert np.all(np.diff(k) > 0) and k.max() < n and np.array_equal(ent[:, 0], pl[r0 + k]), (t, q)
+                k = ent
+                assert np.all(np.diff(k) > 0) and k.min() >= 0 and k.max() < n and pl[r0 + k].min() >= 0, (t, q)
             sub = ncon[ty * 16 + (q >> 1) * 8: ty * 16 + (q >> 1) * 8 + 8, tx * 16 + (q & 1) * 8: tx * 16 + (q & 1) * 8 + 8]
             deepest = int(sub.max()) if sub.size else 0
             # the deepest contributor itself is a survivor of its quadrant's cull, so it is in the list
-            assert deepest == 0 or (qn > 0 and (ent[:, 1] == deepest - 1).any()), (t, q, deepest)
+            assert deepest == 0 or (qn > 0 and (ent == deepest - 1).any()), (t, q, deepest)
     assert 0 < total < 4 * g["num_rendered"]
 
 
