@@ -64,8 +64,8 @@ bool depth_sort_auto_msd(hipStream_t stream, bool async, uint32_t **watch)
     }
     uint32_t *w = g_depth_watch.get();
     if (!w) return false;
-    if (__atomic_load_n(w, __ATOMIC_RELAXED) != 0u) {
-        __atomic_store_n(w, 0u, __ATOMIC_RELAXED);
+    // (test and clear in ONE exchange: a separate store could erase the report of a bucket kernel of a frame still in flight -- ADVICE r05)
+    if (__atomic_load_n(w, __ATOMIC_RELAXED) != 0u && __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED) != 0u) {
         const int b = g_depth_watch.backoff.load();
         g_depth_watch.hold.store(b);
         g_depth_watch.backoff.store(b < (1 << 20) ? 2 * b : b);
@@ -421,8 +421,11 @@ static int forward_impl(
             // between its landing and the launches below is a microsecond the GPU may run dry)
             static const bool spin = []{ const char *e = getenv("EX4D_READBACK_SPIN"); return e ? atoi(e) != 0 : true; }();
             if (spin) {
-                hipError_t q;
-                while ((q = hipEventQuery(g_readback.ev)) == hipErrorNotReady) { }
+                // (bounded: ~100 us of polling cover the preprocess kernel + the copy; behind that -- an oversubscribed host, several ranks
+                // per core, a GPU that hangs -- the thread blocks instead of burning its core: ADVICE r05)
+                hipError_t q = hipErrorNotReady;
+                for (int i = 0; i < 20000 && (q = hipEventQuery(g_readback.ev)) == hipErrorNotReady; i++) { }
+                if (q == hipErrorNotReady) q = hipEventSynchronize(g_readback.ev);
                 HIP_TRY(q);
             } else HIP_TRY(hipEventSynchronize(g_readback.ev));
         }

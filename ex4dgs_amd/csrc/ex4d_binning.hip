@@ -248,6 +248,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __shared__ uint32_t scan_tmp[8];
     __shared__ uint2 stage[RS_THREADS * ITEMS];             // (key, value) in block-local sorted order
     __shared__ uint32_t stage_r[MODE == 3 ? RS_THREADS * ITEMS : 1];      // MODE 3: the third word of the triple
+    // (MODE 3 at 16 items per thread -- more than 2 M Gaussians -- is the largest: 16 K of counters + 8 K + 32 K + 16 K = 72 KB, more than
+    // the 64 KB of gfx90a-class LDS: this library is gfx950 only, 160 KB per CU)
+    static_assert(sizeof(uint32_t) * (4 * BINS + 2 * BINS + 8) + sizeof(uint2) * RS_THREADS * ITEMS + sizeof(uint32_t) * (MODE == 3 ? RS_THREADS * ITEMS : 1) <= 80 * 1024,
+                  "rs_scatter_kernel: static LDS beyond 80 KB (two workgroups per CU)");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (NBITS > 0) nbits = NBITS;
     const uint32_t mask = (1u << nbits) - 1u;

@@ -211,7 +211,8 @@ typedef struct Ex4dGeomLayout {
     size_t clamped;         /* uint8[P]            bit c set <=> channel c clamped at 0 (forward.cu:67-69) */
     size_t tiles_touched;   /* uint32[P]           with option "geom_debug_arrays" = 1 only */
     size_t depth_order;     /* uint32[P]           Gaussian ids, stable-sorted by depth key (visible first) */
-    size_t sorted_offsets;  /* uint32[P]           block-local inclusive scan of tiles_touched in depth order (option "depth_sort_msd" = 2: local to the depth bucket) */
+    size_t sorted_offsets;  /* uint32[P]           INTERNAL SCRATCH, not an interface: written only by the pair-sort path ("tile_sort_rows" = 0; its meaning
+                                                   depends on the depth sort that ran); the default row-segment tile sort of round 6 needs no instance offsets */
     size_t rects;           /* uint2[P]            tile rect (getRect, auxiliary.h:46-56): .x = x0 | y0 << 16, .y = w | h << 16;
                                                    w * h == tiles_touched; defined for visible Gaussians */
     size_t total;

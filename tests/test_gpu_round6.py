@@ -54,3 +54,17 @@ def test_clustered_scene_tile_sorts_agree(hip_lib):
     ins = {k: v.cuda() for k, v in ins.items()}
     ref = _frame(ins, st, tile_sort_rows=0, depth_sort_msd=0)
     _same(_frame(ins, st, tile_sort_rows=1, depth_sort_msd=2), ref, "rows, clustered scene")
+
+
+def test_msd_depth_sort_above_two_million_gaussians(hip_lib):
+    """beyond 2 M Gaussians the MSD depth sort's partition runs with 16 items per thread (72 KB of LDS), its histogram kernel
+    likewise, and the bucket kernel with 512 threads at real bucket sizes -- MSD = LSD = a stable host sort there too; the row-segment
+    tile sort behind both (forward only: the image and the lists)."""
+    from tests.test_gpu_round5 import _host_depth_order
+    ins, st = h.scene_inputs("cfg2", P=2_100_000)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    lsd = _frame(ins, st, depth_sort_msd=0)
+    msd = _frame(ins, st, depth_sort_msd=2)
+    assert torch.equal(lsd["depth_order"], _host_depth_order(lsd)), "LSD depth order differs from the host sort"
+    _same(msd, lsd, "msd vs lsd at 2.1 M")
+    _same(_frame(ins, st, depth_sort_msd=2, tile_sort_rows=0), lsd, "msd + pair sort vs lsd at 2.1 M")
