@@ -351,6 +351,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="N = 1: forward + backward (asynchronous forward, raw C-ABI mirror calls) captured into ONE hipGraph and replayed per step")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
     ap.add_argument("--sync-forward", action="store_true", help="training-core steps: the trainer's rasterizer forward with the blocking instance-count read-back (default: asynchronous where the trainer can re-run a frame itself)")
+    ap.add_argument("--views-per-rank", type=int, default=1, metavar="K",
+                    help="training-core steps: every rank renders K views per optimizer step, accumulates their gradients locally and exchanges ONCE "
+                         "(FrameTrainer(views_per_step=K): batch = N K views, wire time per view 1/K); a timed step stays one view")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="tuning / A-B runs: any library option of ex4d_set_option, e.g. --set depth_sort_msd=0 (the 3-pass LSD depth sort)")
     args = ap.parse_args()
 
@@ -488,9 +491,10 @@ def main():
         exchange = "none" if (world == 1 or args.no_allreduce) else ("sharded" if args.optimizer == "sharded" else "allreduce")
         if world == 1 and args.optimizer == "sharded":
             exchange = "sharded"
-        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if args.dense_keyframe_grads else None),
+        kv = max(1, args.views_per_rank)
+        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if (args.dense_keyframe_grads or kv > 1) else None),
                           lrs={n: 1e-7 for n in model.PARAM_NAMES},       # tiny learning rates: the synthetic scene stays put
-                          async_forward=(False if args.sync_forward else None))
+                          async_forward=(False if (args.sync_forward or kv > 1) else None), views_per_step=kv)
 
         def step(i):
             return tr.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)["render"]
@@ -498,7 +502,8 @@ def main():
         ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all, finish=tr.flush)
         parallelism = f"views/timestamps sharded i = r (mod {world}), parameters replicated" + (
             "" if tr.exchange is None else (" + reduce-scatter / sharded RAdam / all-gather" if exchange == "sharded" else " + async RCCL all-reduce of the 15 model-parameter gradients"))
-        step_what = ("training-iteration core of one view per rank: fused attribute evaluation -> rasterizer forward+backward -> attribute "
+        step_what = (("" if kv == 1 else f"[{kv} views per rank and optimizer step, gradients accumulated locally, one exchange per {kv} views] ") +
+                     "training-iteration core of one view per rank: fused attribute evaluation -> rasterizer forward+backward -> attribute "
                      "backward" + ("" if tr.exchange is None else " -> gradient exchange") + ("" if args.optimizer == "none" else f" -> {args.optimizer} RAdam step"))
         secondary = {}
         if args.optimizer != "none":

@@ -228,6 +228,43 @@ class ParamGradExchange:
             self._grads = None
 
 
+class ViewAccumulator:
+    """k views per rank and optimizer step (round 6): the gradients of a rank's views 1 .. k-1 are added up locally in
+    persistent accumulators, the k-th view's add is followed by ONE exchange of the sums -- the bytes a rank puts on the wire per VIEW
+    drop k-fold, and with them the exposed exchange per view (the exchange cannot hide behind the next frame while the optimizer steps
+    every iteration: DESIGN.md section 6).  The batch of an optimizer step becomes N k views; the sum over ranks and views is the sum the
+    k single-view exchanges would have delivered (addition order: views first, then ranks).
+
+    add(grads) -> True when this was the group's last view: the exchange is on its way (exchange.wait() blocks on it) and `sums` holds /
+    will hold the result; False: accumulated, nothing launched.  exchange: ParamGradExchange | None (one rank: plain accumulation)."""
+
+    def __init__(self, shapes, device, views_per_step, exchange=None):
+        assert views_per_step >= 1
+        self.k, self.exchange = int(views_per_step), exchange
+        self.sums = [torch.zeros(s, dtype=torch.float32, device=device) for s in shapes]
+        self.count = 0
+
+    def add(self, grads):
+        assert len(grads) == len(self.sums)
+        if self.count == 0:
+            if self.exchange is not None:
+                self.exchange.wait()                  # the previous group's collectives own the accumulators until here
+            for a, g in zip(self.sums, grads):
+                a.copy_(g.view_as(a))
+        else:
+            torch._foreach_add_(self.sums, [g.view_as(a) for a, g in zip(self.sums, grads)])
+        self.count += 1
+        if self.count < self.k:
+            return False
+        self.count = 0
+        if self.exchange is not None:
+            self.exchange.launch(self.sums)
+        return True
+
+    def bytes_on_wire_per_view(self):
+        return 0 if self.exchange is None else self.exchange.bytes_on_wire() / self.k
+
+
 class SliceGather:
     """Exchange of the keyframe-gradient SLICES of ex4d_attributes_backward_sliced: every rank contributes its [Nd, count, C] window
     (16 MB at 0.2 M dynamic Gaussians instead of a 196 MB dense all-reduce) plus its first keyframe index; after wait() every rank holds

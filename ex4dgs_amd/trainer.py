@@ -50,7 +50,7 @@ class FrameTrainer:
     all-gather; implies optimizer).  optimizer: False | True (replicated fused RAdam when exchange != "sharded")."""
 
     def __init__(self, model, exchange="none", optimizer=False, lrs=None, overlap=True, group=None, sliced=None, spatial_lr_scale=1.0,
-                 force_collectives=False, async_forward=None):
+                 force_collectives=False, async_forward=None, views_per_step=1):
         """lrs: overrides of the reference table reference_lrs(spatial_lr_scale).
         sliced (default: on whenever an optimizer runs, replicated or sharded): the keyframe gradients stay [Nd,4,3] / [Nd,2,4] slices from
         the attribute backward through the exchange into ex4d_radam_step_sliced -- no 196 MB zero fill, no dense read.  Replicated
@@ -61,8 +61,21 @@ class FrameTrainer:
         run and are checked on a one-GPU box).
         async_forward (default: ON for a single rank with exchange "none", off otherwise): the rasterizer forward runs asynchronously (no instance-count read-back:
         include/ex4d_rasterizer.h Ex4dParams.instance_capacity, under an AsyncFrames policy of the trainer's own); the frame's status is looked at once, right before its gradients are applied, and a frame that overflowed its
-        capacity is RE-RUN first -- the parameters are those of the synchronous path.  `replays` counts such re-runs."""
+        capacity is RE-RUN first -- the parameters are those of the synchronous path.  `replays` counts such re-runs.
+        views_per_step = k > 1 (round 6): a rank renders k views per optimizer step; their gradients are added up locally (persistent
+        accumulators), exchanged ONCE after the k-th view and applied once -- the batch of a step is N k views, the wire time per view
+        1/k of the single-view step's (DESIGN.md section 6 has the projected efficiencies).  Keyframe gradients are dense in this mode (k
+        views touch k windows; the sliced optimizer takes one window per rank), the forward is synchronous."""
         assert exchange in ("none", "allreduce", "sharded")
+        self.k = int(views_per_step)
+        assert self.k >= 1
+        if self.k > 1:
+            if sliced:
+                raise ValueError("views_per_step > 1 accumulates dense keyframe gradients (one gradient window per view and rank): sliced=True does not apply")
+            if async_forward:
+                raise ValueError("views_per_step > 1 runs the synchronous forward (a re-run frame would be accumulated twice)")
+            sliced, async_forward = False, False
+        self._acc, self._nacc = None, 0
         self.model = model
         self.names = list(attr.PARAM_ORDER)
         self.params = [getattr(model, n) for n in self.names]
@@ -241,7 +254,7 @@ class FrameTrainer:
         else:
             ctx = torch.cuda.stream(main)
         with ctx:
-            if self.exchange_feat is not None:
+            if self.exchange_feat is not None and self.k == 1:
                 self.exchange_feat.wait()
                 self.exchange_feat.launch(fgrads)            # on the wire before the attribute backward runs
             if self.exchange is not None:
@@ -258,6 +271,26 @@ class FrameTrainer:
                 if self.mode == "sharded":                   # row all-to-all of the windows (inside the sharded optimizer)
                     windows = {i: (gout[i], first) for i, first in zip(self.kf_idx, (hint[0], hint[2]))}
             grads = [fgrads[self.feature_idx.index(i)] if i in self.feature_idx else gout[i] for i in range(len(self.params))]
+            if self.k > 1:
+                # views 1 .. k-1 of the group: added to the accumulators, nothing goes on the wire, no optimizer step follows
+                if self._acc is None:
+                    self._acc = [torch.zeros_like(p) for p in self.params]
+                if self._nacc == 0:
+                    if self.exchange_feat is not None:
+                        self.exchange_feat.wait()            # (the previous group's collectives own the accumulators until here)
+                    for a, g_ in zip(self._acc, grads):
+                        a.copy_(g_)
+                else:
+                    torch._foreach_add_(self._acc, list(grads))
+                self._nacc += 1
+                if self._nacc < self.k:
+                    self._grads = None
+                    self.last = {"radii": radii}
+                    return out
+                self._nacc = 0
+                grads = self._acc
+                if self.exchange_feat is not None:
+                    self.exchange_feat.launch([grads[i] for i in self.feat_pos])
             self._grads = grads
             if self.exchange is not None:
                 if self.exchange_feat is not None:

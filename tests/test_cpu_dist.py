@@ -209,3 +209,65 @@ def test_shard_ranges_partition_every_tensor():
                 assert lo == covered and hi >= lo and s % 4 == 0
                 covered = hi
             assert covered == n
+
+
+_WORKER_VIEWS = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from ex4dgs_amd import dist as xd
+
+rank, world, local = xd.init_from_env(backend="gloo")
+assert world == 2
+shapes = [(1003, 3), (259, 35, 3), (1003, 16, 3), (7,), (4099,)]
+K = 3
+
+def grads_of(r, view):
+    # exactly representable values (multiples of 1/8 below 2^10): every addition order gives the same float
+    g = torch.Generator().manual_seed(100 * view + r)
+    return [torch.randint(-4096, 4096, s, generator=g).float() / 8 for s in shapes]
+
+# k views accumulated locally + ONE exchange ...
+ex = xd.ParamGradExchange(shapes, "cpu", mode="allreduce", small_bytes=256)
+acc = xd.ViewAccumulator(shapes, "cpu", K, exchange=ex)
+for v in range(K):
+    last = acc.add(grads_of(rank, v))
+    assert last == (v == K - 1)
+ex.wait()
+# ... equals the sum of the k single-view exchanges
+ex1 = xd.ParamGradExchange(shapes, "cpu", mode="allreduce", small_bytes=256)
+ref = [torch.zeros(s) for s in shapes]
+for v in range(K):
+    g = grads_of(rank, v)
+    ex1.launch(g); ex1.wait()
+    for a, b in zip(ref, g):
+        a += b
+for i, (a, b) in enumerate(zip(acc.sums, ref)):
+    assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    want = sum((grads_of(r, v)[i] for r in range(2) for v in range(K)), torch.zeros(shapes[i]))
+    assert torch.equal(a, want), i
+assert acc.bytes_on_wire_per_view() * K == ex.bytes_on_wire()
+# a second group reuses the accumulators (the first view of a group overwrites them)
+for v in range(K):
+    acc.add(grads_of(rank, 10 + v))
+ex.wait()
+want = sum((grads_of(r, 10 + v)[2] for r in range(2) for v in range(K)), torch.zeros(shapes[2]))
+assert torch.equal(acc.sums[2], want)
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_views_per_step_accumulation_equals_single_view_exchanges_gloo_world2(tmp_path):
+    """k views accumulated per rank + one exchange == the sum of k single-view exchanges (dist.ViewAccumulator, what
+    FrameTrainer(views_per_step=k) does with its persistent accumulators)."""
+    script = tmp_path / "worker_views.py"
+    script.write_text(_WORKER_VIEWS)
+    port = 33500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), h.ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o

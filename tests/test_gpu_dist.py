@@ -45,6 +45,42 @@ def test_frame_trainer_matches_the_autograd_path(hip_lib):
             p.requires_grad_(False); p.grad = None
 
 
+def test_views_per_step_accumulates_and_steps_once(hip_lib):
+    """FrameTrainer(views_per_step=k): the gradients of k views are added up in persistent accumulators and handed over (to the exchange /
+    the optimizer) once, after the k-th view -- equal to the sum of the k single-view gradients; with an optimizer the parameters move once
+    per k views."""
+    from ex4dgs_amd.scene import make_scene
+    from ex4dgs_amd.trainer import FrameTrainer
+    model, cam, bg = make_scene("cfg3", P=20000, device="cuda", fused=True)
+    H, W = cam.image_height, cam.image_width
+    up = _fixed_upstream(H, W)
+    stamps = (0, 137, 299)
+    solo = FrameTrainer(model, exchange="none")
+    acc = None
+    for t in stamps:
+        solo.step(cam, bg, t, up); solo.flush()
+        g = {k: v.clone() for k, v in solo.grads().items()}
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    tr = FrameTrainer(model, exchange="none", views_per_step=3)
+    for i, t in enumerate(stamps):
+        tr.step(cam, bg, t, up); tr.flush()
+        assert (tr.grads() is None) == (i < 2), "gradients are handed over after the k-th view only"
+    for name, a in tr.grads().items():
+        b = acc[name]
+        tol = 2e-5 * float(b.abs().max()) + 1e-12          # float atomics in the rasterizer backward: equal to rounding
+        assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
+    # with the optimizer: one RAdam step per k views
+    model2, _, _ = make_scene("cfg3", P=20000, device="cuda", fused=True)
+    tro = FrameTrainer(model2, exchange="none", optimizer=True, views_per_step=2)
+    before = model2._xyz.clone()
+    tro.step(cam, bg, 0, up); tro.flush()
+    assert torch.equal(model2._xyz, before), "no optimizer step after the first of two views"
+    tro.step(cam, bg, 137, up); tro.flush()
+    assert not torch.equal(model2._xyz, before) and tro.steps == 1
+    with pytest.raises(ValueError):
+        FrameTrainer(model2, exchange="none", optimizer=True, views_per_step=2, sliced=True)
+
+
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
