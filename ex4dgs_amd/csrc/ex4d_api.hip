@@ -351,6 +351,7 @@ static int forward_impl(
     uint32_t *keys1 = start_in_b ? g.sort_keys_a : g.sort_keys_b, *vals1 = start_in_b ? g.depth_order : g.sort_vals_b;
     if (msd_depth) { keys0 = g.sort_keys_a; vals0 = g.sort_vals_a; }      // partition: (keys_a, vals_a, rects4) -> (keys_b, depth_order, rects4_b)
 
+    HIP_TRY(ex4d_prepare_rank_lds(stream));          // (first forward on a device: the probe of the LDS-atomic ranking, once)
     g_prof.begin(0, stream);
     HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));        // the frame flags / Ex4dFrameStatus words
     // 1. per-Gaussian preprocess
@@ -628,6 +629,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "composite_clamp_always") && (value == 0 || value == 1)) { ex4d_set_clamp_always(value); return EX4D_OK; }
     if (name && !strcmp(name, "tile_sort_rows") && (value == 0 || value == 1)) { g_tile_rows.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "rank_lds_atomics") && value >= -1 && value <= 1) { ex4d_set_rank_lds(value); return EX4D_OK; }
     if (name && !strcmp(name, "rows_probe")) { ex4d_set_rows_probe(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_probe") && value >= 0 && value < (1 << 16)) { ex4d_set_preprocess_probe(value); return EX4D_OK; }
@@ -650,6 +652,8 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "composite_clamp_always")) return ex4d_get_clamp_always();
     if (name && !strcmp(name, "tile_sort_rows")) return g_tile_rows.load();
+    if (name && !strcmp(name, "rank_lds_atomics")) return ex4d_get_rank_lds();
+    if (name && !strcmp(name, "rank_lds_atomics_in_use")) return ex4d_rank_lds_in_use();      // (read-only) what the probe decided for the current device
     if (name && !strcmp(name, "preprocess_sh_predicate")) return ex4d_get_preprocess_tune();
     if (name && !strcmp(name, "geom_debug_arrays")) return g_geom_debug.load();
     if (name && !strcmp(name, "preprocess_fast_path")) return ex4d_get_preprocess_fast();

@@ -15,8 +15,39 @@
 // over R with 32-bit keys: ~5x less HBM traffic than the 6-pass 64-bit sort, bit-identical point_list.
 // All of it is integer work and HBM/latency bound; wave64 ballots give the stable in-wave ranks.
 #include "ex4d_internal.h"
+#include <atomic>
+#include <mutex>
+
+// Round 6: stable ranking by LDS atomics.  The lanes of ONE ds_add_rtn_u32 instruction that hit the same LDS word receive their pre-op
+// values in ascending lane order on this part (tools/dev/micro/lds_atomic_order.hip: 4.2e9 lane-trials over every collision pattern, none
+// out of order), and a wave's LDS instructions execute in program order: `atomicAdd(&counter[digit], 1)` IS the stable rank of an item
+// among the wave's items of its digit -- one LDS instruction per item instead of 5 VALU per digit bit of ballot ranking (35 to 50 per
+// item in the scatter passes, which were bound by exactly that).  Not an architectural promise, so the library does not assume it: the
+// first forward on a device runs the probe kernel below (a few microseconds, once) and the scatter kernels take the ballot path -- kept,
+// and selectable with option "rank_lds_atomics" = 0 -- wherever the probe finds a lane out of order.
+__device__ int ex4d_g_rank_lds = 0;
 
 namespace {
+
+__global__ __launch_bounds__(256) void lds_rank_probe_kernel(uint32_t seed, int trials, int ndigits, uint32_t *__restrict__ bad)
+{
+    __shared__ uint32_t cnt[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = seed ^ (blockIdx.x * 0x9E3779B9u) ^ (threadIdx.x * 0x85EBCA6Bu);
+    uint32_t nb = 0;
+    for (int t = 0; t < trials; t++) {
+        for (int i = lane; i < 256; i += 64) cnt[wave][i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        x = x * 1664525u + 1013904223u;
+        const uint32_t d = (x >> 16) % (uint32_t)ndigits;
+        uint32_t expect = 0, same = 0;
+        for (int l = 0; l < 64; l++) { const uint32_t dl = __shfl(d, l, 64); if (dl == d) { same++; if (l < lane) expect++; } }
+        const uint32_t got = atomicAdd(&cnt[wave][d], 1u);
+        const uint32_t got2 = atomicAdd(&cnt[wave][d], 1u);          // a second instruction continues behind the first one's counts
+        if (got != expect || got2 != same + expect) nb++;
+    }
+    if (nb) atomicAdd(bad, nb);
+}
 
 __device__ __forceinline__ int to_int_sat(float f)
 {
@@ -265,6 +296,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    const bool lds_rank = ex4d_g_rank_lds != 0;          // (uniform)
     constexpr uint32_t CHUNK = RS_THREADS * ITEMS;
     uint32_t block_first = blockIdx.x * CHUNK, block_end = n, bucket = 0;
     TsBlock tb = { 0u, 0u, 0u, 0u, 0u, 0u };
@@ -295,6 +327,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         const uint32_t i = base + it * 64 + lane;
         const bool valid = i < block_end;
         const uint32_t d = digit_of(key[it]);
+        if (lds_rank) {
+            // stable rank by the LDS atomic's return value (round 6; see ex4d_g_rank_lds above): index among this wave's items of digit d
+            pos[it] = valid ? atomicAdd(&wave_cnt[wave][d], 1u) : 0u;
+            continue;
+        }
         // lanes holding the same digit: per bit keep the ballot if my bit is set, its complement otherwise -- written as
         // ballot ^ (bit - 1) on 32-bit halves (plain xor/and; a select here compiles to the VOP2 v_cndmask that issues in ~24
         // cycles on gfx950 and made this loop the most expensive part of the pass)
@@ -509,6 +546,7 @@ __device__ __forceinline__ uint64_t dls_peers(uint32_t d, int nbits, bool valid)
 template <int NBITS>
 __device__ __forceinline__ uint32_t dls_rank(uint32_t *cnt, uint32_t d, int nbits, bool valid, int lane)
 {
+    if (ex4d_g_rank_lds != 0) return valid ? atomicAdd(&cnt[d], 1u) : 0u;      // (uniform; round 6: see ex4d_g_rank_lds)
     const uint64_t peers = dls_peers<NBITS>(d, nbits, valid);
     const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
     const uint32_t before = cnt[valid ? d : 0u];                            // (all peers read one word; see rs_scatter_kernel)
@@ -963,6 +1001,42 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint
 }
 
 }  // namespace
+
+// ---- "rank_lds_atomics": -1 = probe once per device (default), 0 = ballot ranking, 1 = ranking by LDS atomics without asking
+static std::atomic<int> g_rank_lds_option{-1};
+static std::mutex g_rank_lds_mu;
+static int g_rank_lds_device = -1, g_rank_lds_value = 0;
+void ex4d_set_rank_lds(int v) { std::lock_guard<std::mutex> lock(g_rank_lds_mu); g_rank_lds_option.store(v); g_rank_lds_device = -1; }
+int ex4d_get_rank_lds() { return g_rank_lds_option.load(); }
+int ex4d_rank_lds_in_use() { return g_rank_lds_value; }
+// makes the device flag of the current device match the option; capturing streams keep whatever the device already has
+hipError_t ex4d_prepare_rank_lds(hipStream_t stream)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_rank_lds_mu);
+    if (dev == g_rank_lds_device) return hipSuccess;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return hipSuccess;
+    (void)hipGetLastError();
+    int want = g_rank_lds_option.load();
+    if (want < 0) {
+        uint32_t *bad = nullptr, h = 1;
+        hipError_t e = hipMalloc((void **)&bad, sizeof(uint32_t));
+        if (e != hipSuccess) return e;
+        (void)hipMemset(bad, 0, sizeof(uint32_t));
+        for (int nd : { 1, 3, 17, 64, 256 })
+            hipLaunchKernelGGL(lds_rank_probe_kernel, dim3(256), dim3(256), 0, 0, 0x5EEDu + nd, 200, nd, bad);
+        e = hipMemcpy(&h, bad, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        (void)hipFree(bad);
+        if (e != hipSuccess) return e;
+        want = h == 0u ? 1 : 0;
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(ex4d_g_rank_lds), &want, sizeof(int));
+    if (e != hipSuccess) return e;
+    g_rank_lds_device = dev; g_rank_lds_value = want;
+    return hipSuccess;
+}
 
 // small inputs (the per-Gaussian depth sort) use 1024-item chunks so that every CU gets several workgroups, and 9-bit digits
 // (512 bins): its passes are launch / latency bound, so one pass less is worth more than the two extra ballots per item;

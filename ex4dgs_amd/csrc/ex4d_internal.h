@@ -132,6 +132,11 @@ hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_
     uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
     uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads,       // local_incl / bucket_sums: the tile scan fused into the bucket kernel (nullptr = not)
     uint32_t *watch = nullptr);                                                                  // watch: pinned host word set to 1 when a bucket exceeded the LDS capacity
+// stable ranking by LDS atomics in the scatter kernels (ex4d_binning.hip): probed once per device, option "rank_lds_atomics"
+void ex4d_set_rank_lds(int v);
+int ex4d_get_rank_lds();
+int ex4d_rank_lds_in_use();
+hipError_t ex4d_prepare_rank_lds(hipStream_t stream);
 hipError_t ex4d_launch_zero(void *ptr, size_t bytes, hipStream_t stream);      // ptr 16-byte aligned, bytes a multiple of 4 (a kernel, not hipMemsetAsync: ex4d_binning.hip)
 hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, uint2 *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
 

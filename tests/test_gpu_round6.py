@@ -68,3 +68,23 @@ def test_msd_depth_sort_above_two_million_gaussians(hip_lib):
     assert torch.equal(lsd["depth_order"], _host_depth_order(lsd)), "LSD depth order differs from the host sort"
     _same(msd, lsd, "msd vs lsd at 2.1 M")
     _same(_frame(ins, st, depth_sort_msd=2, tile_sort_rows=0), lsd, "msd + pair sort vs lsd at 2.1 M")
+
+
+def test_ranking_by_lds_atomics_is_probed_and_equals_ballot_ranking(hip_lib):
+    """The scatter kernels rank by the return value of an LDS atomic where the device hands the lanes of one ds_add_rtn their pre-op values
+    in lane order (probed by the library on its first forward: option "rank_lds_atomics" = -1, the default) -- on gfx950 it does; the
+    ballot ranking (option 0) gives the same lists bit for bit."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("rank_lds_atomics") == -1, "probing is the library default"
+    ins, st = h.scene_inputs("cfg3", P=30000, t=137)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    auto = _frame(ins, st)
+    assert _C.get_option("rank_lds_atomics_in_use") == 1, "the probe found the LDS atomics of this device out of lane order"
+    try:
+        ballots = _frame(ins, st, rank_lds_atomics=0)
+        assert _C.get_option("rank_lds_atomics_in_use") == 0
+        for mode in (0, 2):
+            _same(_frame(ins, st, rank_lds_atomics=1, depth_sort_msd=mode, tile_sort_rows=0), ballots, f"forced LDS ranking, pair sort, depth sort {mode}")
+    finally:
+        _C.set_option("rank_lds_atomics", -1)
+    _same(auto, ballots, "probed LDS ranking vs ballot ranking")
