@@ -96,43 +96,47 @@ __device__ __forceinline__ void wave_diff_to_counts(uint32_t *cnt, int lane)
 
 // ---------------------------------------------------------------- pass A': histogram
 // hist: rows 0 .. NR-1 = segments per (tile row, block), rows NR .. 2 NR - 1 = instances per (tile row, block); [2 NR][nblocks] + totals
+// (every wave counts one block of ROWA_GAUSS Gaussians on its own -- wave-private difference arrays, no workgroup barrier: the kernel is
+// a few LDS atomics per Gaussian behind one memory round trip, what it costs is workgroups in flight and launches)
 __global__ __launch_bounds__(ROW_THREADS) void rows_seg_hist_kernel(uint32_t P, int NR, const uint32_t *__restrict__ r4, const uint2 *__restrict__ r8,
     uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ frame_total)
 {
-    __shared__ uint32_t d_seg[ROW_PAD], d_inst[ROW_PAD];
-    __shared__ uint32_t tmp[8];
+    __shared__ __attribute__((aligned(16))) uint32_t d_seg[4][ROW_PAD], d_inst[4][ROW_PAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < ROW_PAD; i += ROW_THREADS) { d_seg[i] = 0u; d_inst[i] = 0u; }
-    __syncthreads();
+    const uint32_t blk = blockIdx.x * 4 + wave;
+    if (blk >= nblocks) return;              // (a whole wave)
+    uint32_t *ds = d_seg[wave], *di = d_inst[wave];
+    RectU r[ROWA_GAUSS / 64];
+#pragma unroll
+    for (int it = 0; it < ROWA_GAUSS / 64; it++) {
+        const uint32_t k = blk * ROWA_GAUSS + it * 64 + lane;
+        r[it] = { 0u, 0u, 0u, 0u };
+        if (k < P) r[it] = rect_at(r4, r8, k);
+    }
+    for (int i = lane; i < ROW_PAD; i += 64) { ds[i] = 0u; di[i] = 0u; }
+    wsync();
     uint32_t inst = 0;
 #pragma unroll
-    for (int it = 0; it < ROWA_GAUSS / ROW_THREADS; it++) {
-        const uint32_t k = blockIdx.x * ROWA_GAUSS + it * ROW_THREADS + tid;
-        if (k < P) {
-            const RectU r = rect_at(r4, r8, k);
-            if (r.w * r.h != 0u) {
-                atomicAdd(&d_seg[r.y0], 1u); atomicAdd(&d_seg[r.y0 + r.h], 0xFFFFFFFFu);
-                atomicAdd(&d_inst[r.y0], r.w); atomicAdd(&d_inst[r.y0 + r.h], 0u - r.w);
-                inst += r.w * r.h;
-            }
+    for (int it = 0; it < ROWA_GAUSS / 64; it++) {
+        if (r[it].w * r[it].h != 0u) {
+            atomicAdd(&ds[r[it].y0], 1u); atomicAdd(&ds[r[it].y0 + r[it].h], 0xFFFFFFFFu);
+            atomicAdd(&di[r[it].y0], r[it].w); atomicAdd(&di[r[it].y0 + r[it].h], 0u - r[it].w);
+            inst += r[it].w * r[it].h;
         }
     }
-    __syncthreads();
-    const uint32_t a = d_seg[tid], b = d_inst[tid];
-    const uint32_t xa = wave_incl_scan(a, lane), xb = wave_incl_scan(b, lane);
-    if (lane == 63) { tmp[wave] = xa; tmp[4 + wave] = xb; }
-    __syncthreads();
-    uint32_t sa = xa, sb = xb;
-    for (int w = 0; w < wave; w++) { sa += tmp[w]; sb += tmp[4 + w]; }
-    if (tid < NR) { hist[(size_t)tid * nblocks + blockIdx.x] = sa; hist[(size_t)(NR + tid) * nblocks + blockIdx.x] = sb; }
+    wsync();
+    wave_diff_to_counts<256>(ds, lane);
+    wave_diff_to_counts<256>(di, lane);
+    wsync();
+    for (int row = lane; row < NR; row += 64) {
+        hist[(size_t)row * nblocks + blk] = ds[row];
+        hist[(size_t)(NR + row) * nblocks + blk] = di[row];
+    }
     if (frame_total) {
-        // device-side instance count of the asynchronous forward (one fire-and-forget atomic per workgroup)
+        // device-side instance count of the asynchronous forward (one fire-and-forget atomic per block)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) inst += __shfl_xor(inst, o, 64);
-        __syncthreads();
-        if (lane == 0) tmp[wave] = inst;
-        __syncthreads();
-        if (tid == 0) atomicAdd(frame_total, tmp[0] + tmp[1] + tmp[2] + tmp[3]);
+        if (lane == 0 && inst != 0u) atomicAdd(frame_total, inst);
     }
 }
 
@@ -411,7 +415,7 @@ hipError_t ex4d_tile_sort_rows(int P, int gx, int gy, const uint32_t *order, con
     const uint32_t nbA = ((uint32_t)P + ROWA_GAUSS - 1) / ROWA_GAUSS;
     uint32_t *totA = histA + (size_t)2 * gy * nbA;
     const int bx = bits_for(gx);
-    hipLaunchKernelGGL(rows_seg_hist_kernel, dim3(nbA), dim3(ROW_THREADS), 0, stream, (uint32_t)P, gy, r4, r8, histA, nbA, frame_total);
+    hipLaunchKernelGGL(rows_seg_hist_kernel, dim3((nbA + 3) / 4), dim3(ROW_THREADS), 0, stream, (uint32_t)P, gy, r4, r8, histA, nbA, frame_total);
     hipLaunchKernelGGL(rows_scan_kernel, dim3(2 * gy), dim3(256), 0, stream, nbA, histA, (uint32_t)(2 * gy));
     // rects more than 3.5 rows high on average (config 5: 6): the larger segment stage
     const bool big = S == 0 ? (uint64_t)cap > 20ull * (uint32_t)P : 2ull * S > 7ull * (uint32_t)P;
