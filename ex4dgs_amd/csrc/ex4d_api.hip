@@ -632,7 +632,6 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "rank_lds_atomics") && value >= -1 && value <= 1) { ex4d_set_rank_lds(value); return EX4D_OK; }
     if (name && !strcmp(name, "rows_probe")) { ex4d_set_rows_probe(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_sh_predicate") && (value == 0 || value == 1)) { ex4d_set_preprocess_tune(value); return EX4D_OK; }
-    if (name && !strcmp(name, "preprocess_probe") && value >= 0 && value < (1 << 16)) { ex4d_set_preprocess_probe(value); return EX4D_OK; }
     if (name && !strcmp(name, "geom_debug_arrays") && (value == 0 || value == 1)) { g_geom_debug.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "preprocess_fast_path") && (value == 0 || value == 1)) { ex4d_set_preprocess_fast(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 3) { g_depth_msd.store(value); g_depth_watch.reset(); return EX4D_OK; }

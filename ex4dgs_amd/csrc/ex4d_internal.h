@@ -142,7 +142,6 @@ hipError_t ex4d_launch_tile_ranges(uint32_t R, int T, const uint32_t *tile_ids, 
 
 void ex4d_set_preprocess_tune(int v);   // ex4d_preprocess.hip: 1 (default) = SH rows of frustum-culled Gaussians are not requested
 int ex4d_get_preprocess_tune();
-void ex4d_set_preprocess_probe(int v);   // developer timing probes of preprocess_fwd (bit 0: no record stores, 1: no direction sums, 2: no per-Gaussian words)
 void ex4d_set_preprocess_fast(int v);   // 1 (default) = frames with one [P,16,3] SH tensor at degree 3 and scale + rotation take the specialised kernel
 int ex4d_get_preprocess_fast();
 void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled entry walk (default) or the compiler's loop

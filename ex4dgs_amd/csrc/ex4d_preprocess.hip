@@ -429,12 +429,6 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t *__restrict__ total_instances, const ShSplit sp_, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4,
     uint32_t *__restrict__ key_range_slots)
 {
-    const int probe = (sh_predicate >> 4) & 7;       // developer timing probes ("preprocess_probe": stores left out, stale buffers downstream)
-    const int stagger = sh_predicate >> 8;
-    sh_predicate &= 1;
-    // experiment: the workgroups of the first wave of workgroups start staggered (0 .. 3 x `stagger` sleeps of ~3.4 us) so that the
-    // load / arithmetic / store phases of the waves sharing a CU do not coincide
-    if (stagger && blockIdx.x < 1024u) { const int n = (int)((blockIdx.x >> 8) & 3u) * stagger; for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127); }
     const int D = FAST ? 3 : D_, M = FAST ? 16 : M_;
     const float *__restrict__ cov3D_precomp = FAST ? nullptr : cov3D_precomp_;
     const float *__restrict__ colors_precomp = FAST ? nullptr : colors_precomp_;
@@ -698,7 +692,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 res[ch] = fmaxf(result, 0.0f);
             }
             clamped[idx] = clamp_bits;
-            if (sh_dsums && !(probe & 2)) {
+            if (sh_dsums) {
                 // d(colour)/d(direction) sums of the SH backward (CR/backward.cu:57-131): they depend on the SH values and the direction
                 // only, both in registers here -- stored (36 B per visible Gaussian, Ex4dParams.prepare_backward) so that the backward
                 // does not read the 192-byte SH rows again.  Same function, same operands as the backward's own evaluation: same bits.
@@ -721,13 +715,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         else if (!(conic.x > 0.f && conic.z > 0.f && conic.x * conic.z - conic.y * conic.y > 0.f)) tau = __builtin_inff();
         else tau = logf(255.0f * w_op) + 0.01f;
         float4 *rec = records + 4 * (size_t)idx;
-        if (!(probe & 1))
-        {
         rec[0] = make_float4(pix_x, pix_y, conic.x, conic.y);
         rec[1] = make_float4(conic.z, tau, -conic.y / conic.z, -conic.y / conic.x);
         rec[2] = make_float4(depth, res[0], res[1], res[2]);
         rec[3] = make_float4(in_d0, in_d1, in_d2, w_op);
-        }
     }
     // frame flag for the compositing forward: does any visible Gaussian carry a flow vector?  (plain store of the same value by every
     // wave that sees one: no atomic, no contention; the training loop's dir3D is the all-zero gradient trap and never sets it)
@@ -735,7 +726,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         if (lane == 0) prefilter_violation[1] = 1u;
     }
     if (sh_dsums && idx == 0) prefilter_violation[2] = EX4D_DSUMS_MARK;      // frame flag [3]: this frame's direction sums exist (checked by the backward)
-    if (in_range && !(probe & 4)) {
+    if (in_range) {
         radii[idx] = out_radius;
         if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
         rects[idx] = rect;
@@ -1115,8 +1106,6 @@ static std::atomic<int> g_preprocess_fast{1};      // "preprocess_fast_path": th
 void ex4d_set_preprocess_fast(int v) { g_preprocess_fast.store(v); }
 int ex4d_get_preprocess_fast() { return g_preprocess_fast.load(); }
 static std::atomic<int> g_preprocess_tune{preprocess_option_default()};
-static std::atomic<int> g_preprocess_probe{0};
-void ex4d_set_preprocess_probe(int v) { g_preprocess_probe.store(v); }
 void ex4d_set_preprocess_tune(int v) { g_preprocess_tune.store(v != 0); }
 int ex4d_get_preprocess_tune() { return g_preprocess_tune.load(); }
 
@@ -1137,10 +1126,8 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation, \
         radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split, \
         (prm.prepare_backward && (shs != nullptr || is_split)) ? g.sh_dsums : (float *)nullptr, \
-        g_preprocess_tune.load(std::memory_order_relaxed) | ((g_preprocess_probe.load(std::memory_order_relaxed) & 7) << 4) | ((g_preprocess_probe.load(std::memory_order_relaxed) >> 10) << 8), rects4, key_range_slots
-    // (developer probe: bits 3.. of "preprocess_probe" = KB of unused dynamic LDS per workgroup, to lower the occupancy)
-    const unsigned dyn_lds = (unsigned)((g_preprocess_probe.load(std::memory_order_relaxed) >> 3) & 127) * 1024u;
-    if (fast) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), dyn_lds, stream, PF_ARGS);
+        g_preprocess_tune.load(std::memory_order_relaxed), rects4, key_range_slots
+    if (fast) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
 #undef PF_ARGS
     return hipGetLastError();
