@@ -178,7 +178,7 @@ EXPORTS = ("ex4d_last_error", "ex4d_abi_version", "ex4d_target_arch", "ex4d_forw
            "ex4d_forward_split_sh", "ex4d_backward_split_sh",
            "ex4d_backward_scratch_bytes", "ex4d_mark_visible", "ex4d_geom_bytes", "ex4d_binning_bytes", "ex4d_img_bytes",
            "ex4d_geom_layout", "ex4d_binning_layout", "ex4d_img_layout",
-           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option", "ex4d_debug_bwd_stats", "ex4d_debug_bwd_stats16")
+           "ex4d_profile_enable", "ex4d_profile_read", "ex4d_set_option", "ex4d_get_option", "ex4d_debug_bwd_stats", "ex4d_debug_bwd_stats16", "ex4d_debug_rows_prof")
 
 
 def library_path():
