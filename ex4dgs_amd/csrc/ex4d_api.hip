@@ -272,7 +272,7 @@ ImgState carve_img(void *buf, int W, int H, Ex4dImgLayout *lay, size_t *total)
 extern "C" {
 
 const char *ex4d_last_error(void) { return g_err; }
-int ex4d_abi_version(void) { return 4; }
+int ex4d_abi_version(void) { return 5; }      // 5 (round 6): binning buffer 24 B per instance, 4-byte compacted-list entries, per-chunk (instance, segment) counts
 const char *ex4d_target_arch(void) { return "gfx950"; }
 
 size_t ex4d_geom_bytes(int32_t P) { size_t t; carve_geom(nullptr, P, nullptr, &t); return t; }

@@ -262,8 +262,9 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *                            Bit-identical results.
  *   "depth_sort_msd"         0 = the Gaussians are ordered by depth with a 3-pass LSD radix sort, the tile scan gathers their rects;
  *                            2 = MSD-first depth sort: one partition on the top digit of the key range the frame occupies, every bucket finished
- *                            in LDS, the tile scan fused into that kernel (5 launches instead of 10; ~13 us per frame faster at 1.0 M Gaussians
- *                            spread in depth); 1 = the same with the tile scan as a kernel of its own.  Identical results.  A bucket of more
+ *                            in LDS (4 launches instead of 10; ~13 us per frame faster at 1.0 M Gaussians spread in depth; behind the pair sort
+ *                            -- "tile_sort_rows" = 0 -- the tile scan is fused into the bucket kernel); 1 = the same with the tile scan as a
+ *                            kernel of its own.  Identical results.  A bucket of more
  *                            than 4096 (8192 beyond 1.2 M Gaussians) is sorted by one workgroup through global memory -- a fronto-parallel
  *                            wall holding a third of the Gaussians costs 1.4 ms there ("Round 5").  Hence
  *                            3 (default) = auto: the MSD sort, until its bucket kernel reports an oversize bucket (a word in pinned host
@@ -272,6 +273,19 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *                            the option resets the hold; "depth_sort_hold" / "depth_sort_trips" (read-only) show frames left on the LSD
  *                            sort / reports seen.  The MSD sort needs 0 <= min_depth < max_depth with at most 28 significant key bits and
  *                            an image of at most 255 x 255 tiles; other frames take the LSD sort whatever the option says.
+ *   "tile_sort_rows"         1 (default, round 6) = the tile lists come from the row-segment sort (ex4d_rowsort.hip): a stable partition of the
+ *                            rects' row segments by tile row whose write-out expands them into instance words, then a counting sort by
+ *                            tile column per row -- no duplication kernel, no instance offsets, no (tile, id) pairs; 0 = duplication + the
+ *                            MSD-first pair sort of rounds 2-5.  Identical point_list / ranges.  Needs an image of at most 255 x 255 tiles
+ *                            and P <= 2^24; other frames take the pair sort whatever the option says.
+ *   "rank_lds_atomics"       -1 (default) = the scatter kernels rank their items by the return value of an LDS atomic IF a probe kernel,
+ *                            run once per device by the first forward, finds that the lanes of one ds_add_rtn instruction receive their
+ *                            pre-op values in ascending lane order (gfx950: yes; not an architectural promise), else by wave ballots;
+ *                            0 = always ballots; 1 = LDS atomics without asking.  Identical results where the probe holds.
+ *                            "rank_lds_atomics_in_use" (read-only): what the last forward's device uses.
+ *   "composite_clamp_always" 0 (default) = the flow-free compositing forward evaluates alpha = min(0.99, w G) only in chunks that staged an
+ *                            entry with w > 0.99 (the clamp cannot bind elsewhere: same bits); 1 = everywhere (rounds 1-5; A/B runs).
+ *   "rows_probe"             developer: 1 = the row partition's scatter kernel records shader-clock cycles per phase (ex4d_debug_rows_prof).
  *   "depth_sort_local_cap"   tests: largest bucket (0 = the kernel's capacity) the MSD depth sort finishes in LDS.
  *   "depth_sort_local_threads" 0 (default: by Gaussian count) / 256 / 512 = workgroup size of the MSD depth sort's bucket kernel.
  * Returns EX4D_OK / the value, or an error / -1. */

@@ -784,7 +784,7 @@ def test_c_abi_library_builds_loads_and_exports_declared_symbols():
     for name in declared:
         assert hasattr(handle, name), name
     l = _C.load()
-    assert l.ex4d_abi_version() == 4 and l.ex4d_target_arch() == b"gfx950"
+    assert l.ex4d_abi_version() == 5 and l.ex4d_target_arch() == b"gfx950"
     # size / layout queries are pure host code
     P = 1000
     lay = _C.GeomLayout(); l.ex4d_geom_layout(P, ctypes.byref(lay))
