@@ -284,17 +284,18 @@ __global__ __launch_bounds__(ROW_THREADS) void rows_seg_scatter_kernel(uint32_t 
     ROWS_TS(2);
     if (total == 0u) return;                 // (uniform)
     if (total > CAP) {
-        // sequential path (uniform): thread t = tile row t keeps the row's write position, the block's Gaussians pass by in depth order
+        // sequential path (uniform): thread t = tile row t keeps the row's write position, the block's Gaussians (rect + id, through LDS)
+        // pass by in depth order
+        stage[tid] = make_uint2(rc.x0 | (rc.y0 << 8) | (rc.w << 16) | (rc.h << 24), id);      // (h = 0: no instances)
+        __syncthreads();
         if (tid < NR) {
             uint32_t pos = inst_base[tid];
-            const uint32_t kend = (blockIdx.x + 1) * ROWA_GAUSS < P ? (blockIdx.x + 1) * ROWA_GAUSS : P;
-            for (uint32_t kk = blockIdx.x * ROWA_GAUSS; kk < kend; kk++) {
-                const RectU g = rect_at(r4, r8, kk);
-                if (g.w * g.h == 0u) continue;
-                const uint32_t gid = order[kk];
-                if ((uint32_t)tid >= g.y0 && (uint32_t)tid < g.y0 + g.h) {
-                    for (uint32_t j = 0; j < g.w; j++) if (pos + j < cap) words[pos + j] = ((g.x0 + j) << shift) | gid;
-                    pos += g.w;
+            for (int kk = 0; kk < ROWA_GAUSS; kk++) {
+                const uint2 e = stage[kk];
+                const uint32_t x0 = e.x & 0xFFu, y0 = (e.x >> 8) & 0xFFu, w = (e.x >> 16) & 0xFFu, h = e.x >> 24;
+                if ((uint32_t)tid - y0 < h) {
+                    for (uint32_t j = 0; j < w; j++) if (pos + j < cap) words[pos + j] = ((x0 + j) << shift) | e.y;
+                    pos += w;
                 }
             }
         }

@@ -36,6 +36,41 @@ template <int V> __global__ __launch_bounds__(256) void k(int P, const float *m,
     }
     if (acc == 12345.678f) out[idx] = acc;          // (never: keeps the loads alive)
 }
+// the STORES of preprocess_fwd: records (4 x float4 per lane, 64 bytes apart), direction sums (9 dwords per lane, 36 bytes apart), five 4-byte words;
+// W = 0: as the kernel issues them; W = 1: the same bytes as whole-wave contiguous float4 / dword streams (what a transposition through LDS would issue)
+template <int W> __global__ __launch_bounds__(256) void kst(int P, float4 *rec, float *ds, uint32_t *w0, uint32_t *w1, uint32_t *w2, uint32_t *w3, uint32_t *w4, float v)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wc = blockIdx.x * 4 + wave;
+    const int idx = wc * 64 + lane;
+    if (idx >= P) return;
+    const bool vis = (idx * 2654435761u >> 8) % 100u < 81u;
+    const float4 x = make_float4(v, v, v, v);
+    if (W == 0) {
+        if (vis) {
+            float4 *r = rec + 4 * (size_t)idx; r[0] = x; r[1] = x; r[2] = x; r[3] = x;
+            float *o = ds + 9 * (size_t)idx;
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[i] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rec[(size_t)wc * 256 + i * 64 + lane] = x;
+        float4 *o4 = reinterpret_cast<float4 *>(ds) + (size_t)wc * 144;
+        o4[lane] = x; o4[64 + lane] = x; if (lane < 16) o4[128 + lane] = x;
+    }
+    w0[idx] = 1u; w1[idx] = 2u; w2[idx] = 3u; w3[idx] = 4u; w4[idx] = 5u;
+}
+template <int W> void runst(const char *name, int P, double mb, float4 *rec, float *ds, uint32_t *w)
+{
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kst<W>, dim3((P + 255) / 256), dim3(256), 0, 0, P, rec, ds, w, w + P, w + 2 * P, w + 3 * P, w + 4 * P, 1.f);
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL(kst<W>, dim3((P + 255) / 256), dim3(256), 0, 0, P, rec, ds, w, w + P, w + 2 * P, w + 3 * P, w + 4 * P, 1.f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-64s %7.1f us  %6.2f TB/s\n", name, ms / 20 * 1e3, mb / (ms / 20 * 1e-3) / 1e6);
+}
 template <int V> void run(const char *name, int P, double mb, float *m, float *d, float *s, float4 *q, float *o, float4 *sh, float *out)
 {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -54,7 +89,11 @@ int main()
     (void)hipMalloc(&o, 4 * (size_t)P); (void)hipMalloc(&sh, 192 * (size_t)P + 4096); (void)hipMalloc(&out, 4 * (size_t)P);
     (void)hipMemset(m, 0, 12 * (size_t)P); (void)hipMemset(d, 0, 12 * (size_t)P); (void)hipMemset(s, 0, 12 * (size_t)P); (void)hipMemset(q, 0, 16 * (size_t)P);
     (void)hipMemset(o, 0, 4 * (size_t)P); (void)hipMemset(sh, 0, 192 * (size_t)P);
+    float4 *rec; float *ds; uint32_t *w;
+    (void)hipMalloc(&rec, 64 * (size_t)P + 4096); (void)hipMalloc(&ds, 36 * (size_t)P + 4096); (void)hipMalloc(&w, 20 * (size_t)P);
     for (int rep = 0; rep < 2; rep++) {
+        runst<0>("stores as the kernel issues them (81 % of 100 MB + 20 MB)", P, 0.81 * 100 + 20, rec, ds, w);
+        runst<1>("the same arrays as whole-wave contiguous streams (120 MB)", P, 120, rec, ds, w);
         run<0>("all loads of preprocess_fwd (248 MB)", P, 248, m, d, s, q, o, sh, out);
         run<1>("the SH block alone (192 MB)", P, 192, m, d, s, q, o, sh, out);
         run<2>("the per-Gaussian arrays alone (56 MB)", P, 56, m, d, s, q, o, sh, out);
