@@ -628,6 +628,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "composite_fwd_asm") && (value == 0 || value == 1)) { ex4d_set_fwd_asm(value); return EX4D_OK; }
     if (name && !strcmp(name, "binning_tile_ids") && (value == 0 || value == 1)) { g_tile_ids.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "composite_clamp_always") && (value == 0 || value == 1)) { ex4d_set_clamp_always(value); return EX4D_OK; }
+    if (name && !strcmp(name, "composite_bwd_pairs") && (value == 0 || value == 1)) { ex4d_set_bwd_pairs(value); return EX4D_OK; }
     if (name && !strcmp(name, "tile_sort_rows") && (value == 0 || value == 1)) { g_tile_rows.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "rank_lds_atomics") && value >= -1 && value <= 1) { ex4d_set_rank_lds(value); return EX4D_OK; }
     if (name && !strcmp(name, "rows_probe")) { ex4d_set_rows_probe(value); return EX4D_OK; }
@@ -650,6 +651,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "composite_fwd_asm")) return ex4d_get_fwd_asm();
     if (name && !strcmp(name, "binning_tile_ids")) return g_tile_ids.load();
     if (name && !strcmp(name, "composite_clamp_always")) return ex4d_get_clamp_always();
+    if (name && !strcmp(name, "composite_bwd_pairs")) return ex4d_get_bwd_pairs();
     if (name && !strcmp(name, "tile_sort_rows")) return g_tile_rows.load();
     if (name && !strcmp(name, "rank_lds_atomics")) return ex4d_get_rank_lds();
     if (name && !strcmp(name, "rank_lds_atomics_in_use")) return ex4d_rank_lds_in_use();      // (read-only) what the probe decided for the current device

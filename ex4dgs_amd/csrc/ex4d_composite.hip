@@ -190,7 +190,8 @@ __device__ __forceinline__ void tile_of_block(int num_tiles, int &tile, int &qua
 // pixel's running (key, location) with the strict compare `key > (best_key | 15)` -- 4 VALU per 16 entries.
 // Every chunk's survivors are appended to the quadrant's compacted list (BinState::qlist) -- all the backward reads of the tile list.
 std::atomic<int> g_fwd_asm{1};
-std::atomic<int> g_alpha_clamp_always{0};      // "composite_clamp_always" = 1: every chunk / batch evaluates min(0.99, w G) (rounds 1-5; A/B runs)      // compositing forward: hand-scheduled walk (1, default) or the compiler's (0)
+std::atomic<int> g_alpha_clamp_always{0};
+std::atomic<int> g_bwd_pairs{1};                 // "composite_bwd_pairs": the compositing backward handles two pixels per lane on packed math where it applies (round 6)      // "composite_clamp_always" = 1: every chunk / batch evaluates min(0.99, w G) (rounds 1-5; A/B runs)      // compositing forward: hand-scheduled walk (1, default) or the compiler's (0)
 
 struct FwdLds {                  // per wave: the survivors of one 64-entry chunk (4.5 KB; the kernel's VGPRs, not LDS, bound its occupancy)
     float4 q0[64];               // mean.x, mean.y, a', b'
@@ -548,12 +549,28 @@ template <int R> __device__ __forceinline__ int ring_wrap(int i) { return i >= R
 // [10] steps run in the top half, [11] in the bottom half, [12] batches with no contributing pair in the top half, [13] ... bottom half
 __device__ unsigned long long g_bwd_stats[16];
 
+// Round 6, pixel PAIRS: the per-pixel constants of the two pixels a lane handles in one row-step -- (row r, column g) and (row r, column 4 + g),
+// pair index 4 r + g -- interleaved so that every quantity is a register pair (a, b) straight from a 16-byte read: the step then runs on
+// v_pk_*_f32 (bwd_batch_pairs below).  Same LDS as the per-pixel arrays (a quadrant uses one layout or the other).
+struct BwdPairConsts {
+    float4 A[32];                // gp0.a gp0.b gp1.a gp1.b
+    float4 A2[32];               // gp2.a gp2.b gdepth.a gdepth.b
+    float4 B[32];                // final_depth.a .b  last_contributor.a .b
+    float4 C[32];                // carries: T.a T.b (bgT - E).a .b
+    float4 F[32];                // gflow0.a .b gflow1.a .b
+    float2 F2[32];               // gflow2.a .b
+};
 template <int RING> struct BwdLdsT {
     float4 ring[3][RING];        // [0] x y a' b'   [1] c' w depth id   [2] r g b list-position     (also: transposition scratch at setup)
-    float4 pa[64];               // per pixel: gp0 gp1 gp2 gdepth
-    float4 pb[64];               //            final_depth  last_contributor  T carry  (bgT - E) carry      (the two carries: one 8-byte store)
-    float4 pc[64];               //            gflow0 gflow1 gflow2  gacc carry      (read only with depth / flow / acc gradients)
-    float4 pd[64];               //            fx  fy  -  -                          (read only with sub-pixel offsets)
+    union {
+        struct {
+            float4 pa[64];       // per pixel: gp0 gp1 gp2 gdepth
+            float4 pb[64];       //            final_depth  last_contributor  T carry  (bgT - E) carry      (the two carries: one 8-byte store)
+            float4 pc[64];       //            gflow0 gflow1 gflow2  gacc carry      (read only with depth / flow / acc gradients)
+            float4 pd[64];       //            fx  fy  -  -                          (read only with sub-pixel offsets)
+        };
+        BwdPairConsts pp;
+    };
     float dump[DUMP_FLOATS];
 };
 
@@ -627,6 +644,60 @@ __device__ __forceinline__ float row_scan_add_with_sums_extra(float e, f32x2 &c7
         : [e] "+v"(e), [c78] "+v"(c78), [c9] "+v"(c9), [c1011] "+v"(c1011), [c12] "+v"(c12), [gdT] "=&v"(gdT), [v2] "+v"(v2)
         : [pxy] "v"(pxy), [pz] "v"(pz), [dd] "v"(dd), [d] "v"(d), [fxy] "v"(fxy), [fz] "v"(fz), [gd] "v"(gd), [T] "v"(T), [alpha] "v"(alpha));
     return e;
+}
+
+// The 13 sums of a batch leave the wave: every lane holds partial sums over ITS pixels -- add the four pixel-slot lanes of a Gaussian
+// (lanes n, n+16, n+32, n+48), transpose through 1 KB of LDS, one atomic instruction per 4 Gaussians covering whole 64-byte rows.
+template <bool NOLAST, typename LDS>
+__device__ __forceinline__ void bwd_batch_finish(LDS &L, int nvalid, float *__restrict__ acc16, const float (&v)[13], uint32_t id, int n, int g)
+{
+    float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
+    {
+        // every lane holds partial sums over ITS 16 pixels: add the four pixel-slot lanes of a Gaussian (lanes n, n+16, n+32, n+48).
+        // Half / row exchanges reduce two values per instruction: v_permlane32_swap(a, b) leaves a.lo | b.lo and a.hi | b.hi, whose
+        // sum holds a reduced over the halves in lanes 0-31 and b in lanes 32-63; v_permlane16_swap does the same for odd / even
+        // rows.  Four sums (a, b, c, d) end up fully reduced in ONE register: row 0 a, row 1 c, row 2 b, row 3 d.
+        // 12 exchanges + 12 additions instead of 26 ds_bpermute + 26 additions.
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float quad4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) quad4[q] = (4 * j + q < 13) ? v[4 * j + q] : 0.f;
+            float x, y;
+            if (j < 3) {
+                x = halves_sum(quad4[0], quad4[1]);
+                y = halves_sum(quad4[2], quad4[3]);
+            } else {
+                x = halves_sum(quad4[0], quad4[0]);            // only v[12]: reduced in both halves ...
+                y = x;
+            }
+            const float r = rows_sum(x, y);                     // ... and in all four rows
+            const int q = 4 * j + ((g & 1) << 1) + (g >> 1);    // rows 0 1 2 3 hold sums a c b d
+            if (q < 13) out[q] = r;
+        }
+    }
+    // byte offset of this lane's Gaussian's accumulator row (all four pixel-slot lanes write the same value); slots 304..319 of the
+    // dump area lie behind everything the steps and the transposition touch
+    reinterpret_cast<uint32_t *>(L.dump)[304 + n] = 64u * id;
+    wave_lds_sync();
+    // round r: lane (n, g) adds slot n of Gaussian 4r + g -- one atomic instruction covers whole 64-byte rows of four Gaussians.  The
+    // row offsets and the sums sit at immediate offsets of two per-lane LDS addresses; the global address is the (scalar) base of
+    // the accumulator array + a 32-bit lane offset: 1 VALU instruction per round besides the two LDS reads and the atomic
+    // (round 2 recomputed the ring slot, the LDS addresses and a 64-bit address per round: 12 VALU, one of them the ~24-cycle
+    // VOP2 v_cndmask of the ring wrap)
+    {
+        const float *pv = L.dump + 17 * g + n;
+        const uint32_t *po = reinterpret_cast<const uint32_t *>(L.dump) + 304 + g;
+        const uint32_t n4 = 4u * (uint32_t)n;
+        char *base = reinterpret_cast<char *>(acc16);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float val = pv[68 * r];
+            const uint32_t off = po[4 * r] | n4;               // 64 id + 4 n: the row offset has its low six bits clear
+            if (n < 13 && (NOLAST || 4 * r + g < nvalid)) unsafeAtomicAdd(reinterpret_cast<float *>(base + off), val);
+        }
+    }
+    wave_lds_sync();
 }
 
 // Every lane accumulates the 13 Gaussian-centred partial sums of its 16 pixels in registers (15 VALU per step), the four pixel-slot
@@ -769,7 +840,6 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
         atomicAdd(&g_bwd_stats[12], top16 == 0 ? 1ull : 0ull); atomicAdd(&g_bwd_stats[13], bot16 == 0 ? 1ull : 0ull);
     }
     wave_lds_sync();
-    float *out = L.dump + 17 * n;                  // [16 Gaussians][16 slots], row stride 17: the 16 writers of a slot hit 16 banks
     {
         float v[13];
         if (MOMENTS) {
@@ -792,51 +862,149 @@ __device__ __forceinline__ void bwd_batch(BwdLdsT<BWD_RING> &L, int head, int nv
             v[1] = (2.f * cp) * m1 + bp * m0;
             v[2] *= flagf;
         }
-        // every lane holds partial sums over ITS 16 pixels: add the four pixel-slot lanes of a Gaussian (lanes n, n+16, n+32, n+48).
-        // Half / row exchanges reduce two values per instruction: v_permlane32_swap(a, b) leaves a.lo | b.lo and a.hi | b.hi, whose
-        // sum holds a reduced over the halves in lanes 0-31 and b in lanes 32-63; v_permlane16_swap does the same for odd / even
-        // rows.  Four sums (a, b, c, d) end up fully reduced in ONE register: row 0 a, row 1 c, row 2 b, row 3 d.
-        // 12 exchanges + 12 additions instead of 26 ds_bpermute + 26 additions.
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float quad4[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) quad4[q] = (4 * j + q < 13) ? v[4 * j + q] : 0.f;
-            float x, y;
-            if (j < 3) {
-                x = halves_sum(quad4[0], quad4[1]);
-                y = halves_sum(quad4[2], quad4[3]);
-            } else {
-                x = halves_sum(quad4[0], quad4[0]);            // only v[12]: reduced in both halves ...
-                y = x;
-            }
-            const float r = rows_sum(x, y);                     // ... and in all four rows
-            const int q = 4 * j + ((g & 1) << 1) + (g >> 1);    // rows 0 1 2 3 hold sums a c b d
-            if (q < 13) out[q] = r;
-        }
+        bwd_batch_finish<NOLAST>(L, nvalid, acc16, v, __float_as_uint(g1.w), n, g);
     }
-    // byte offset of this lane's Gaussian's accumulator row (all four pixel-slot lanes write the same value); slots 304..319 of the
-    // dump area lie behind everything the steps and the transposition touch
-    reinterpret_cast<uint32_t *>(L.dump)[304 + n] = 64u * __float_as_uint(g1.w);
+}
+
+// Two inclusive scans over the 16 lanes of every DPP row, interleaved (round 6: one per pixel of a pair): between the dependent steps of one
+// chain sit the other chain's instruction and one s_nop -- the two wait states a DPP read needs behind the VALU write of its source.
+__device__ __forceinline__ void row_scan_mul2(float &a, float &b)
+{
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void row_scan_add2(float &a, float &b)
+{
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0" : "+v"(a), "+v"(b));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the batch with TWO PIXELS PER LANE.  Lane (n, g) handles, in row-step r = 0..7, the pixels (row r, column g) and (row r, column
+// 4 + g) of the quadrant -- what bwd_batch does in steps 2 r and 2 r + 1 -- with every per-pixel quantity as a register pair (a, b): the
+// exponent, alpha, 1 - alpha, the colour dot product, T, the weights, the sums all run on v_pk_{fma,mul,add}_f32 (28 packed + 28 plain
+// VALU instructions per row-step against 83 for the two steps; a packed instruction costs 1.75 plain ones on this part, the transcendentals,
+// compares, selects and the 16 DPP scan steps do not pack).  The row terms of the exponent (dy, b'dy, c'dy^2) are shared by the pair, the
+// two pixels' scans interleave (each fills the other's DPP wait states), one skip test covers both pixels.  Quadrants without sub-pixel
+// offsets and without an upstream dL_dacc (the training loop's); same decisions as the forward (the same q2 / tauq bits), sums
+// reassociated (column a and column b accumulate apart: they are the even / odd step parities of bwd_batch).
+template <bool EXTRA, bool NOLAST>
+__device__ __forceinline__ void bwd_batch_pairs(BwdLdsT<BWD_RING> &L, int head, int nvalid, float ox, float oy, float min_depth, float *__restrict__ acc16)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    constexpr int RING = BWD_RING;
+    const int slot = ring_wrap<RING>(head + n);
+    const float4 g0 = L.ring[0][slot], g1 = L.ring[1][slot], g2 = L.ring[2][slot];
+    const bool valid = n < nvalid;
+    const float ap = g0.z, bp = g0.w, cp = g1.x, w = g1.y, dep = g1.z;
+    const uint32_t orig = (uint32_t)select_i(LANES(valid), (int)__float_as_uint(g2.w), -1);
+    const uint32_t tauq = tauq_bits_of(w);
+    const float flagf = dep > min_depth ? 1.f : 0.f;
+    const float depflag = dep * flagf;
+    const float dxe = g0.x - (ox + (float)g), dxo = g0.x - (ox + (float)(4 + g));
+    const f32x2 dx2 = { dxe, dxo };
+    f32x2 S2 = { 0.f, 0.f }, Y2 = { 0.f, 0.f }, M5 = { 0.f, 0.f };                 // (sum s6, sum s6 dy, sum s6 dy dy) per column
+    f32x2 c7 = { 0.f, 0.f }, c8 = { 0.f, 0.f }, c9 = { 0.f, 0.f }, c10 = { 0.f, 0.f }, c11 = { 0.f, 0.f }, c12 = { 0.f, 0.f }, v2 = { 0.f, 0.f };
+    // carries of pixel pair 4 r + g are written by lane n == 15 of row g; the other lanes write into the dump area (no exec masking)
+    float4 *wC = (n == 15) ? &L.pp.C[g] : reinterpret_cast<float4 *>(&L.dump[4 * n]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        // (the pair's constants are requested at the top of the step and first needed behind the exponent: their LDS latency hides there;
+        // requesting them a step ahead like bwd_batch does costs 22 registers the 128-register budget does not have)
+        const float4 A = L.pp.A[4 * r + g], A2 = L.pp.A2[4 * r + g], B = L.pp.B[4 * r + g], C = L.pp.C[4 * r + g];
+        float4 F = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 F2 = make_float2(0.f, 0.f);
+        if (EXTRA) { F = L.pp.F[4 * r + g]; F2 = L.pp.F2[4 * r + g]; }
+        const float dyr = g0.y - (oy + (float)r);
+        const float bdy = bp * dyr, cdydy = (cp * dyr) * dyr, dy2 = dyr * dyr;
+        // the forward kernel's arithmetic per pixel: q2_rows(dx, ap, bdy, cdydy) = fma(dx, fma(dx, -ap, -bdy), -cdydy), identical bits
+        const f32x2 inner = __builtin_elementwise_fma(dx2, (f32x2){ -ap, -ap }, (f32x2){ -bdy, -bdy });
+        const f32x2 q2 = __builtin_elementwise_fma(dx2, inner, (f32x2){ -cdydy, -cdydy });
+        const lanemask ok_a = NOLAST ? LANES(__float_as_uint(q2.x) <= tauq) : (LANES(orig < __float_as_uint(B.z)) & LANES(__float_as_uint(q2.x) <= tauq));
+        const lanemask ok_b = NOLAST ? LANES(__float_as_uint(q2.y) <= tauq) : (LANES(orig < __float_as_uint(B.w)) & LANES(__float_as_uint(q2.y) <= tauq));
+        if ((ok_a | ok_b) == 0) continue;          // nothing changes: the carries stay, the sums get zeros
+        f32x2 G;
+        G.x = select_f(ok_a, __builtin_amdgcn_exp2f(-q2.x), 0.f);
+        G.y = select_f(ok_b, __builtin_amdgcn_exp2f(-q2.y), 0.f);
+        f32x2 alpha = (f32x2){ w, w } * G;
+        alpha.x = fminf(0.99f, alpha.x); alpha.y = fminf(0.99f, alpha.y);
+        const f32x2 om = (f32x2){ 1.f, 1.f } - alpha;
+        f32x2 inv;
+        inv.x = __builtin_amdgcn_rcpf(om.x); inv.y = __builtin_amdgcn_rcpf(om.y);
+        // c . dL_dpixel of both pixels
+        f32x2 cgp = (f32x2){ g2.x, g2.x } * (f32x2){ A.x, A.y };
+        cgp = __builtin_elementwise_fma((f32x2){ g2.y, g2.y }, (f32x2){ A.z, A.w }, cgp);
+        cgp = __builtin_elementwise_fma((f32x2){ g2.z, g2.z }, (f32x2){ A2.x, A2.y }, cgp);
+        // T = T_carry * prod_{j <= i} inv_j, both pixels
+        float sa = inv.x, sb = inv.y;
+        row_scan_mul2(sa, sb);
+        const f32x2 T = (f32x2){ C.x, C.y } * (f32x2){ sa, sb };
+        const f32x2 dcc = alpha * T;
+        const f32x2 e = dcc * cgp;
+        float ea = e.x, eb = e.y;
+        row_scan_add2(ea, eb);
+        c7 = __builtin_elementwise_fma((f32x2){ A.x, A.y }, dcc, c7);
+        c8 = __builtin_elementwise_fma((f32x2){ A.z, A.w }, dcc, c8);
+        c9 = __builtin_elementwise_fma((f32x2){ A2.x, A2.y }, dcc, c9);
+        const f32x2 Q = (f32x2){ C.z, C.w } - (f32x2){ ea, eb };
+        f32x2 dLa = __builtin_elementwise_fma(cgp, T, Q) * inv;
+        if (EXTRA) {
+            c10 = __builtin_elementwise_fma((f32x2){ F.x, F.y }, dcc, c10);
+            c11 = __builtin_elementwise_fma((f32x2){ F.z, F.w }, dcc, c11);
+            c12 = __builtin_elementwise_fma((f32x2){ F2.x, F2.y }, dcc, c12);
+            const f32x2 gdT = (f32x2){ A2.z, A2.w } * T;
+            v2 = __builtin_elementwise_fma(alpha, gdT, v2);
+            const f32x2 t = __builtin_elementwise_fma((f32x2){ B.x, B.y }, (f32x2){ flagf, flagf }, (f32x2){ -depflag, -depflag }) * gdT;
+            dLa = __builtin_elementwise_fma(t, T, dLa);
+        }
+        const f32x2 s6 = G * dLa;
+        S2 = S2 + s6;
+        Y2 = __builtin_elementwise_fma((f32x2){ dyr, dyr }, s6, Y2);
+        M5 = __builtin_elementwise_fma((f32x2){ dy2, dy2 }, s6, M5);
+        wC[4 * r] = make_float4(T.x, T.y, Q.x, Q.y);
+    }
     wave_lds_sync();
-    // round r: lane (n, g) adds slot n of Gaussian 4r + g -- one atomic instruction covers whole 64-byte rows of four Gaussians.  The
-    // row offsets and the sums sit at immediate offsets of two per-lane LDS addresses; the global address is the (scalar) base of
-    // the accumulator array + a 32-bit lane offset: 1 VALU instruction per round besides the two LDS reads and the atomic
-    // (round 2 recomputed the ring slot, the LDS addresses and a 64-bit address per round: 12 VALU, one of them the ~24-cycle
-    // VOP2 v_cndmask of the ring wrap)
     {
-        const float *pv = L.dump + 17 * g + n;
-        const uint32_t *po = reinterpret_cast<const uint32_t *>(L.dump) + 304 + g;
-        const uint32_t n4 = 4u * (uint32_t)n;
-        char *base = reinterpret_cast<char *>(acc16);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float val = pv[68 * r];
-            const uint32_t off = po[4 * r] | n4;               // 64 id + 4 n: the row offset has its low six bits clear
-            if (n < 13 && (NOLAST || 4 * r + g < nvalid)) unsafeAtomicAdd(reinterpret_cast<float *>(base + off), val);
+        float v[13];
+        const float Se = S2.x, So = S2.y, Ye = Y2.x, Yo = Y2.y;
+        v[0] = dxe * Se + dxo * So;
+        v[1] = Ye + Yo;
+        v[3] = (dxe * dxe) * Se + (dxo * dxo) * So;
+        v[4] = dxe * Ye + dxo * Yo;
+        v[0] *= w; v[1] *= w; v[3] *= w; v[4] *= w;           // sG = w s6
+        v[5] = w * (M5.x + M5.y);
+        v[2] = v2.x + v2.y; v[6] = Se + So; v[7] = c7.x + c7.y; v[8] = c8.x + c8.y; v[9] = c9.x + c9.y;
+        v[10] = c10.x + c10.y; v[11] = c11.x + c11.y; v[12] = c12.x + c12.y;
+        {
+            const float m0 = v[0], m1 = v[1];
+            v[0] = (2.f * ap) * m0 + bp * m1;
+            v[1] = (2.f * cp) * m1 + bp * m0;
+            v[2] *= flagf;
         }
+        bwd_batch_finish<NOLAST>(L, nvalid, acc16, v, __float_as_uint(g1.w), n, g);
     }
-    wave_lds_sync();
 }
 
 template <int WPB, bool STATS>
@@ -849,7 +1017,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     const float *__restrict__ final_Ts, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpixels, const float *__restrict__ dL_ddepths,
     const float *__restrict__ dL_dflows, const float *__restrict__ dL_daccs,
-    float *__restrict__ acc16, const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount)
+    float *__restrict__ acc16, const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, int pairs_on)
 {
     constexpr int RING = BWD_RING;
     __shared__ BwdLdsT<RING> lds[WPB];
@@ -882,14 +1050,27 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
     }
     const float bgT = -T_final * (bg[0] * gp0 + bg[1] * gp1 + bg[2] * gp2);
     const float ox = (float)((tile % gx) * EX4D_TILE + (quad & 1) * 8), oy = (float)((tile / gx) * EX4D_TILE + (quad >> 1) * 8);
-    L.pa[lane] = make_float4(gp0, gp1, gp2, gdepth);
-    L.pb[lane] = make_float4(final_depth, __uint_as_float(last_contributor), T_final, bgT);     // w: bgT - E, E = 0 behind the deepest contributor
-    L.pc[lane] = make_float4(gflow0, gflow1, gflow2, gacc);
-    L.pd[lane] = make_float4(p.fx, p.fy, 0.f, 0.f);
     // wave-uniform: which optional upstream gradients take part in this quadrant at all (training on the image alone has none of them)
     const bool use_gacc = LANES(gacc != 0.0f) != 0;
     const bool sep = LANES(p.fx != ox + (float)(lane & 7) || p.fy != oy + (float)(lane >> 3)) == 0;    // no sub-pixel offsets in this quadrant
     const bool use_extra = LANES(gdepth != 0.0f || gflow0 != 0.0f || gflow1 != 0.0f || gflow2 != 0.0f) != 0;
+    // round 6: two pixels per lane (bwd_batch_pairs) where the quadrant has integer pixel positions and no upstream dL_dacc
+    const bool pairs = !STATS && pairs_on && sep && !use_gacc;
+    if (pairs) {
+        // lane = pixel (x = lane & 7, y = lane >> 3): pair 4 y + (x & 3), half x >> 2
+        const int pi = 4 * (lane >> 3) + (lane & 3), hf = (lane >> 2) & 1;
+        reinterpret_cast<float *>(L.pp.A)[4 * pi + hf] = gp0;  reinterpret_cast<float *>(L.pp.A)[4 * pi + 2 + hf] = gp1;
+        reinterpret_cast<float *>(L.pp.A2)[4 * pi + hf] = gp2; reinterpret_cast<float *>(L.pp.A2)[4 * pi + 2 + hf] = gdepth;
+        reinterpret_cast<float *>(L.pp.B)[4 * pi + hf] = final_depth; reinterpret_cast<float *>(L.pp.B)[4 * pi + 2 + hf] = __uint_as_float(last_contributor);
+        reinterpret_cast<float *>(L.pp.C)[4 * pi + hf] = T_final; reinterpret_cast<float *>(L.pp.C)[4 * pi + 2 + hf] = bgT;     // (bgT - E, E = 0 behind the deepest contributor)
+        reinterpret_cast<float *>(L.pp.F)[4 * pi + hf] = gflow0; reinterpret_cast<float *>(L.pp.F)[4 * pi + 2 + hf] = gflow1;
+        reinterpret_cast<float *>(L.pp.F2)[2 * pi + hf] = gflow2;
+    } else {
+        L.pa[lane] = make_float4(gp0, gp1, gp2, gdepth);
+        L.pb[lane] = make_float4(final_depth, __uint_as_float(last_contributor), T_final, bgT);     // w: bgT - E, E = 0 behind the deepest contributor
+        L.pc[lane] = make_float4(gflow0, gflow1, gflow2, gacc);
+        L.pd[lane] = make_float4(p.fx, p.fy, 0.f, 0.f);
+    }
 
     // the ring holds finite values from the start (stale entries are read by invalid lanes)
     for (int i = lane; i < RING; i += 64) {
@@ -941,7 +1122,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
                 const bool nolast = nb == 16 && kfirst < min_last;
 #define BATCH(E, S, N, G) bwd_batch<STATS, E, S, N, G>(L, head, nb, ox, oy, min_depth, acc16)
                 // (quadrants with sub-pixel offsets take the general variant: all scans, all sums)
-                if (!sep) BATCH(true, false, false, true);
+                if (pairs) {
+                    if (use_extra) { if (nolast) bwd_batch_pairs<true, true>(L, head, nb, ox, oy, min_depth, acc16); else bwd_batch_pairs<true, false>(L, head, nb, ox, oy, min_depth, acc16); }
+                    else { if (nolast) bwd_batch_pairs<false, true>(L, head, nb, ox, oy, min_depth, acc16); else bwd_batch_pairs<false, false>(L, head, nb, ox, oy, min_depth, acc16); }
+                }
+                else if (!sep) BATCH(true, false, false, true);
                 else if (use_extra) {
                     if (use_gacc) { if (nolast) BATCH(true, true, true, true); else BATCH(true, true, false, true); }
                     else { if (nolast) BATCH(true, true, true, false); else BATCH(true, true, false, false); }
@@ -960,6 +1145,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void composite_bwd_scan_kernel(
 
 void ex4d_set_fwd_asm(int on) { g_fwd_asm.store(on); }
 void ex4d_set_clamp_always(int on) { g_alpha_clamp_always.store(on); }
+void ex4d_set_bwd_pairs(int on) { g_bwd_pairs.store(on); }
+int ex4d_get_bwd_pairs() { return g_bwd_pairs.load(); }
 int ex4d_get_clamp_always() { return g_alpha_clamp_always.load(); }
 int ex4d_get_fwd_asm() { return g_fwd_asm.load(); }
 
@@ -1002,8 +1189,8 @@ hipError_t ex4d_launch_composite_bwd(const Ex4dParams &prm, const uint2 *ranges,
     const int Tpad = 8 * ((T + 7) / 8);
 #define BWD_ARGS prm.W, prm.H, gx, T, ranges, point_list, subpixel_offset, bg, records, out_depth, out_acc, prm.min_depth, \
                  final_T, n_contrib, dL_dpix, dL_ddepth, dL_dflow, dL_dacc, acc16
-    if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, true>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, qlist, qcount);
-    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, false>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, qlist, qcount);
+    if (variant == 8) hipLaunchKernelGGL((composite_bwd_scan_kernel<1, true>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, qlist, qcount, 0);
+    else hipLaunchKernelGGL((composite_bwd_scan_kernel<1, false>), dim3(4 * Tpad), dim3(64), 0, stream, BWD_ARGS, qlist, qcount, g_bwd_pairs.load(std::memory_order_relaxed));
 #undef BWD_ARGS
     return hipGetLastError();
 }

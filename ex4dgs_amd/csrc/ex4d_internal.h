@@ -148,6 +148,8 @@ void ex4d_set_fwd_asm(int on);           // compositing forward: hand-scheduled 
 int ex4d_get_fwd_asm();
 void ex4d_set_clamp_always(int on);     // compositing: 1 = evaluate min(0.99, w G) everywhere (rounds 1-5), 0 (default) = only where w > 0.99 can reach it
 int ex4d_get_clamp_always();
+void ex4d_set_bwd_pairs(int on);        // compositing backward: two pixels per lane on packed math (default 1)
+int ex4d_get_bwd_pairs();
 hipError_t ex4d_launch_composite_fwd(const Ex4dParams &prm, const uint2 *ranges, const uint32_t *point_list,
     const float *subpixel_offset, const float4 *records, const float *bg, float *final_T, uint32_t *n_contrib,
     float *out_color, float *out_depth, float *out_acc, float *out_flow, int32_t *out_idx, uint32_t *qlist, uint32_t *qcount,
