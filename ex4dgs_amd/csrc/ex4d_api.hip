@@ -76,6 +76,7 @@ bool depth_sort_auto_msd(hipStream_t stream, bool async, uint32_t **watch)
     *watch = w;
     return true;
 }
+std::atomic<int> g_readback_side{1};        // "readback_side_stream": 1 (default, round 6) = the synchronous forward's read-back copy runs on a side stream; 0 = on the caller's stream (rounds 1-5)
 std::atomic<int> g_depth_local_cap{0};      // "depth_sort_local_cap": largest bucket the MSD depth sort finishes in LDS (0 = the kernel's capacity; tests force the through-memory path with a small value)
 std::atomic<int> g_depth_local_threads{0};  // "depth_sort_local_threads": 256 / 512 = workgroup size of the depth sort's bucket kernel, 0 = by Gaussian count
 std::atomic<int> g_geom_debug{0};    // "geom_debug_arrays": also write cov3D[P,6] and tiles_touched[P] into the geometry buffer (tests)      // "binning_tile_ids": also write the sorted tile ids (tests, debugging)
@@ -148,15 +149,21 @@ struct Readback {
     uint32_t *host = nullptr;
     size_t words = 0;
     hipEvent_t ev;
+    // "readback_side_stream": the copy runs on a stream of its own behind `ev_pre` (recorded on the caller's stream after the per-Gaussian
+    // kernel), so that the depth sort's kernels do not queue behind the copy and its system-scope release
+    hipEvent_t ev_pre;
+    hipStream_t side = nullptr;
     bool have_ev = false;
     int device = -1;
     bool init(size_t need_words)
     {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (have_ev && dev != device) { (void)hipEventDestroy(ev); have_ev = false; }
+        if (have_ev && dev != device) { (void)hipEventDestroy(ev); (void)hipEventDestroy(ev_pre); (void)hipStreamDestroy(side); side = nullptr; have_ev = false; }
         if (!have_ev) {
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ev); return false; }
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipEventDestroy(ev); (void)hipEventDestroy(ev_pre); side = nullptr; return false; }
             have_ev = true; device = dev;
         }
         if (need_words > words) {
@@ -369,8 +376,15 @@ static int forward_impl(
     const size_t rb_words = (size_t)(g.block_totals - g.total) + 2 * nblk;
     if (!async) {
         if (!g_readback.init(rb_words)) return fail(EX4D_ERR_HIP, "pinned read-back buffer allocation failed");
-        HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipEventRecord(g_readback.ev, stream));
+        if (g_readback_side.load(std::memory_order_relaxed)) {
+            HIP_TRY(hipEventRecord(g_readback.ev_pre, stream));
+            HIP_TRY(hipStreamWaitEvent(g_readback.side, g_readback.ev_pre, 0));
+            HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, g_readback.side));
+            HIP_TRY(hipEventRecord(g_readback.ev, g_readback.side));
+        } else {
+            HIP_TRY(hipMemcpyAsync(g_readback.host, g.total, rb_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(g_readback.ev, stream));
+        }
     }
     // 2. order Gaussians by depth (stable; invisible ones last); keys/ids were emitted by the preprocess kernel
     // depth_sort_msd == 2 (and auto): the tile scan is fused into the bucket kernel of the depth sort (bucket-local inclusive scans +
@@ -637,6 +651,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "preprocess_fast_path") && (value == 0 || value == 1)) { ex4d_set_preprocess_fast(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 3) { g_depth_msd.store(value); g_depth_watch.reset(); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_cap") && value >= 0 && value <= 8192) { g_depth_local_cap.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "readback_side_stream") && (value == 0 || value == 1)) { g_readback_side.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_threads") && (value == 0 || value == 256 || value == 512)) { g_depth_local_threads.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }
@@ -662,6 +677,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "depth_sort_hold")) return g_depth_watch.hold.load();        // (read-only) auto mode: frames left on the LSD sort
     if (name && !strcmp(name, "depth_sort_trips")) return g_depth_watch.trips.load();      // (read-only) auto mode: oversize buckets seen since the option was set
     if (name && !strcmp(name, "depth_sort_local_cap")) return g_depth_local_cap.load();
+    if (name && !strcmp(name, "readback_side_stream")) return g_readback_side.load();
     if (name && !strcmp(name, "depth_sort_local_threads")) return g_depth_local_threads.load();
     return -1;
 }

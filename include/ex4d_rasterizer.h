@@ -285,6 +285,14 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *                            "rank_lds_atomics_in_use" (read-only): what the last forward's device uses.
  *   "composite_clamp_always" 0 (default) = the flow-free compositing forward evaluates alpha = min(0.99, w G) only in chunks that staged an
  *                            entry with w > 0.99 (the clamp cannot bind elsewhere: same bits); 1 = everywhere (rounds 1-5; A/B runs).
+ *   "composite_bwd_pairs"    1 (default, round 6) = quadrants with integer pixel positions and no upstream dL_dacc run the compositing backward
+ *                            with two pixels per lane on packed math (v_pk_*_f32); 0 = one pixel per lane and step everywhere (rounds 2-5).
+ *                            Same decisions, sums reassociated (even / odd columns accumulate apart): equal within the gradient bars.
+ *   "readback_side_stream"   1 (default, round 6) = the synchronous forward's one read-back (instance count, frame flags) is copied on a
+ *                            stream of the library's own behind an event recorded after the per-Gaussian kernel, so that the depth sort
+ *                            does not queue behind the copy and its system-scope release (-14 us per frame at 1.0 M Gaussians);
+ *                            0 = the copy sits on the caller's stream (rounds 1-5).  Same results; the call still returns only after the
+ *                            count has arrived.
  *   "rows_probe"             developer: 1 = the row partition's scatter kernel records shader-clock cycles per phase (ex4d_debug_rows_prof).
  *   "depth_sort_local_cap"   tests: largest bucket (0 = the kernel's capacity) the MSD depth sort finishes in LDS.
  *   "depth_sort_local_threads" 0 (default: by Gaussian count) / 256 / 512 = workgroup size of the MSD depth sort's bucket kernel.

@@ -88,3 +88,22 @@ def test_ranking_by_lds_atomics_is_probed_and_equals_ballot_ranking(hip_lib):
     finally:
         _C.set_option("rank_lds_atomics", -1)
     _same(auto, ballots, "probed LDS ranking vs ballot ranking")
+
+
+def test_read_back_on_a_side_stream_equals_the_in_stream_copy(hip_lib):
+    """The synchronous forward's one read-back (instance / segment counts, frame flags) runs on a stream of its own behind an event
+    (option "readback_side_stream" = 1, the default): same frame as with the copy on the caller's stream, also from a non-default
+    stream and over frames of different sizes back to back (the pinned buffer and the side stream are reused)."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("readback_side_stream") == 1, "the side-stream read-back is the library default"
+    for cfg, P in (("cfg2", 20000), ("cfg3", 12000), ("cfg2", 1), ("cfg5", 6000)):
+        ins, st = h.scene_inputs(cfg, P=P, t=0)
+        ins = {k: v.cuda() for k, v in ins.items()}
+        ref = _frame(ins, st, readback_side_stream=0)
+        _same(_frame(ins, st, readback_side_stream=1), ref, f"side-stream read-back, {cfg} {P}")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            other = _frame(ins, st, readback_side_stream=1)
+        torch.cuda.current_stream().wait_stream(s)
+        _same(other, ref, f"side-stream read-back from a non-default stream, {cfg} {P}")
