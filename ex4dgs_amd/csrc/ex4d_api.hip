@@ -360,14 +360,16 @@ static int forward_impl(
 
     HIP_TRY(ex4d_prepare_rank_lds(stream));          // (first forward on a device: the probe of the LDS-atomic ranking, once)
     g_prof.begin(0, stream);
-    HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));        // the frame flags / Ex4dFrameStatus words
+    // the frame flags / Ex4dFrameStatus words: zeroed for the asynchronous forward (its status copy and the device-side instance count live
+    // there); the synchronous forward reads its flags from the per-chunk count pairs (round 6: one launch less in front of the per-Gaussian kernel)
+    if (async) HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
     GeomState gw = g;          // cov3D[P,6] / tiles_touched[P] are written on request only: nothing downstream reads them
     if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
                                      keys0, (uint32_t *)nullptr, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream,
-                                     msd_depth ? reinterpret_cast<uint32_t *>(g.key_ranges) : nullptr), prm, stream);
+                                     msd_depth ? reinterpret_cast<uint32_t *>(g.key_ranges) : nullptr, async), prm, stream);
     MARK(0, "preprocess_fwd");
     // the one read-back the reference also has (rasterizer_impl.cu:298-299), started here: the instance count was summed by
     // the preprocess kernel and travels to a pinned host word while the depth sort below keeps the GPU busy
@@ -445,12 +447,15 @@ static int forward_impl(
             } else HIP_TRY(hipEventSynchronize(g_readback.ev));
         }
         uint32_t instance_sum = 0;      // uint32 wrap-around like the reference's scan
+        uint32_t chunk_flags = 0;       // EX4D_CHUNK_FLOW / EX4D_CHUNK_FILTERED of every chunk, in the high bits of its segment count
         for (size_t i = 0; i < nblk; i++) {
+            const uint32_t seg = g_readback.host[(size_t)(g.block_totals - g.total) + 2 * i + 1];
             instance_sum += g_readback.host[(size_t)(g.block_totals - g.total) + 2 * i];
-            segment_sum += g_readback.host[(size_t)(g.block_totals - g.total) + 2 * i + 1];
+            segment_sum += seg & 0x3FFFFFFFu;
+            chunk_flags |= seg;
         }
-        has_flow = g_readback.host[2] != 0u;      // frame flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
-        if (prm->prefiltered && g_readback.host[1])
+        has_flow = (chunk_flags & EX4D_CHUNK_FLOW) != 0u;      // flag of the preprocess kernel: some visible Gaussian carries a non-zero dir3D
+        if (prm->prefiltered && (chunk_flags & EX4D_CHUNK_FILTERED))
             return fail(EX4D_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
         R = instance_sum;
         if (R > 0x7FFFFFFFu) return fail(EX4D_ERR_ARG, "more than 2^31-1 tile instances");

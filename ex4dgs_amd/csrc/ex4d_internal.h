@@ -18,6 +18,8 @@ static inline size_t ex4d_align_up(size_t x) { return (x + (EX4D_ALIGN - 1)) & ~
 //   float4 #2: depth (p_view.z), r, g, b          (SH colour or colors_precomp)
 //   float4 #3: dir3D.x, dir3D.y, dir3D.z, w       (per-Gaussian "flow" channel, zeros if absent; w = opacity*coef)
 #define EX4D_RECORD_FLOATS 16
+#define EX4D_CHUNK_FLOW 0x80000000u       // per-chunk count pair, second word: some visible Gaussian of the chunk carries a non-zero dir3D
+#define EX4D_CHUNK_FILTERED 0x40000000u   // ... a Gaussian of the chunk failed the frustum test although `prefiltered` was set
 #define EX4D_DSUMS_MARK 0x44535553u     // frame flag [3]: the forward stored the SH direction sums (Ex4dParams.prepare_backward)
 
 struct GeomState {
@@ -81,7 +83,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
     uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream,
-    uint32_t *key_range_slots = nullptr);      // key_range_slots: uint2[(P + 63) / 64] <- (max, max(~)) of every wave's visible depth keys (MSD depth sort)
+    uint32_t *key_range_slots = nullptr, bool global_flags = true);      // global_flags: also raise the frame-flag words [1] / [2] (else the flags travel in the per-chunk count pairs only); key_range_slots: uint2[(P + 63) / 64] <- (max, max(~)) of every wave's visible depth keys (MSD depth sort)
 
 hipError_t ex4d_launch_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
     float min_depth, float max_depth, uint8_t *present, hipStream_t stream);

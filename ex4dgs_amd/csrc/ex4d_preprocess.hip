@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint8_t *__restrict__ clamped, uint32_t *__restrict__ tiles_touched, uint2 *__restrict__ rects,
     uint32_t *__restrict__ depth_keys, uint32_t *__restrict__ depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible,
     uint32_t *__restrict__ total_instances, const ShSplit sp_, float *__restrict__ sh_dsums, int sh_predicate, uint32_t *__restrict__ rects4,
-    uint32_t *__restrict__ key_range_slots)
+    uint32_t *__restrict__ key_range_slots, int global_flags)
 {
     const int D = FAST ? 3 : D_, M = FAST ? 16 : M_;
     const float *__restrict__ cov3D_precomp = FAST ? nullptr : cov3D_precomp_;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t out_tiles = 0;
     uint32_t depth_key = depth_key_invisible;   // invisible Gaussians sort behind every visible one
     uint2 rect = make_uint2(0u, 0u);
-    bool visible = false;
+    bool visible = false, filtered = false;
     float3 p = make_float3(0.f, 0.f, 0.f), conic = make_float3(0.f, 0.f, 0.f);
     float pix_x = 0.f, pix_y = 0.f, depth = 0.f, coef = 0.f;
     if (in_range) do {
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             in_view = frustum_test(p, vm, pm, min_depth, max_depth, p_view, ndc_x, ndc_y);
         }
         if (!in_view) {
-            if (prefiltered) atomicOr(prefilter_violation, 1u);
+            if (prefiltered) { filtered = true; if (global_flags) atomicOr(prefilter_violation, 1u); }
             break;
         }
         float cov3D[6];
@@ -722,10 +722,17 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     }
     // frame flag for the compositing forward: does any visible Gaussian carry a flow vector?  (plain store of the same value by every
     // wave that sees one: no atomic, no contention; the training loop's dir3D is the all-zero gradient trap and never sets it)
-    if (__ballot(visible && (in_d0 != 0.f || in_d1 != 0.f || in_d2 != 0.f)) != 0ull) {
+    // Round 6: the two flags also travel in the chunk's count pair (bits 31 / 30 of the segment count, below) -- the synchronous forward reads
+    // them there with the counts, and the frame-flag words need no zero-fill launch in front of this kernel (global_flags = 0); the
+    // asynchronous forward keeps the words (Ex4dFrameStatus is copied from them).
+    const bool chunk_flow = __ballot(visible && (in_d0 != 0.f || in_d1 != 0.f || in_d2 != 0.f)) != 0ull;
+    const bool chunk_filtered = prefiltered && __ballot(filtered) != 0ull;
+    if (global_flags && chunk_flow) {
         if (lane == 0) prefilter_violation[1] = 1u;
     }
-    if (sh_dsums && idx == 0) prefilter_violation[2] = EX4D_DSUMS_MARK;      // frame flag [3]: this frame's direction sums exist (checked by the backward)
+    // frame flag [3]: this frame's direction sums exist (checked by the backward); written either way, so that the word never keeps the
+    // mark of an earlier frame on these buffers
+    if (idx == 0) prefilter_violation[2] = sh_dsums ? EX4D_DSUMS_MARK : 0u;
     if (in_range) {
         radii[idx] = out_radius;
         if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
@@ -743,7 +750,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t wave_sum = out_tiles, wave_seg = visible ? (rect.y >> 16) : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { wave_sum += __shfl_xor(wave_sum, o, 64); wave_seg += __shfl_xor(wave_seg, o, 64); }
-    if (lane == 0) reinterpret_cast<uint2 *>(total_instances)[wc] = make_uint2(wave_sum, wave_seg);        // one pair per 64-Gaussian chunk
+    // (a chunk has at most 64 x 255 segments: bits 30 / 31 of the word are free for the chunk's flags)
+    if (lane == 0) reinterpret_cast<uint2 *>(total_instances)[wc] = make_uint2(wave_sum, wave_seg | (chunk_flow ? EX4D_CHUNK_FLOW : 0u) | (chunk_filtered ? EX4D_CHUNK_FILTERED : 0u));        // one pair per 64-Gaussian chunk
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -1114,7 +1122,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
     const float *colors_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
     int32_t *radii, GeomState g, uint32_t *prefilter_violation, ShSplit split,
     uint32_t *depth_keys, uint32_t *depth_vals, uint32_t depth_key_base, uint32_t depth_key_invisible, uint32_t *rects4, hipStream_t stream,
-    uint32_t *key_range_slots)
+    uint32_t *key_range_slots, bool global_flags)
 {
     const float fy = prm.H / (2.0f * prm.tanfovy);   // CR/rasterizer_impl.cu:237-238
     const float fx = prm.W / (2.0f * prm.tanfovx);
@@ -1126,7 +1134,7 @@ hipError_t ex4d_launch_preprocess_fwd(const Ex4dParams &prm, const float *means3
         prm.min_depth, prm.max_depth, prm.prefiltered, prefilter_violation, \
         radii, g.records, g.cov3D, g.clamped, g.tiles_touched, g.rects, depth_keys, depth_vals, depth_key_base, depth_key_invisible, g.block_totals, split, \
         (prm.prepare_backward && (shs != nullptr || is_split)) ? g.sh_dsums : (float *)nullptr, \
-        g_preprocess_tune.load(std::memory_order_relaxed), rects4, key_range_slots
+        g_preprocess_tune.load(std::memory_order_relaxed), rects4, key_range_slots, global_flags ? 1 : 0
     if (fast) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((prm.P + 255) / 256), dim3(256), 0, stream, PF_ARGS);
 #undef PF_ARGS
