@@ -354,6 +354,7 @@ def main():
     ap.add_argument("--views-per-rank", type=int, default=1, metavar="K",
                     help="training-core steps: every rank renders K views per optimizer step, accumulates their gradients locally and exchanges ONCE "
                          "(FrameTrainer(views_per_step=K): batch = N K views, wire time per view 1/K); a timed step stays one view")
+    ap.add_argument("--no-train-leg", action="store_true", help="N > 1 rasterizer steps: skip the secondary training-core leg (gradient exchange over RCCL) reported under multi_gpu")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="tuning / A-B runs: any library option of ex4d_set_option, e.g. --set depth_sort_msd=0 (the 3-pass LSD depth sort)")
     args = ap.parse_args()
 
@@ -382,11 +383,17 @@ def main():
         _C.set_option(name, int(value))
 
     cfg = CONFIGS[args.config]
-    train_mode = (world > 1 or args.config == "cfg4" or args.train_core) and not args.forward_only
+    # N > 1 (round 6): the timed step is the SAME step as at N = 1 -- GaussianRasterizer forward + backward on resident frames, every rank on
+    # its own views, no collective in the data path (the metric BASELINE.json names; `value` at N ranks compares like with like with N = 1).
+    # The training-iteration core with the RCCL gradient exchange -- what BASELINE config 4 quotes -- is `--train-core` / `--config cfg4`
+    # (its N = 1 counterpart: `--train-core` at N = 1); at N > 1 the default run also times a short leg of it and reports it under
+    # `multi_gpu` (`--no-train-leg` skips that).
+    train_mode = (args.config == "cfg4" or args.train_core) and not args.forward_only
+    train_leg = world > 1 and not train_mode and not args.forward_only and not args.no_train_leg
     if args.optimizer is None:
         # N >= 4: reduce-scatter + sharded RAdam (row-sharded keyframe windows) + all-gather -- half the bytes per link of the all-reduce
         # and 1/N of the optimizer's HBM stream per rank; N < 4: the replicated optimizer
-        args.optimizer = ("sharded" if world >= 4 else "replicated") if train_mode else "none"
+        args.optimizer = ("sharded" if world >= 4 else "replicated") if (train_mode or train_leg) else "none"
     H, W = cfg.height, cfg.width
     g = torch.Generator().manual_seed(1000 + rank)
     grads = [torch.randn(3, H, W, generator=g).to(dev), (0.1 * torch.randn(1, H, W, generator=g)).to(dev),
@@ -397,6 +404,91 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    def run_train_core(steps, warmup):
+        """The training-iteration core, one view per rank per step (N > 1: with the gradient exchange); returns its timings and, for the
+        statistics pass of a run whose PRIMARY step it is, the frames it rendered."""
+        multi = None
+        # ---------------- training-iteration core, one view per rank per step ----------------
+        from ex4dgs_amd.trainer import FrameTrainer
+        model, cam, bg = make_scene(args.config, P=args.points, device=dev, fused=True)
+        cam = cam.to(dev); bg = bg.to(dev)
+        P = model.num_static + model.num_dynamic
+        n_stamps = 300 if args.config == "cfg4" else 8
+        all_stamps = list(range(300)) if args.config == "cfg4" else [0, 137, 299, 41, 203, 88, 266, 171]
+        my_stamps = [all_stamps[i] for i in xdist.shard_views(n_stamps, rank, world)]      # i = rank (mod world)
+        upstream = lambda out: ([out["render"], out["depth"], out["opticalflow"], out["acc"]], grads)
+        exchange = "none" if (world == 1 or args.no_allreduce) else ("sharded" if args.optimizer == "sharded" else "allreduce")
+        if world == 1 and args.optimizer == "sharded":
+            exchange = "sharded"
+        kv = max(1, args.views_per_rank)
+        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if (args.dense_keyframe_grads or kv > 1) else None),
+                          lrs={n: 1e-7 for n in model.PARAM_NAMES},       # tiny learning rates: the synthetic scene stays put
+                          async_forward=(False if (args.sync_forward or kv > 1) else None), views_per_step=kv)
+
+        def step(i):
+            return tr.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)["render"]
+
+        ms_wall, per_step = timed_loop(step, steps, warmup, sync_all, finish=tr.flush)
+        parallelism = f"views/timestamps sharded i = r (mod {world}), parameters replicated" + (
+            "" if tr.exchange is None else (" + reduce-scatter / sharded RAdam / all-gather" if exchange == "sharded" else " + async RCCL all-reduce of the 15 model-parameter gradients"))
+        step_what = (("" if kv == 1 else f"[{kv} views per rank and optimizer step, gradients accumulated locally, one exchange per {kv} views] ") +
+                     "training-iteration core of one view per rank: fused attribute evaluation -> rasterizer forward+backward -> attribute "
+                     "backward" + ("" if tr.exchange is None else " -> gradient exchange") + ("" if args.optimizer == "none" else f" -> {args.optimizer} RAdam step"))
+        secondary = {}
+        if args.optimizer != "none":
+            # secondary number: the same step without the optimizer (the mode in which the exchange can hide behind the next frame)
+            trn = FrameTrainer(model, exchange=("none" if exchange == "sharded" else exchange), optimizer=False)
+            stepn = lambda i: trn.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)
+            ms_noopt, _ = timed_loop(stepn, steps, max(2, warmup // 2), sync_all, finish=trn.flush)
+            secondary["ms_per_step_without_optimizer"] = round(xdist.allreduce_max_scalar(ms_noopt, device=dev), 4)
+            del trn
+        if world > 1:
+            # the same loop (same optimizer) without the exchange (exposed communication = difference) and the exchange alone (its full length)
+            tr0 = FrameTrainer(model, exchange="none", optimizer=(args.optimizer != "none"), sliced=(False if args.dense_keyframe_grads else None),
+                               lrs={n: 1e-7 for n in model.PARAM_NAMES})
+            step0 = lambda i: tr0.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)
+            ms_noex, _ = timed_loop(step0, steps, max(2, warmup // 2), sync_all, finish=tr0.flush)
+            ex_alone = None
+            if tr.exchange is not None and exchange == "allreduce":
+                trg = FrameTrainer(model, exchange="none")
+                trg.step(cam, bg, my_stamps[0], upstream, near=cfg.min_depth, far=cfg.max_depth); trg.flush()
+                gd = trg.grads()
+                gfeat = [gd[tr.names[i]] for i in tr.feat_pos]
+                grest = [gd[tr.names[i]] for i in tr.rest_pos]
+
+                def ex_only(i):
+                    tr.exchange_feat.launch(gfeat); tr.exchange.launch(grest); tr.exchange_feat.wait(); tr.exchange.wait()
+                ex_alone, _ = timed_loop(ex_only, max(4, steps // 4), 2, sync_all)
+            ms_noex_local = ms_noex
+            ms_noex = xdist.allreduce_max_scalar(ms_noex, device=dev)
+            # ranks that really took part: a sum all-reduce of ones over the process group (RCCL on the GPU backend), not the configured size
+            ones = torch.ones(1, device=dev)
+            torch.distributed.all_reduce(ones)
+            per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+            per_rank[rank] = max(0.0, ms_wall - ms_noex_local)          # this rank's own exposed exchange (its step with - without the exchange)
+            torch.distributed.all_reduce(per_rank)
+            multi = {"ranks_seen": int(round(float(ones.item()))), "world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                     "exposed_exchange_ms_per_rank": [round(float(x), 4) for x in per_rank.tolist()],
+                     "optimizer": args.optimizer,
+                     "collective_tensors": len(model.PARAM_NAMES) if tr.exchange is not None else 0,
+                     "exchange_bytes_per_rank": tr.exchange_bytes_on_wire(),
+                     "sliced_keyframe_gradients": bool(tr.sliced),
+                     "ms_per_step_without_exchange": round(ms_noex, 4),
+                     "allreduce_ms_per_step": None if ex_alone is None else round(xdist.allreduce_max_scalar(ex_alone, device=dev), 4),
+                     "share_device": bool(args.share_device)}
+            multi.update(secondary)
+        ms_step = xdist.allreduce_max_scalar(ms_wall, device=dev)
+        if multi is not None:
+            multi["exposed_exchange_ms_per_step"] = round(max(0.0, ms_step - multi["ms_per_step_without_exchange"]), 4)
+            if multi["allreduce_ms_per_step"] is not None:
+                multi["overlapped_exchange_ms_per_step"] = round(max(0.0, multi["allreduce_ms_per_step"] - multi["exposed_exchange_ms_per_step"]), 4)
+        model.fused = False           # plain getters for the statistics pass below (one [P,16,3] SH tensor instead of the SplitSH)
+        frames = [frame_inputs(model, t, dev) for t in my_stamps[:2]]
+        settings = tr._settings(cam, bg, cfg.min_depth, cfg.max_depth)
+        return dict(ms_wall=ms_wall, ms_step=ms_step, per_step=per_step, multi=multi, secondary=secondary, parallelism=parallelism, step_what=step_what,
+                    frames=frames, settings=settings, P=P, my_stamps=my_stamps)
+
 
     multi = None
     if not train_mode:
@@ -478,88 +570,30 @@ def main():
                 async_frames.enabled = False
         parallelism = f"frame-sharded x{world}" + ("" if world == 1 else " (no collective)")
         step_what = "GaussianRasterizer forward" + ("" if args.forward_only else " + backward") + " on a resident frame" + mode_note
-    else:
-        # ---------------- training-iteration core, one view per rank per step ----------------
-        from ex4dgs_amd.trainer import FrameTrainer
-        model, cam, bg = make_scene(args.config, P=args.points, device=dev, fused=True)
-        cam = cam.to(dev); bg = bg.to(dev)
-        P = model.num_static + model.num_dynamic
-        n_stamps = 300 if args.config == "cfg4" else 8
-        all_stamps = list(range(300)) if args.config == "cfg4" else [0, 137, 299, 41, 203, 88, 266, 171]
-        my_stamps = [all_stamps[i] for i in xdist.shard_views(n_stamps, rank, world)]      # i = rank (mod world)
-        upstream = lambda out: ([out["render"], out["depth"], out["opticalflow"], out["acc"]], grads)
-        exchange = "none" if (world == 1 or args.no_allreduce) else ("sharded" if args.optimizer == "sharded" else "allreduce")
-        if world == 1 and args.optimizer == "sharded":
-            exchange = "sharded"
-        kv = max(1, args.views_per_rank)
-        tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if (args.dense_keyframe_grads or kv > 1) else None),
-                          lrs={n: 1e-7 for n in model.PARAM_NAMES},       # tiny learning rates: the synthetic scene stays put
-                          async_forward=(False if (args.sync_forward or kv > 1) else None), views_per_step=kv)
 
-        def step(i):
-            return tr.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)["render"]
 
-        ms_wall, per_step = timed_loop(step, args.steps, args.warmup, sync_all, finish=tr.flush)
-        parallelism = f"views/timestamps sharded i = r (mod {world}), parameters replicated" + (
-            "" if tr.exchange is None else (" + reduce-scatter / sharded RAdam / all-gather" if exchange == "sharded" else " + async RCCL all-reduce of the 15 model-parameter gradients"))
-        step_what = (("" if kv == 1 else f"[{kv} views per rank and optimizer step, gradients accumulated locally, one exchange per {kv} views] ") +
-                     "training-iteration core of one view per rank: fused attribute evaluation -> rasterizer forward+backward -> attribute "
-                     "backward" + ("" if tr.exchange is None else " -> gradient exchange") + ("" if args.optimizer == "none" else f" -> {args.optimizer} RAdam step"))
-        secondary = {}
-        if args.optimizer != "none":
-            # secondary number: the same step without the optimizer (the mode in which the exchange can hide behind the next frame)
-            trn = FrameTrainer(model, exchange=("none" if exchange == "sharded" else exchange), optimizer=False)
-            stepn = lambda i: trn.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)
-            ms_noopt, _ = timed_loop(stepn, args.steps, max(2, args.warmup // 2), sync_all, finish=trn.flush)
-            secondary["ms_per_step_without_optimizer"] = round(xdist.allreduce_max_scalar(ms_noopt, device=dev), 4)
-            del trn
-        if world > 1:
-            # the same loop (same optimizer) without the exchange (exposed communication = difference) and the exchange alone (its full length)
-            tr0 = FrameTrainer(model, exchange="none", optimizer=(args.optimizer != "none"), sliced=(False if args.dense_keyframe_grads else None),
-                               lrs={n: 1e-7 for n in model.PARAM_NAMES})
-            step0 = lambda i: tr0.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)
-            ms_noex, _ = timed_loop(step0, args.steps, max(2, args.warmup // 2), sync_all, finish=tr0.flush)
-            ex_alone = None
-            if tr.exchange is not None and exchange == "allreduce":
-                trg = FrameTrainer(model, exchange="none")
-                trg.step(cam, bg, my_stamps[0], upstream, near=cfg.min_depth, far=cfg.max_depth); trg.flush()
-                gd = trg.grads()
-                gfeat = [gd[tr.names[i]] for i in tr.feat_pos]
-                grest = [gd[tr.names[i]] for i in tr.rest_pos]
-
-                def ex_only(i):
-                    tr.exchange_feat.launch(gfeat); tr.exchange.launch(grest); tr.exchange_feat.wait(); tr.exchange.wait()
-                ex_alone, _ = timed_loop(ex_only, max(4, args.steps // 4), 2, sync_all)
-            ms_noex_local = ms_noex
-            ms_noex = xdist.allreduce_max_scalar(ms_noex, device=dev)
-            # ranks that really took part: a sum all-reduce of ones over the process group (RCCL on the GPU backend), not the configured size
-            ones = torch.ones(1, device=dev)
-            torch.distributed.all_reduce(ones)
-            per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
-            per_rank[rank] = max(0.0, ms_wall - ms_noex_local)          # this rank's own exposed exchange (its step with - without the exchange)
-            torch.distributed.all_reduce(per_rank)
-            multi = {"ranks_seen": int(round(float(ones.item()))), "world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
-                     "exposed_exchange_ms_per_rank": [round(float(x), 4) for x in per_rank.tolist()],
-                     "optimizer": args.optimizer,
-                     "collective_tensors": len(model.PARAM_NAMES) if tr.exchange is not None else 0,
-                     "exchange_bytes_per_rank": tr.exchange_bytes_on_wire(),
-                     "sliced_keyframe_gradients": bool(tr.sliced),
-                     "ms_per_step_without_exchange": round(ms_noex, 4),
-                     "allreduce_ms_per_step": None if ex_alone is None else round(xdist.allreduce_max_scalar(ex_alone, device=dev), 4),
-                     "share_device": bool(args.share_device)}
-            multi.update(secondary)
-        model.fused = False           # plain getters for the statistics pass below (one [P,16,3] SH tensor instead of the SplitSH)
-        frames = [frame_inputs(model, t, dev) for t in my_stamps[:2]]
-        settings = tr._settings(cam, bg, cfg.min_depth, cfg.max_depth)
+    secondary = {}
+    if train_mode:
+        tc = run_train_core(args.steps, args.warmup)
+        ms_wall, per_step, multi, secondary = tc["ms_wall"], tc["per_step"], tc["multi"], tc["secondary"]
+        parallelism, step_what, frames, settings, P, my_stamps = tc["parallelism"], tc["step_what"], tc["frames"], tc["settings"], tc["P"], tc["my_stamps"]
         empty = torch.Tensor([])
         means2D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
         dir3D = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in frames]
+    elif train_leg:
+        # secondary leg of an N > 1 run: the training-iteration core with the RCCL exchange, a short loop -- NOT the line's `value`
+        tc = run_train_core(min(args.steps, 12), min(args.warmup, 3))
+        multi = tc["multi"] or {}
+        multi["train_core_ms_per_step"] = round(tc["ms_step"], 4)
+        multi["train_core_ms_per_frame"] = round(tc["ms_step"] / world, 4)
+        multi["train_core_step"] = tc["step_what"]
+        multi["train_core_parallelism"] = tc["parallelism"]
+        multi["note"] = ("secondary leg (min(steps, 12) timed steps): the training-iteration core of BASELINE config 4's kind on this config, one view per rank and step, "
+                         "with the gradient exchange over the process group; the line's `value` is the rasterizer step above, without any collective")
+        multi.update(tc["secondary"])
+        del tc
 
     ms_per_step = xdist.allreduce_max_scalar(ms_wall, device=dev)
-    if multi is not None:
-        multi["exposed_exchange_ms_per_step"] = round(max(0.0, ms_per_step - multi["ms_per_step_without_exchange"]), 4)
-        if multi["allreduce_ms_per_step"] is not None:
-            multi["overlapped_exchange_ms_per_step"] = round(max(0.0, multi["allreduce_ms_per_step"] - multi["exposed_exchange_ms_per_step"]), 4)
 
     # ---- per-stage hipEvent timing of the rasterizer (outside the timed region), scene statistics ----------------
     _C.profile_enable(True)

@@ -365,7 +365,10 @@ static int forward_impl(
     if (async) HIP_TRY(ex4d_launch_zero(g.total, 8 * sizeof(uint32_t), stream));
     // 1. per-Gaussian preprocess
     GeomState gw = g;          // cov3D[P,6] / tiles_touched[P] are written on request only: nothing downstream reads them
-    if (!g_geom_debug.load(std::memory_order_relaxed)) { gw.cov3D = nullptr; gw.tiles_touched = nullptr; }
+    if (!g_geom_debug.load(std::memory_order_relaxed)) {
+        gw.cov3D = nullptr; gw.tiles_touched = nullptr;
+        if (packed_rects) gw.rects = nullptr;      // (round 6) every consumer takes the packed 4-byte rects when the image has <= 255 x 255 tiles: 8 MB less written at 1.0 M Gaussians
+    }
     STAGE(ex4d_launch_preprocess_fwd(*prm, means3D, dir3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                                      viewmatrix, projmatrix, campos, radii, gw, g.total + 1, split,
                                      keys0, (uint32_t *)nullptr, key_base, key_invisible, packed_rects ? g.rects4 : nullptr, stream,

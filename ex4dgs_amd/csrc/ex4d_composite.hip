@@ -209,16 +209,16 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
 // (red, green, depth, 1) is requested into CUR0 as soon as the mean and the conic have been consumed; v60-v63 temporaries.  Branch targets carry the statement's unique id (%=) and the set's letter.
 #define EX4D_FWD_CLAMP "v_min_f32 v60, 0x3f7d70a4, v60\n\t"              /* alpha = min(0.99, w G) */
 #define EX4D_FWD_NOCLAMP ""                                            /* w <= 0.99 and G <= 1 in range: w G <= 0.99 already */
-#define EX4D_FWD_ENTRY(S, CLAMP, CUR0, CX, CY, CA, CB, CC, CW, CT, CBLUE, NXT0, NXT1, G2RG, G2DA) \
-    "ds_read_b128 " NXT0 ", %[va] offset:16\n\t" \
-    "ds_read_b128 " NXT1 ", %[va] offset:1040\n\t" \
+#define EX4D_FWD_ENTRY(S, CLAMP, CUR0, CX, CY, CA, CB, CC, CW, CT, CBLUE, NXT0, NXT1, G2RG, G2DA, ONXT0, ONXT1, OCOL, LAST, ADVANCE) \
+    "ds_read_b128 " NXT0 ", %[va] offset:" ONXT0 "\n\t" \
+    "ds_read_b128 " NXT1 ", %[va] offset:" ONXT1 "\n\t" \
     "s_waitcnt lgkmcnt(2)\n\t"                                   /* this entry's operands (requested one entry earlier) have arrived */ \
     "v_sub_f32 v60, " CY ", %[fy]\n\t" \
     "v_sub_f32 v61, " CX ", %[fx]\n\t" \
     "v_mul_f32 v62, v60, " CC "\n\t" \
     "v_mul_f32_e64 v63, " CB ", -v60\n\t" \
     "v_fma_f32 v63, v61, -" CA ", v63\n\t" \
-    "ds_read_b128 " CUR0 ", %[va] offset:2048\n\t"               /* (red, green, depth, 1) into the quad whose mean / conic are consumed */ \
+    "ds_read_b128 " CUR0 ", %[va] offset:" OCOL "\n\t"           /* (red, green, depth, 1) into the quad whose mean / conic are consumed */ \
     "v_mul_f32_e64 v62, v62, -v60\n\t" \
     "v_fmac_f32 v62, v61, v63\n\t"                               /* q2 = -power log2(e) */ \
     "v_exp_f32_e64 v60, -v62\n\t" \
@@ -241,11 +241,11 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
     "v_lshl_or_b32 v61, v62, 4, %[jkey]\n\t"                     /* dominant index key: (weight bits << 4) | (15 - j mod 16), exact */ \
     "v_sub_f32 %[T], %[T], v62\n\t" \
     "v_max_u32 %[best], %[best], v61\n\t" \
-    "v_mov_b32 %[last], %[va]\n\t" \
+    LAST                                                         /* the lane's last contributing entry, as its LDS address */ \
     "s_mov_b64 exec, -1\n" \
     "Lskip" S "_%=:\n\t" \
     "s_add_i32 %[jkey], %[jkey], -1\n\t" \
-    "v_add_u32 %[va], 16, %[va]\n\t" \
+    ADVANCE \
     "s_cmp_lg_u32 %[jkey], %[jend]\n\t"
 #define EX4D_FWD_RARE(S, V) \
     "Lrare" S "_%=:\n\t" \
@@ -253,7 +253,7 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
     "s_andn2_b64 %[ok], %[ok], %[stop]\n\t"                      /* the lanes that still add */ \
     "s_cbranch_scc1 Ladd" S "_%=\n\t" \
     "s_cmp_eq_u64 %[live], 0\n\t" \
-    "s_cbranch_scc1 Ldead" V "_%=\n\t" \
+    "s_cbranch_scc1 Ldead" S "_%=\n\t" \
     "s_branch Lskip" S "_%=\n"
 
 // the walk over the staged entries of a chunk (labels carry the variant tag V: both variants live in ONE asm statement -- two statements in
@@ -264,9 +264,11 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
                     "s_max_i32 %[jend], %[jend], -1\n\t" \
                     "s_mov_b32 %[jkey], 15\n" \
                     "Lloop" V "_%=:\n\t" \
-                    EX4D_FWD_ENTRY("a" V, CLAMP, "v[40:43]", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[48:51]", "v[52:55]", "v[40:41]", "v[42:43]") \
-                    "s_cbranch_scc0 Lgdone" V "_%=\n\t" \
-                    EX4D_FWD_ENTRY("b" V, CLAMP, "v[48:51]", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[40:43]", "v[44:47]", "v[48:49]", "v[50:51]") \
+                    EX4D_FWD_ENTRY("a" V, CLAMP, "v[40:43]", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[48:51]", "v[52:55]", "v[40:41]", "v[42:43]", \
+                                   "16", "1040", "2048", "v_mov_b32 %[last], %[va]\n\t", "") \
+                    "s_cbranch_scc0 Lgodd" V "_%=\n\t" \
+                    EX4D_FWD_ENTRY("b" V, CLAMP, "v[48:51]", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[40:43]", "v[44:47]", "v[48:49]", "v[50:51]", \
+                                   "32", "1056", "2064", "v_add_u32 %[last], 16, %[va]\n\t", "v_add_u32 %[va], 32, %[va]\n\t") \
                     "s_cbranch_scc1 Lloop" V "_%=\n" \
                     "Lgdone" V "_%=:\n\t" \
                     "v_or_b32 v60, 15, %[dkey]\n\t" \
@@ -281,7 +283,12 @@ typedef const __attribute__((address_space(3))) f32x4 *lds_float4_ptr;
                     "s_branch Ldone_%=\n" \
                     EX4D_FWD_RARE("a" V, V) \
                     EX4D_FWD_RARE("b" V, V) \
-                    "Ldead" V "_%=:\n\t" \
+                    "Lgodd" V "_%=:\n\t"                         /* the group ended on set a (the chunk's last, odd count): va behind that entry */ \
+                    "v_add_u32 %[va], 16, %[va]\n\t" \
+                    "s_branch Lgdone" V "_%=\n" \
+                    "Ldeadb" V "_%=:\n\t"                        /* every lane is done: va behind the current entry, nothing left of the chunk */ \
+                    "v_add_u32 %[va], 16, %[va]\n" \
+                    "Ldeada" V "_%=:\n\t" \
                     "v_add_u32 %[va], 16, %[va]\n\t" \
                     "s_mov_b32 %[rem], 0\n\t" \
                     "s_branch Lgdone" V "_%=\n"

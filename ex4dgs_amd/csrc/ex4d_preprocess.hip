@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     if (in_range) {
         radii[idx] = out_radius;
         if (tiles_touched) tiles_touched[idx] = out_tiles;      // only on request ("geom_debug_arrays"): the rect carries the count
-        rects[idx] = rect;
+        if (rects) rects[idx] = rect;      // (the 8-byte form: frames whose rects do not fit the packed word, and on request -- "geom_debug_arrays")
         if (rects4) rects4[idx] = (rect.x & 0xFFu) | ((rect.x >> 16) << 8) | ((rect.y & 0xFFu) << 16) | ((rect.y >> 16) << 24);      // (<= 255 x 255 tiles)
         depth_keys[idx] = depth_key;
         if (depth_vals) depth_vals[idx] = (uint32_t)idx;          // (nullptr: the depth sort's first pass takes the index itself)

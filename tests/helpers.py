@@ -130,8 +130,10 @@ def compare_forward(o, g, atol=1e-5, max_fragile_frac=2e-3, frag_eps=None, tag="
         assert np.array_equal(o["radii"], to_np(g["radii"])), "radii differ"
         if geom_debug:
             assert np.array_equal(o["tiles_touched"].astype(np.int64), to_np(g["tiles_touched"]).astype(np.int64) & 0xFFFFFFFF), "tiles_touched differ"
-        rects = to_np(g["rects"]).astype(np.int64)         # the tile rect is always there: its area is tiles_touched
-        assert np.array_equal(o["tiles_touched"].astype(np.int64)[vis], ((rects[:, 1] & 0xFFFF) * (rects[:, 1] >> 16))[vis]), "tile rect area differs from tiles_touched"
+            # (the 8-byte tile rects: with the debug option, or when the image has more than 255 x 255 tiles -- otherwise only the packed
+            # 4-byte rects exist, an internal array whose content shows in point_list / ranges)
+            rects = to_np(g["rects"]).astype(np.int64)
+            assert np.array_equal(o["tiles_touched"].astype(np.int64)[vis], ((rects[:, 1] & 0xFFFF) * (rects[:, 1] >> 16))[vis]), "tile rect area differs from tiles_touched"
         keys = ("depths", "means2D", "conic_opacity") + (("cov3D",) if (o["_inputs"]["cov3D_precomp"] is None and geom_debug) else ())
         for k in keys:
             a, b = o[k][vis], to_np(g[k])[vis]

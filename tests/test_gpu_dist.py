@@ -307,6 +307,14 @@ def test_bench_spawns_its_ranks_itself(hip_lib, config):
     assert d["multi_gpu"]["collective_tensors"] == 15
     assert d["multi_gpu"]["exchange_bytes_per_rank"] > 0 and d["value"] > 0
     assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2
+    if config == "cfg3":
+        # round 6: the default N > 1 step is the N = 1 step (rasterizer forward + backward, every rank its own views, no collective) --
+        # the training-iteration core with the exchange is the secondary leg under multi_gpu
+        assert "no collective" in d["config"]["parallelism"] and "GaussianRasterizer forward + backward" in d["config"]["step"]
+        assert d["multi_gpu"]["train_core_ms_per_step"] > 0 and "gradient exchange" in d["multi_gpu"]["train_core_step"]
+        assert d["roofline"] is not None and d["roofline"]["kernel"] in d["roofline"]["stage_ms"]
+    else:
+        assert "gradient exchange" in d["config"]["step"]          # BASELINE config 4 is quoted on the training core
 
 
 def test_bench_refuses_a_rank_count_it_cannot_start(hip_lib):
