@@ -303,18 +303,27 @@ def percentiles(ms):
     s = sorted(ms)
     pick = lambda q: s[min(len(s) - 1, int(round(q * (len(s) - 1))))]
     return {"mean": round(sum(s) / len(s), 4), "p50": round(pick(0.5), 4), "p95": round(pick(0.95), 4), "min": round(s[0], 4), "max": round(s[-1], 4),
-            "n": len(s), "how": "hipEvent pairs around every timed step on the op's stream"}
+            "n": len(s), "how": "hipEvent pairs around every step of a second loop of the same K steps, behind the timed region (which holds nothing but the steps)"}
 
 
 def timed_loop(step, steps, warmup, sync_all, finish=None):
-    """W warm-up steps, then K timed steps between barrier + synchronize pairs; per-step hipEvents on the current stream."""
+    """W warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs -- nothing but the steps inside the timed region
+    (round 6: the per-step hipEvents of rounds 2-5 sat inside it, one marker packet per step on the op's stream).  The per-step
+    distribution (`step_ms`) comes from a SECOND loop of the same K steps with an event recorded after every step, outside the timed
+    region."""
     for i in range(warmup):
         step(i)
     if finish:
         finish()
     sync_all()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    if finish:
+        finish()
+    sync_all()
+    t1 = time.perf_counter()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     ev[0].record()
     for i in range(steps):
         step(i)
@@ -322,7 +331,6 @@ def timed_loop(step, steps, warmup, sync_all, finish=None):
     if finish:
         finish()
     sync_all()
-    t1 = time.perf_counter()
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     return 1e3 * (t1 - t0) / max(steps, 1), per_step
 

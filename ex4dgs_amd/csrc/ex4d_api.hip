@@ -76,6 +76,7 @@ bool depth_sort_auto_msd(hipStream_t stream, bool async, uint32_t **watch)
     *watch = w;
     return true;
 }
+std::atomic<int> g_depth_msd_bits{0};       // "depth_sort_msd_bits": 0 (default) = by Gaussian count (9 bits up to 1.3 M, 10 beyond); 9 / 10 = forced (tests, A/B runs)
 std::atomic<int> g_readback_side{1};        // "readback_side_stream": 1 (default, round 6) = the synchronous forward's read-back copy runs on a side stream; 0 = on the caller's stream (rounds 1-5)
 std::atomic<int> g_depth_local_cap{0};      // "depth_sort_local_cap": largest bucket the MSD depth sort finishes in LDS (0 = the kernel's capacity; tests force the through-memory path with a small value)
 std::atomic<int> g_depth_local_threads{0};  // "depth_sort_local_threads": 256 / 512 = workgroup size of the depth sort's bucket kernel, 0 = by Gaussian count
@@ -352,6 +353,11 @@ static int forward_impl(
     if (!(packed_rects && ex4d_depth_sort_msd_applies((uint32_t)P, key_bits))) msd_mode = 0;
     else if (msd_mode == 3) msd_mode = depth_sort_auto_msd(stream, async, &msd_watch) ? 2 : 0;
     const bool msd_depth = msd_mode != 0;
+    int msd_bits = ex4d_depth_sort_msd_bits((uint32_t)P, key_bits);      // width of its top digit: 9 bits up to 1.3 M Gaussians, 10 beyond (round 6)
+    {   // (option "depth_sort_msd_bits": a forced 9 only where the key bits under a 9-bit digit fit the bucket kernel's LDS word)
+        const int forced = g_depth_msd_bits.load(std::memory_order_relaxed);
+        if (forced == EX4D_DLS_MSD_BITS || (forced == EX4D_DLS_MSD_BITS - 1 && ex4d_depth_sort_msd_bits(1u, key_bits) == forced)) msd_bits = forced;
+    }
     // the LSD sort ping-pongs between the (a) and (b) pairs and has to end in (a) = depth_order: start in (b) for an odd pass count
     const bool start_in_b = (ex4d_radix_passes((uint32_t)P, key_bits) & 1) != 0;
     uint32_t *keys0 = start_in_b ? g.sort_keys_b : g.sort_keys_a, *vals0 = start_in_b ? g.sort_vals_b : g.depth_order;
@@ -401,7 +407,7 @@ static int forward_impl(
         STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_invisible,
                                   g.total, g.key_ranges, g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
                                   fused_scan ? g.sorted_offsets : nullptr, fused_scan ? g.bucket_sums : nullptr, T, (fused_scan || rows_sort) ? im.ranges : nullptr,
-                                  g_depth_local_threads.load(std::memory_order_relaxed), msd_watch), prm, stream);
+                                  g_depth_local_threads.load(std::memory_order_relaxed), msd_watch, msd_bits), prm, stream);
         MARK(0, "depth_sort");
         // 3. instance offsets in depth order + total: the rects arrive in depth order (rects4_b), nothing to gather
         if (!fused_scan && !rows_sort) {
@@ -487,7 +493,7 @@ static int forward_impl(
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).
         // The sorted tile ids are materialised on request only (option "binning_tile_ids"): nothing downstream reads them
         STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, b.tile_ids, b.vals_tmp, R, stream,
-                                    fused_scan ? g.sort_keys_b : nullptr, g.total + EX4D_FLAG_DPARAMS, g.bucket_sums, g.total), prm, stream);
+                                    fused_scan ? g.sort_keys_b : nullptr, g.total + EX4D_FLAG_DPARAMS, g.bucket_sums, g.total, msd_bits), prm, stream);
         if (async && fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         MARK(0, "duplicate");
         STAGE(ex4d_tile_sort_msd(b.tile_ids, b.vals_tmp, b.keys_tmp, b.point_list, g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr,
@@ -497,7 +503,7 @@ static int forward_impl(
     } else {
         if (R > 0) {
             STAGE(ex4d_launch_duplicate(P, W, H, g.depth_order, g.sorted_offsets, g.scan_block_sums, dup_rects, dup_rects4, k0, v0, R, stream,
-                                        fused_scan ? g.sort_keys_b : nullptr, g.total + EX4D_FLAG_DPARAMS, g.bucket_sums, g.total), prm, stream);
+                                        fused_scan ? g.sort_keys_b : nullptr, g.total + EX4D_FLAG_DPARAMS, g.bucket_sums, g.total, msd_bits), prm, stream);
             if (async && fused_scan) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
             MARK(0, "duplicate");
             bool res_a = true;
@@ -660,6 +666,7 @@ int ex4d_set_option(const char *name, int value)
     if (name && !strcmp(name, "depth_sort_msd") && value >= 0 && value <= 3) { g_depth_msd.store(value); g_depth_watch.reset(); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_cap") && value >= 0 && value <= 8192) { g_depth_local_cap.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "readback_side_stream") && (value == 0 || value == 1)) { g_readback_side.store(value); return EX4D_OK; }
+    if (name && !strcmp(name, "depth_sort_msd_bits") && (value == 0 || value == EX4D_DLS_MSD_BITS - 1 || value == EX4D_DLS_MSD_BITS)) { g_depth_msd_bits.store(value); return EX4D_OK; }
     if (name && !strcmp(name, "depth_sort_local_threads") && (value == 0 || value == 256 || value == 512)) { g_depth_local_threads.store(value); return EX4D_OK; }
     return fail(EX4D_ERR_ARG, "unknown option or value out of range");
 }
@@ -686,6 +693,7 @@ int ex4d_get_option(const char *name)
     if (name && !strcmp(name, "depth_sort_trips")) return g_depth_watch.trips.load();      // (read-only) auto mode: oversize buckets seen since the option was set
     if (name && !strcmp(name, "depth_sort_local_cap")) return g_depth_local_cap.load();
     if (name && !strcmp(name, "readback_side_stream")) return g_readback_side.load();
+    if (name && !strcmp(name, "depth_sort_msd_bits")) return g_depth_msd_bits.load();
     if (name && !strcmp(name, "depth_sort_local_threads")) return g_depth_local_threads.load();
     return -1;
 }

@@ -1088,17 +1088,28 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
 // visible key); flags: the frame-flag words (the digit parameters land there); wave_ranges: the per-wave key ranges of the per-Gaussian kernel; hist: ex4d_radix_hist_words(n) words; starts: 1 << DLS_MSD_BITS words.
 // key_bits (host bound on the visible keys): the bits below the digit must fit the LDS word next to the arrival index
 bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits) { return n <= (1u << 26) && key_bits - (EX4D_DLS_MSD_BITS - 1) + DLS_IDX_BITS <= 32; }
-hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
+// Width of the top digit (round 6): 9 bits -- 511 visible buckets of ~1.6 k Gaussians at 1.0 M, each finished by a 512-thread workgroup
+// (<= 8192 in LDS) -- up to 1.3 M Gaussians where the key bits under it fit the LDS word; 10 bits beyond (buckets twice as small: the
+// margin below the LDS capacity that 2 M Gaussians need).  Same-box A/B at 1.0 M (stage depth_sort, ms): 10 bits / 256 threads 0.0708,
+// 10 / 512 0.0768, 9 / 512 0.0632, 9 / 256 0.0744 (oversize buckets); config 2 (100 k) 0.0420 -> 0.0402: the partition's histogram is half as
+// large (its ~0.5 M scattered 4-byte stores are what that kernel costs), the bucket kernel runs 511 workgroups instead of 1023.
+int ex4d_depth_sort_msd_bits(uint32_t n, int key_bits)
+{
+    const int narrow = EX4D_DLS_MSD_BITS - 1;
+    return (n <= 1300000u && key_bits - (narrow - 1) + DLS_IDX_BITS <= 32) ? narrow : EX4D_DLS_MSD_BITS;
+}
+template <int MB>
+static hipError_t depth_sort_msd_launch(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
     uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
     uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads, uint32_t *watch)
 {
     if (n == 0) return hipSuccess;
-    constexpr int MB = EX4D_DLS_MSD_BITS, BINS = 1 << MB;
+    constexpr int BINS = 1 << MB;
     const uint32_t nb = rs_blocks_for(n);
     const bool small = rs_items_for(n) == RS_SMALL_ITEMS;
     uint32_t *dparams = flags + EX4D_FLAG_DPARAMS;
     const uint32_t nranges = (n + 255u) / 256u;          // one (max key, max ~key) pair per workgroup of the per-Gaussian kernel
-    if (local_threads != 256 && local_threads != 512) local_threads = n <= 1200000u ? 256 : 512;
+    if (local_threads != 256 && local_threads != 512) local_threads = (MB < EX4D_DLS_MSD_BITS || n > 1200000u) ? 512 : 256;      // (the 9-bit digit's buckets are twice as large)
     const uint32_t kcap = (uint32_t)local_threads * DLS_ITEMS;
     if (local_cap == 0 || local_cap > kcap) local_cap = kcap;
     if (small) {
@@ -1119,6 +1130,15 @@ hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_
         hipLaunchKernelGGL(depth_local_sort_kernel<512>, dim3(BINS), dim3(512), 0, stream, kb, vb, rb, ka, va, ra, starts, hist + (size_t)BINS * nb, (const uint32_t *)dparams, local_cap,
             local_incl, bucket_sums, T, ranges, watch);
     return hipGetLastError();
+}
+
+hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
+    uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
+    uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads, uint32_t *watch, int msd_bits)
+{
+    if (msd_bits == EX4D_DLS_MSD_BITS - 1)
+        return depth_sort_msd_launch<EX4D_DLS_MSD_BITS - 1>(ka, va, ra, kb, vb, rb, n, inv_key, flags, wave_ranges, hist, starts, local_cap, stream, local_incl, bucket_sums, T, ranges, local_threads, watch);
+    return depth_sort_msd_launch<EX4D_DLS_MSD_BITS>(ka, va, ra, kb, vb, rb, n, inv_key, flags, wave_ranges, hist, starts, local_cap, stream, local_incl, bucket_sums, T, ranges, local_threads, watch);
 }
 
 // ---- MSD tile sort (see ts_block_table_kernel).  Applies when the tile id needs 9..16 bits and the Gaussian ids fit under the low digit.
@@ -1187,11 +1207,11 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rec
 
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream,
-    const uint32_t *bucket_keys, const uint32_t *dparams, const uint32_t *bucket_sums, uint32_t *frame_total)
+    const uint32_t *bucket_keys, const uint32_t *dparams, const uint32_t *bucket_sums, uint32_t *frame_total, int msd_bits)
 {
     const int gx = (W + EX4D_TILE - 1) / EX4D_TILE, gy = (H + EX4D_TILE - 1) / EX4D_TILE;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, gy, order, sorted_offsets, block_sums,
-        sorted_rects, sorted_rects4, tile_keys, vals, cap, bucket_keys, dparams, bucket_sums, 1 << EX4D_DLS_MSD_BITS, frame_total);
+        sorted_rects, sorted_rects4, tile_keys, vals, cap, bucket_keys, dparams, bucket_sums, 1 << msd_bits, frame_total);
     return hipGetLastError();
 }
 

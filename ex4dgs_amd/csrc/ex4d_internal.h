@@ -18,6 +18,7 @@ static inline size_t ex4d_align_up(size_t x) { return (x + (EX4D_ALIGN - 1)) & ~
 //   float4 #2: depth (p_view.z), r, g, b          (SH colour or colors_precomp)
 //   float4 #3: dir3D.x, dir3D.y, dir3D.z, w       (per-Gaussian "flow" channel, zeros if absent; w = opacity*coef)
 #define EX4D_RECORD_FLOATS 16
+#define EX4D_DLS_MSD_BITS 10          // the widest top digit (array sizes); the sort runs with 9 or 10 bits: ex4d_depth_sort_msd_bits()
 #define EX4D_CHUNK_FLOW 0x80000000u       // per-chunk count pair, second word: some visible Gaussian of the chunk carries a non-zero dir3D
 #define EX4D_CHUNK_FILTERED 0x40000000u   // ... a Gaussian of the chunk failed the frustum test although `prefiltered` was set
 #define EX4D_DSUMS_MARK 0x44535553u     // frame flag [3]: the forward stored the SH direction sums (Ex4dParams.prepare_backward)
@@ -122,18 +123,20 @@ hipError_t ex4d_launch_scan_tiles(int P, const uint2 *rects, const uint32_t *rec
     uint32_t *block_sums, int T, uint2 *ranges, uint32_t *frame_total, hipStream_t stream);
 hipError_t ex4d_launch_duplicate(int P, int W, int H, const uint32_t *order, const uint32_t *sorted_offsets,
     const uint32_t *block_sums, const uint2 *sorted_rects, const uint32_t *sorted_rects4, uint32_t *tile_keys, uint32_t *vals, uint32_t cap, hipStream_t stream,
-    const uint32_t *bucket_keys = nullptr, const uint32_t *dparams = nullptr, const uint32_t *bucket_sums = nullptr, uint32_t *frame_total = nullptr);
+    const uint32_t *bucket_keys = nullptr, const uint32_t *dparams = nullptr, const uint32_t *bucket_sums = nullptr, uint32_t *frame_total = nullptr,
+    int msd_bits = EX4D_DLS_MSD_BITS);      // msd_bits: the digit width the MSD depth sort ran with (fused tile scan: bucket bases)
 
 // MSD-first depth sort (ex4d_binning.hip): one global partition on the top digit of (key - smallest visible key), every bucket finished in LDS.
 // Frame-flag words used by it (GeomState::total): [EX4D_FLAG_DPARAMS ..+3] = {kmin, shift, invisible key, 0} written by its range kernel
-#define EX4D_DLS_MSD_BITS 10
 #define EX4D_FLAG_DPARAMS 8
 #define EX4D_FLAG_WORDS 64
 bool ex4d_depth_sort_msd_applies(uint32_t n, int key_bits);
 hipError_t ex4d_depth_sort_msd(uint32_t *ka, uint32_t *va, uint32_t *ra, uint32_t *kb, uint32_t *vb, uint32_t *rb, uint32_t n, uint32_t inv_key,
     uint32_t *flags, const uint2 *wave_ranges, uint32_t *hist, uint32_t *starts, uint32_t local_cap, hipStream_t stream,
     uint32_t *local_incl, uint32_t *bucket_sums, int T, uint2 *ranges, int local_threads,       // local_incl / bucket_sums: the tile scan fused into the bucket kernel (nullptr = not)
-    uint32_t *watch = nullptr);                                                                  // watch: pinned host word set to 1 when a bucket exceeded the LDS capacity
+    uint32_t *watch = nullptr,                                                                   // watch: pinned host word set to 1 when a bucket exceeded the LDS capacity
+    int msd_bits = EX4D_DLS_MSD_BITS);                                                           // EX4D_DLS_MSD_BITS or one less: ex4d_depth_sort_msd_bits()
+int ex4d_depth_sort_msd_bits(uint32_t n, int key_bits);      // digit width by Gaussian count (9 bits up to 1.3 M, 10 beyond)
 // stable ranking by LDS atomics in the scatter kernels (ex4d_binning.hip): probed once per device, option "rank_lds_atomics"
 void ex4d_set_rank_lds(int v);
 int ex4d_get_rank_lds();

@@ -294,8 +294,12 @@ void ex4d_img_layout(int32_t W, int32_t H, Ex4dImgLayout *out);
  *                            0 = the copy sits on the caller's stream (rounds 1-5).  Same results; the call still returns only after the
  *                            count has arrived.
  *   "rows_probe"             developer: 1 = the row partition's scatter kernel records shader-clock cycles per phase (ex4d_debug_rows_prof).
+ *   "depth_sort_msd_bits"    0 (default) = the MSD depth sort cuts its top digit 9 bits wide up to 1.3 M Gaussians (511 visible buckets of
+ *                            ~1.6 k at 1.0 M, each finished by a 512-thread workgroup: <= 8192 in LDS) and 10 bits beyond; 9 / 10 = forced
+ *                            (tests, A/B runs; a forced 9 only where the key bits under the digit fit the bucket kernel's LDS word).
+ *                            Same order either way.
  *   "depth_sort_local_cap"   tests: largest bucket (0 = the kernel's capacity) the MSD depth sort finishes in LDS.
- *   "depth_sort_local_threads" 0 (default: by Gaussian count) / 256 / 512 = workgroup size of the MSD depth sort's bucket kernel.
+ *   "depth_sort_local_threads" 0 (default: 512 under the 9-bit digit and beyond 1.2 M Gaussians, else 256) / 256 / 512 = workgroup size of the MSD depth sort's bucket kernel.
  * Returns EX4D_OK / the value, or an error / -1. */
 int ex4d_set_option(const char *name, int value);
 int ex4d_get_option(const char *name);

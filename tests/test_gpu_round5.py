@@ -109,7 +109,8 @@ def test_depth_sort_auto_mode_leaves_the_msd_sort_after_an_oversize_bucket(hip_l
     assert _C.get_option("depth_sort_msd") == 3, "auto is the library default"
     spread, st = h.scene_inputs("cfg2", P=20000)
     spread = {k: v.cuda() for k, v in spread.items()}
-    wall, st_w = _squeezed(30000, 6.0, 6.4, 9000)            # 9000 Gaussians at one depth: one bucket of > 4096
+    # 14000 Gaussians at one depth: one bucket of > 8192 visible ones (round 6: up to 1.3 M Gaussians the bucket workgroups have 512 threads)
+    wall, st_w = _squeezed(30000, 6.0, 6.4, 14000)
     ref_spread = _frame(spread, st, depth_sort_msd=0)
     ref_wall = _frame(wall, st_w, depth_sort_msd=0)
     try:

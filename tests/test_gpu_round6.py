@@ -107,3 +107,38 @@ def test_read_back_on_a_side_stream_equals_the_in_stream_copy(hip_lib):
             other = _frame(ins, st, readback_side_stream=1)
         torch.cuda.current_stream().wait_stream(s)
         _same(other, ref, f"side-stream read-back from a non-default stream, {cfg} {P}")
+
+
+@pytest.mark.parametrize("cfg,P,t", SCENES + [("cfg3c", 30000, 0)])
+def test_msd_depth_sort_digit_width_9_and_10_bits_agree(hip_lib, cfg, P, t):
+    """The MSD depth sort cuts its top digit 9 bits wide up to 1.3 M Gaussians (511 visible buckets, 512-thread bucket workgroups) and
+    10 bits beyond (option "depth_sort_msd_bits" = 0: by count; 9 / 10: forced): same order, same lists as the LSD sort -- also behind
+    the pair sort with the fused tile scan (bucket bases over 512 or 1024 buckets) and with 256-thread bucket workgroups under the 9-bit
+    digit (twice the Gaussians per bucket: more of them take the through-memory path)."""
+    from ex4dgs_amd import _C
+    assert _C.get_option("depth_sort_msd_bits") == 0
+    ins, st = h.scene_inputs(cfg, P=P, t=t)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    ref = _frame(ins, st, depth_sort_msd=0)
+    for bits in (9, 10):
+        _same(_frame(ins, st, depth_sort_msd=2, depth_sort_msd_bits=bits), ref, f"{bits}-bit digit, row-segment sort")
+        _same(_frame(ins, st, depth_sort_msd=2, depth_sort_msd_bits=bits, tile_sort_rows=0), ref, f"{bits}-bit digit, pair sort with the fused tile scan")
+        _same(_frame(ins, st, depth_sort_msd=2, depth_sort_msd_bits=bits, depth_sort_local_threads=256, depth_sort_local_cap=64), ref, f"{bits}-bit digit, small buckets in LDS only")
+
+
+def test_msd_depth_sort_9_bit_digit_at_the_bench_size(hip_lib):
+    """1.0 M Gaussians (BASELINE config 3, what bench.py times): the 9-bit digit is what the count selects, no bucket leaves the LDS path
+    (the auto mode's watch word stays clear), the order equals the LSD sort's and a stable host sort."""
+    from ex4dgs_amd import _C
+    from tests.test_gpu_round5 import _host_depth_order
+    ins, st = h.scene_inputs("cfg3", t=137)
+    ins = {k: v.cuda() for k, v in ins.items()}
+    lsd = _frame(ins, st, depth_sort_msd=0)
+    _C.set_option("depth_sort_msd", 3)          # (resets the auto mode's counters)
+    auto = _frame(ins, st)
+    assert _C.get_option("depth_sort_trips") == 0 and _C.get_option("depth_sort_hold") == 0, "a bucket of the 9-bit digit exceeded the LDS capacity at 1.0 M"
+    _frame(ins, st)
+    assert _C.get_option("depth_sort_trips") == 0
+    assert torch.equal(lsd["depth_order"], _host_depth_order(lsd))
+    _same(auto, lsd, "auto (9-bit MSD) vs LSD at 1.0 M")
+    _same(_frame(ins, st, depth_sort_msd=2, depth_sort_msd_bits=10), lsd, "10-bit MSD vs LSD at 1.0 M")
