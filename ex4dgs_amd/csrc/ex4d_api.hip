@@ -163,7 +163,7 @@ struct Readback {
         if (have_ev && dev != device) { (void)hipEventDestroy(ev); (void)hipEventDestroy(ev_pre); (void)hipStreamDestroy(side); side = nullptr; have_ev = false; }
         if (!have_ev) {
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-            if (hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) { (void)hipEventDestroy(ev); return false; }
+            if (hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ev); return false; }
             if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipEventDestroy(ev); (void)hipEventDestroy(ev_pre); side = nullptr; return false; }
             have_ev = true; device = dev;
         }
