@@ -423,7 +423,7 @@ def compare_backward(ob, gb, fwd_o, atol=1e-5, k_eps=64.0, rel_tol=1e-5, conic=N
     rep["rows_total"] = int(P)
     # the allowances are for a handful of ill-conditioned rows, never for a systematic share of the Gaussians
     # (the suite's 361 recorded comparisons: no row needs the cancellation term, at most 4 of 1837 rows are beyond the shared-state bar
-    # end to end, none at the BASELINE sizes; the opt-in long sweep -- 300 more scenes, profiles/r05_long_sweep_report.json -- has the two
+    # end to end, none at the BASELINE sizes; the opt-in long sweep -- 300 more scenes, profiles/r05_long_sweep_report.json.gz -- has the two
     # scenes the term was introduced for: sharp Gaussians at kernel_size 0.05, 5 of 4139 and 7 of 2680 rows)
     assert rep["rows_needing_cancel_term"] <= max(8, 3e-3 * P), f"{rep['rows_needing_cancel_term']} of {P} rows need the cancellation allowance"
     # (end to end the same two scenes have 26 of 4139 and 20 of 2680 rows beyond the plain bar + cancellation term)

@@ -818,7 +818,7 @@ def test_randomised_parity_sweep(hip_lib, n, seed, dir_scale):
 def test_randomised_parity_sweep_long(hip_lib, seed, dir_scale):
     """The 300 extra random scenes of round 4 (seeds 11-13, 100 each) as a committed, opt-in test:
     `python -m pytest tests -m "gpu and long"`.  Its per-case numbers land in gpurun_out/parity_report.json like every other
-    comparison (round 5's run: profiles/r05_long_sweep_report.json)."""
+    comparison (round 5's run: profiles/r05_long_sweep_report.json.gz)."""
     from tests import fuzz_sweep
     fails = fuzz_sweep.run(100, seed, dir_scale, verbose=False)
     assert not fails, "\n".join(fails)
