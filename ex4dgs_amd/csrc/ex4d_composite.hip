@@ -908,6 +908,27 @@ __device__ __forceinline__ void row_scan_add2(float &a, float &b)
         "s_nop 0" : "+v"(a), "+v"(b));
 }
 
+// the two sum scans of a pixel pair into FRESH registers, ending in  q = c - inclusive scan(e):  the first step of each chain reads e in
+// place (bound_ctrl: lanes without a DPP source add zero), so neither e's register pair nor the result needs a copy
+__device__ __forceinline__ void row_scan_add2_from(float &qa, float &qb, float ea, float eb, float ca, float cb)
+{
+    asm("s_nop 1\n\t"                  /* (e may come straight out of the preceding VALU instruction: two wait states in front of a DPP read) */
+        "v_add_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_sub_f32 %0, %4, %0\n\t"
+        "v_sub_f32 %1, %5, %1"
+        : "=&v"(qa), "=&v"(qb) : "v"(ea), "v"(eb), "v"(ca), "v"(cb));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Round 6: the batch with TWO PIXELS PER LANE.  Lane (n, g) handles, in row-step r = 0..7, the pixels (row r, column g) and (row r, column
 // 4 + g) of the quadrant -- what bwd_batch does in steps 2 r and 2 r + 1 -- with every per-pixel quantity as a register pair (a, b): the
@@ -970,12 +991,14 @@ __device__ __forceinline__ void bwd_batch_pairs(BwdLdsT<BWD_RING> &L, int head, 
         const f32x2 T = (f32x2){ C.x, C.y } * (f32x2){ sa, sb };
         const f32x2 dcc = alpha * T;
         const f32x2 e = dcc * cgp;
-        float ea = e.x, eb = e.y;
-        row_scan_add2(ea, eb);
+        // (the scans write fresh registers -- their first step reads the pair's halves in place, lanes without a DPP source add zero --
+        // and end in the subtraction from the carry: no copy into or out of a register pair around the sixteen DPP steps)
+        float qa, qb;
+        row_scan_add2_from(qa, qb, e.x, e.y, C.z, C.w);
         c7 = __builtin_elementwise_fma((f32x2){ A.x, A.y }, dcc, c7);
         c8 = __builtin_elementwise_fma((f32x2){ A.z, A.w }, dcc, c8);
         c9 = __builtin_elementwise_fma((f32x2){ A2.x, A2.y }, dcc, c9);
-        const f32x2 Q = (f32x2){ C.z, C.w } - (f32x2){ ea, eb };
+        const f32x2 Q = { qa, qb };                                     // (bgT - E) carry - inclusive scan of e
         f32x2 dLa = __builtin_elementwise_fma(cgp, T, Q) * inv;
         if (EXTRA) {
             c10 = __builtin_elementwise_fma((f32x2){ F.x, F.y }, dcc, c10);
