@@ -362,7 +362,8 @@ def main():
     ap.add_argument("--views-per-rank", type=int, default=1, metavar="K",
                     help="training-core steps: every rank renders K views per optimizer step, accumulates their gradients locally and exchanges ONCE "
                          "(FrameTrainer(views_per_step=K): batch = N K views, wire time per view 1/K); a timed step stays one view")
-    ap.add_argument("--no-train-leg", action="store_true", help="N > 1 rasterizer steps: skip the secondary training-core leg (gradient exchange over RCCL) reported under multi_gpu")
+    ap.add_argument("--train-leg", action="store_true", help="N > 1 rasterizer steps: also time a short leg of the training-iteration core with its gradient exchange (reported under multi_gpu; "
+                                                             "the default N > 1 run prices the wire with a plain all-reduce of the exchange's byte count only)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="tuning / A-B runs: any library option of ex4d_set_option, e.g. --set depth_sort_msd=0 (the 3-pass LSD depth sort)")
     args = ap.parse_args()
 
@@ -394,10 +395,12 @@ def main():
     # N > 1 (round 6): the timed step is the SAME step as at N = 1 -- GaussianRasterizer forward + backward on resident frames, every rank on
     # its own views, no collective in the data path (the metric BASELINE.json names; `value` at N ranks compares like with like with N = 1).
     # The training-iteration core with the RCCL gradient exchange -- what BASELINE config 4 quotes -- is `--train-core` / `--config cfg4`
-    # (its N = 1 counterpart: `--train-core` at N = 1); at N > 1 the default run also times a short leg of it and reports it under
-    # `multi_gpu` (`--no-train-leg` skips that).
+    # (its N = 1 counterpart: `--train-core` at N = 1).  Beside the headline a default N > 1 run prices the WIRE alone under `multi_gpu`: a
+    # plain all-reduce of the replicated exchange's byte count (the one collective a barrier needs anyway -- nothing that could take the
+    # headline down with it); `--train-leg` adds a short leg of the training core itself with its exchange.
     train_mode = (args.config == "cfg4" or args.train_core) and not args.forward_only
-    train_leg = world > 1 and not train_mode and not args.forward_only and not args.no_train_leg
+    train_leg = world > 1 and not train_mode and not args.forward_only and args.train_leg
+    wire_probe = world > 1 and not train_mode and not args.forward_only
     if args.optimizer is None:
         # N >= 4: reduce-scatter + sharded RAdam (row-sharded keyframe windows) + all-gather -- half the bytes per link of the all-reduce
         # and 1/N of the optimizer's HBM stream per rank; N < 4: the replicated optimizer
@@ -600,6 +603,31 @@ def main():
                          "with the gradient exchange over the process group; the line's `value` is the rasterizer step above, without any collective")
         multi.update(tc["secondary"])
         del tc
+    if wire_probe:
+        # what the replicated gradient exchange would put on the wire per step (15 model-parameter gradients with the keyframe tensors as
+        # 4 / 2 touched time slices: ex4dgs_amd/dist.py), as ONE flat all-reduce: ring time of that byte count over this node's links
+        # (259.2 bytes per Gaussian at the 20 % dynamic share of configs 3 / 4: FrameTrainer.exchange_bytes_on_wire() reports 259 200 004 at 1.0 M)
+        nbytes = 4 * int(64.8 * P)
+        buf = torch.zeros(nbytes // 4, device=dev)
+        for _ in range(2):
+            torch.distributed.all_reduce(buf)
+        sync_all()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            torch.distributed.all_reduce(buf)
+        sync_all()
+        wire_ms = xdist.allreduce_max_scalar(1e3 * (time.perf_counter() - t0) / reps, device=dev)
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        probe = {"ranks_seen": int(round(float(ones.item()))), "world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                 "allreduce_probe_bytes": int(nbytes), "allreduce_probe_ms": round(wire_ms, 4),
+                 "allreduce_probe_busbw_GBps": round(2.0 * (world - 1) / world * nbytes / (wire_ms * 1e-3) / 1e9, 1),
+                 "allreduce_probe_note": "one flat all-reduce of the replicated gradient exchange's byte count, outside the timed region: the wire time a training step adds "
+                                         "when nothing overlaps it (DESIGN.md section 6); `--train-leg` / `--train-core` time the training core itself",
+                 "share_device": bool(args.share_device)}
+        del buf
+        multi = dict(probe, **(multi or {}))
 
     ms_per_step = xdist.allreduce_max_scalar(ms_wall, device=dev)
 

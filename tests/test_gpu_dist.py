@@ -296,7 +296,7 @@ def test_bench_spawns_its_ranks_itself(hip_lib, config):
     """`bench.py --gpus 2` without torchrun: the script starts both ranks (sharing the box's GPU over gloo), rank 0 prints ONE JSON
     line whose n_gpus is what was asked for, the collective carries the 15 model-parameter gradients."""
     cmd = [sys.executable, os.path.join(h.ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--config", config,
-           "--points", "20000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+           "--points", "20000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"] + (["--train-leg"] if config == "cfg3" else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -311,7 +311,8 @@ def test_bench_spawns_its_ranks_itself(hip_lib, config):
         # round 6: the default N > 1 step is the N = 1 step (rasterizer forward + backward, every rank its own views, no collective) --
         # the training-iteration core with the exchange is the secondary leg under multi_gpu
         assert "no collective" in d["config"]["parallelism"] and "GaussianRasterizer forward + backward" in d["config"]["step"]
-        assert d["multi_gpu"]["train_core_ms_per_step"] > 0 and "gradient exchange" in d["multi_gpu"]["train_core_step"]
+        assert d["multi_gpu"]["allreduce_probe_ms"] > 0 and d["multi_gpu"]["allreduce_probe_bytes"] == 4 * int(64.8 * 20000)      # the default wire probe
+        assert d["multi_gpu"]["train_core_ms_per_step"] > 0 and "gradient exchange" in d["multi_gpu"]["train_core_step"]                 # --train-leg
         assert d["roofline"] is not None and d["roofline"]["kernel"] in d["roofline"]["stage_ms"]
     else:
         assert "gradient exchange" in d["config"]["step"]          # BASELINE config 4 is quoted on the training core
