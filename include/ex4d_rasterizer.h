@@ -214,7 +214,9 @@ typedef struct Ex4dGeomLayout {
     size_t sorted_offsets;  /* uint32[P]           INTERNAL SCRATCH, not an interface: written only by the pair-sort path ("tile_sort_rows" = 0; its meaning
                                                    depends on the depth sort that ran); the default row-segment tile sort of round 6 needs no instance offsets */
     size_t rects;           /* uint2[P]            tile rect (getRect, auxiliary.h:46-56): .x = x0 | y0 << 16, .y = w | h << 16;
-                                                   w * h == tiles_touched; defined for visible Gaussians */
+                                                   w * h == tiles_touched; defined for visible Gaussians.  Written for images of more than
+                                                   255 x 255 tiles and with option "geom_debug_arrays" = 1; smaller images carry their rects in
+                                                   an internal packed 4-byte form only (round 6) */
     size_t total;
 } Ex4dGeomLayout;
 typedef struct Ex4dBinningLayout {
