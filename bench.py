@@ -358,7 +358,8 @@ def main():
     ap.add_argument("--async-frames", action="store_true", help="N = 1 rasterizer steps with the ASYNCHRONOUS forward (no instance-count read-back: Ex4dParams.instance_capacity)")
     ap.add_argument("--graph", action="store_true", help="N = 1: forward + backward (asynchronous forward, raw C-ABI mirror calls) captured into ONE hipGraph and replayed per step")
     ap.add_argument("--bwd-variant", type=int, default=None, help="tuning: compositing-backward kernel (include/ex4d_rasterizer.h: ex4d_set_option)")
-    ap.add_argument("--sync-forward", action="store_true", help="training-core steps: the trainer's rasterizer forward with the blocking instance-count read-back (default: asynchronous where the trainer can re-run a frame itself)")
+    ap.add_argument("--sync-forward", action="store_true", help="(the default since round 6; kept for old command lines) training-core steps: the trainer's rasterizer forward with the instance-count read-back")
+    ap.add_argument("--async-forward", action="store_true", help="training-core steps on one rank without an exchange: the trainer's asynchronous rasterizer forward (no read-back, a frame that overflows its capacity is re-run)")
     ap.add_argument("--views-per-rank", type=int, default=1, metavar="K",
                     help="training-core steps: every rank renders K views per optimizer step, accumulates their gradients locally and exchanges ONCE "
                          "(FrameTrainer(views_per_step=K): batch = N K views, wire time per view 1/K); a timed step stays one view")
@@ -435,7 +436,7 @@ def main():
         kv = max(1, args.views_per_rank)
         tr = FrameTrainer(model, exchange=exchange, optimizer=(args.optimizer != "none"), sliced=(False if (args.dense_keyframe_grads or kv > 1) else None),
                           lrs={n: 1e-7 for n in model.PARAM_NAMES},       # tiny learning rates: the synthetic scene stays put
-                          async_forward=(False if (args.sync_forward or kv > 1) else None), views_per_step=kv)
+                          async_forward=(True if (args.async_forward and kv == 1 and exchange == "none") else False), views_per_step=kv)
 
         def step(i):
             return tr.step(cam, bg, my_stamps[i % len(my_stamps)], upstream, near=cfg.min_depth, far=cfg.max_depth)["render"]

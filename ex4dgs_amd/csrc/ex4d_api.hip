@@ -438,7 +438,8 @@ static int forward_impl(
         const bool count_later = fused_scan || (rows_sort && msd_depth);
         if (!count_later) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         R = (uint32_t)prm->instance_capacity;
-        segment_sum = R;
+        segment_sum = 0;          // (not known on the host: the row partition picks its segment stage from the capacity -- round 6: passing the capacity
+                                  // here chose the large stage for every frame, 32 us instead of 25 at config 3)
         n_dev = g.total;
         has_flow = prm->assume_no_flow == 0;
     } else {

@@ -132,16 +132,13 @@ __global__ __launch_bounds__(ROW_THREADS) void rows_seg_hist_kernel(uint32_t P, 
         hist[(size_t)row * nblocks + blk] = ds[row];
         hist[(size_t)(NR + row) * nblocks + blk] = di[row];
     }
-    if (frame_total) {
-        // device-side instance count of the asynchronous forward (one fire-and-forget atomic per block)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) inst += __shfl_xor(inst, o, 64);
-        if (lane == 0 && inst != 0u) atomicAdd(frame_total, inst);
-    }
+    (void)inst; (void)frame_total;      // (the device-side instance count of the asynchronous forward is summed by the row scan below: one atomic per
+                                        // tile row instead of one per block -- 3907 atomics on ONE word cost this kernel 25 us at 1.0 M Gaussians)
 }
 
 // one workgroup per histogram row: exclusive scan of its `len` per-block counts, row total to hist[nrows * len + row]
-__global__ __launch_bounds__(256) void rows_scan_kernel(uint32_t len, uint32_t *__restrict__ hist, uint32_t nrows)
+// frame_total (optional): += the totals of the rows first_total_row .. nrows - 1 (the instance rows: the frame's instance count)
+__global__ __launch_bounds__(256) void rows_scan_kernel(uint32_t len, uint32_t *__restrict__ hist, uint32_t nrows, uint32_t *__restrict__ frame_total, uint32_t first_total_row)
 {
     __shared__ uint32_t wave_sums[4];
     __shared__ uint32_t carry_s;
@@ -180,7 +177,10 @@ __global__ __launch_bounds__(256) void rows_scan_kernel(uint32_t len, uint32_t *
         if (threadIdx.x == 255) carry_s = woff + run;
         __syncthreads();
     }
-    if (threadIdx.x == 0) hist[(size_t)nrows * len + blockIdx.x] = carry_s;
+    if (threadIdx.x == 0) {
+        hist[(size_t)nrows * len + blockIdx.x] = carry_s;
+        if (frame_total && blockIdx.x >= first_total_row && carry_s != 0u) atomicAdd(frame_total, carry_s);
+    }
 }
 
 // ---------------------------------------------------------------- placement by coverage masks
@@ -417,7 +417,7 @@ hipError_t ex4d_tile_sort_rows(int P, int gx, int gy, const uint32_t *order, con
     uint32_t *totA = histA + (size_t)2 * gy * nbA;
     const int bx = bits_for(gx);
     hipLaunchKernelGGL(rows_seg_hist_kernel, dim3((nbA + 3) / 4), dim3(ROW_THREADS), 0, stream, (uint32_t)P, gy, r4, r8, histA, nbA, frame_total);
-    hipLaunchKernelGGL(rows_scan_kernel, dim3(2 * gy), dim3(256), 0, stream, nbA, histA, (uint32_t)(2 * gy));
+    hipLaunchKernelGGL(rows_scan_kernel, dim3(2 * gy), dim3(256), 0, stream, nbA, histA, (uint32_t)(2 * gy), frame_total, (uint32_t)gy);
     // rects more than 3.5 rows high on average (config 5: 6): the larger segment stage
     const bool big = S == 0 ? (uint64_t)cap > 20ull * (uint32_t)P : 2ull * S > 7ull * (uint32_t)P;
 #define ROWS_A(NRP, CAP) hipLaunchKernelGGL((rows_seg_scatter_kernel<NRP, CAP>), dim3(nbA), dim3(ROW_THREADS), 0, stream, (uint32_t)P, gy, order, r4, r8, (const uint32_t *)histA, nbA, \

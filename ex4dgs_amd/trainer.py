@@ -59,7 +59,8 @@ class FrameTrainer:
         at 8 ranks).
         force_collectives: issue the exchange's collectives even in a process group of one rank (dist.py: the RCCL-native branches
         run and are checked on a one-GPU box).
-        async_forward (default: ON for a single rank with exchange "none", off otherwise): the rasterizer forward runs asynchronously (no instance-count read-back:
+        async_forward (default: off since round 6 -- with the synchronous forward's read-back off the caller's stream the two are equal at 1.0 M Gaussians
+        and the synchronous one is 8 % faster at 100 k (bench.py --train-core [--sync-forward]); round 5: on for a single rank with exchange "none"): the rasterizer forward runs asynchronously (no instance-count read-back:
         include/ex4d_rasterizer.h Ex4dParams.instance_capacity, under an AsyncFrames policy of the trainer's own); the frame's status is looked at once, right before its gradients are applied, and a frame that overflowed its
         capacity is RE-RUN first -- the parameters are those of the synchronous path.  `replays` counts such re-runs.
         views_per_step = k > 1 (round 6): a rank renders k views per optimizer step; their gradients are added up locally (persistent
@@ -131,8 +132,9 @@ class FrameTrainer:
                 self.v = [torch.zeros_like(p) for p in self.params]
                 self.steps = 0
         self.optimizer = bool(optimizer) or self.mode == "sharded"
-        # the non-blocking forward is what callers of this class get wherever the class can recover from an overflow by itself
-        self.async_forward = (self.mode == "none") if async_forward is None else bool(async_forward)
+        # (round 5 made the non-blocking forward the default wherever the class can recover from an overflow by itself; round 6 measured the
+        # synchronous forward -- its read-back off the caller's stream now -- equal or faster, and it needs no capacity policy: opt-in again)
+        self.async_forward = False if async_forward is None else bool(async_forward)
         self.replays = 0
         self._frame = self._last_args = None
         if self.async_forward:

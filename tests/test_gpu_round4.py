@@ -232,8 +232,8 @@ def test_frame_trainer_asynchronous_forward_replays_and_matches_the_synchronous_
     up = lambda out: ([l1_ssim_loss(out["render"], gt, 0.2)[0]], [None])
     try:
         fa = FrameTrainer(ma, optimizer=True, lrs=lrs, async_forward=False)
-        fb = FrameTrainer(mb, optimizer=True, lrs=lrs)              # round 5: the asynchronous forward is the DEFAULT of a single-rank trainer
-        assert fb.async_forward and not fa.async_forward
+        fb = FrameTrainer(mb, optimizer=True, lrs=lrs, async_forward=True)
+        assert fb.async_forward and not fa.async_forward and not FrameTrainer(ma, optimizer=False).async_forward      # (round 6: opt-in, the default is synchronous)
         with torch.no_grad():
             for m in (ma, mb):
                 m._scaling -= 3.0; m._scaling_motion -= 3.0
