@@ -85,38 +85,38 @@ def _fwd_bwd(cfg, P=None, t=0, sh_degree=3, grad_acc_zero=False, mutate=None, su
     return o, g, ob, gb, rep
 
 
-def test_cfg1_forward_backward(hip_lib):
+def test_cfg1_forward_backward(hip_lib_both):
     _fwd_bwd("cfg1")
 
 
 @pytest.mark.parametrize("cfg,P,t", [("cfg1", None, 0), ("cfg2", 20000, 0), ("cfg3", 12000, 137), ("cfg5", 6000, 0)])
-def test_zero_dir3D_integer_pixels_fast_path(hip_lib, cfg, P, t):
+def test_zero_dir3D_integer_pixels_fast_path(hip_lib_both, cfg, P, t):
     """What render() and bench.py actually pass: dir3D = 0 (the gradient trap) and a zero subpixel_offset -- the forward kernel's
     flow-free variant with the per-row exponent table, which no other parity case reaches (they carry random dir3D)."""
     o, g, ob, gb, rep = _fwd_bwd(cfg, P=P, t=t, dir_scale=0.0)
     assert float(np.abs(o["flow"]).max()) == 0.0 and float(g["flow"].abs().max()) == 0.0
 
 
-def test_cfg1_training_grads(hip_lib):
+def test_cfg1_training_grads(hip_lib_both):
     _fwd_bwd("cfg1", grad_acc_zero=True, seed=9)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
-def test_sh_degrees(hip_lib, deg):
+def test_sh_degrees(hip_lib_both, deg):
     _fwd_bwd("cfg1", sh_degree=deg)
 
 
-def test_static_20k_full_resolution(hip_lib):
+def test_static_20k_full_resolution(hip_lib_both):
     o, *_ = _fwd_bwd("cfg2", P=20000)
     assert o["W"] == 1352 and o["H"] == 1014          # 1352 = 84*16+8, 1014 = 63*16+6: partial edge tiles
 
 
 @pytest.mark.parametrize("t", [0, 137, 299])
-def test_dynamic_keyframed_scene(hip_lib, t):
+def test_dynamic_keyframed_scene(hip_lib_both, t):
     _fwd_bwd("cfg3", P=12000, t=t)
 
 
-def test_deep_overlap_offcentre_projection(hip_lib):
+def test_deep_overlap_offcentre_projection(hip_lib_both):
     o, *_ = _fwd_bwd("cfg5", P=6000)
     assert o["num_rendered"] / max(1, (o["radii"] > 0).sum()) > 10
 
