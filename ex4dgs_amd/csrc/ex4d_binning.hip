@@ -277,11 +277,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     __shared__ uint32_t local_start[BINS];        // first block-local slot of each digit
     __shared__ uint32_t global_base[BINS];        // global position of this block's first item of each digit
     __shared__ uint32_t scan_tmp[8];
-    __shared__ uint2 stage[RS_THREADS * ITEMS];             // (key, value) in block-local sorted order
+    // (key, value) in block-local sorted order; MODE 2 (pass B of the tile sort) sorts packed words and writes ids: ONE word per item -- 16 KB
+    // instead of 32, 22.5 KB of LDS per workgroup instead of 38.9: seven workgroups per CU instead of four (round 6)
+    constexpr int STAGE_WORDS = (MODE == 2 ? 1 : 2) * RS_THREADS * ITEMS;
+    __shared__ __attribute__((aligned(16))) uint32_t stage_w[STAGE_WORDS];
+    uint2 *const stage = reinterpret_cast<uint2 *>(stage_w);
     __shared__ uint32_t stage_r[MODE == 3 ? RS_THREADS * ITEMS : 1];      // MODE 3: the third word of the triple
     // (MODE 3 at 16 items per thread -- more than 2 M Gaussians -- is the largest: 16 K of counters + 8 K + 32 K + 16 K = 72 KB, more than
     // the 64 KB of gfx90a-class LDS: this library is gfx950 only, 160 KB per CU)
-    static_assert(sizeof(uint32_t) * (4 * BINS + 2 * BINS + 8) + sizeof(uint2) * RS_THREADS * ITEMS + sizeof(uint32_t) * (MODE == 3 ? RS_THREADS * ITEMS : 1) <= 80 * 1024,
+    static_assert(sizeof(TsLocateLds) <= sizeof(uint32_t) * STAGE_WORDS, "the block table's scratch lives in the staging area");
+    static_assert(sizeof(uint32_t) * (4 * BINS + 2 * BINS + 8) + sizeof(uint32_t) * STAGE_WORDS + sizeof(uint32_t) * (MODE == 3 ? RS_THREADS * ITEMS : 1) <= 80 * 1024,
                   "rs_scatter_kernel: static LDS beyond 80 KB (two workgroups per CU)");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (NBITS > 0) nbits = NBITS;
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     uint32_t block_first = blockIdx.x * CHUNK, block_end = n, bucket = 0;
     TsBlock tb = { 0u, 0u, 0u, 0u, 0u, 0u };
     if (MODE == 2) {
-        TsLocateLds &loc = *reinterpret_cast<TsLocateLds *>(stage);          // the staging area is not in use yet (no extra LDS)
+        TsLocateLds &loc = *reinterpret_cast<TsLocateLds *>(stage_w);        // the staging area is not in use yet (no extra LDS)
         tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);
         __syncthreads();                            // every thread has its copy before the area is reused
         if (tb.count == 0) return;                  // past the last block (uniform: the whole workgroup)
@@ -426,7 +431,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         const uint32_t i = base + it * 64 + lane;
         if (i < block_end) {
             const uint32_t d = digit_of(key[it]);
-            stage[wave_cnt[wave][d] + pos[it]] = make_uint2(key[it], val[it]);
+            if constexpr (MODE == 2) stage_w[wave_cnt[wave][d] + pos[it]] = key[it];
+            else stage[wave_cnt[wave][d] + pos[it]] = make_uint2(key[it], val[it]);
             if constexpr (MODE == 3) stage_r[wave_cnt[wave][d] + pos[it]] = rct[it];
         }
     }
@@ -434,7 +440,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     const uint32_t count = (block_end - block_first) < CHUNK ? (block_end - block_first) : CHUNK;
 #pragma unroll 4
     for (uint32_t p = tid; p < count; p += RS_THREADS) {
-        const uint2 kv = stage[p];
+        uint2 kv;
+        if constexpr (MODE == 2) kv = make_uint2(stage_w[p], 0u); else kv = stage[p];
         const uint32_t d = digit_of(kv.x);
         const uint32_t dst = global_base[d] + (p - local_start[d]);
         if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; }
