@@ -228,7 +228,14 @@ __global__ __launch_bounds__(RS_THREADS) void dls_histogram_kernel(const uint32_
 // Every workgroup derives its own block from the <= 256 bucket totals of pass A (two scans + a 8-step search: cheaper than a
 // one-workgroup table kernel and its launch in the middle of the sort):
 //   fb[h] = first block of bucket h (fb[256] = number of blocks), st[h] = first output position of bucket h
-struct TsBlock { uint32_t start, count, bucket, fb_first, fb_next, bucket_start; };
+typedef Ex4dTsBlock TsBlock;        // { start, count, bucket, fb_first, fb_next, bucket_start }
+// the block's record from the frame's table (two 16-byte-aligned... plain dword loads, L2-resident: 24 bytes)
+__device__ __forceinline__ TsBlock ts_block_from_table(const Ex4dTsBlock *__restrict__ table, uint32_t b)
+{
+    const uint2 *p = reinterpret_cast<const uint2 *>(table + b);
+    const uint2 a = p[0], c = p[1], e = p[2];
+    return { a.x, a.y, c.x, c.y, e.x, e.y };
+}
 struct TsLocateLds { uint32_t cnt[257], fb[257], st[257], wave_sums[8]; };
 __device__ __forceinline__ TsBlock ts_locate_block(const uint32_t *__restrict__ totals, int nbuckets, uint32_t b, TsLocateLds &L)
 {
@@ -266,7 +273,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     uint32_t n, int shift, int nbits, uint32_t nblocks, const uint32_t *__restrict__ hist,
     int low_bits, const uint32_t *__restrict__ bucket_totals, int nbuckets, uint2 *__restrict__ ranges, const uint32_t *__restrict__ n_dev,
     const uint32_t *__restrict__ rects_in = nullptr, uint32_t *__restrict__ rects_out = nullptr, uint32_t *__restrict__ bucket_starts = nullptr,
-    const uint32_t *__restrict__ dparams = nullptr, uint32_t range_stride = 0, uint32_t out_cap = 0xFFFFFFFFu)
+    const uint32_t *__restrict__ dparams = nullptr, uint32_t range_stride = 0, uint32_t out_cap = 0xFFFFFFFFu,
+    const Ex4dTsBlock *__restrict__ block_table = nullptr)
 {
     // MODE 2 only: range_stride = tile ids per bucket (0: 1 << nbits, the binary split of the pair sort; the row-segment sort of round 6
     // has bucket = tile row, digit = tile column: the image's tiles per row); out_cap = capacity of the packed / output arrays (an
@@ -306,9 +314,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     uint32_t block_first = blockIdx.x * CHUNK, block_end = n, bucket = 0;
     TsBlock tb = { 0u, 0u, 0u, 0u, 0u, 0u };
     if (MODE == 2) {
-        TsLocateLds &loc = *reinterpret_cast<TsLocateLds *>(stage_w);        // the staging area is not in use yet (no extra LDS)
-        tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);
-        __syncthreads();                            // every thread has its copy before the area is reused
+        if (block_table) tb = ts_block_from_table(block_table, blockIdx.x);
+        else {
+            TsLocateLds &loc = *reinterpret_cast<TsLocateLds *>(stage_w);        // the staging area is not in use yet (no extra LDS)
+            tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);
+            __syncthreads();                            // every thread has its copy before the area is reused
+        }
         if (tb.count == 0) return;                  // past the last block (uniform: the whole workgroup)
         block_first = tb.start; block_end = tb.start + tb.count; bucket = tb.bucket;
         if (block_first >= out_cap) return;         // (uniform)
@@ -465,12 +476,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 // bucket = stable by the whole tile id.  HBM traffic per instance: 8 written by the duplication + (4 + 8 + 4) + (4 + 4 + 4) = 36 bytes
 // instead of 8 + 2 x (4 + 8 + 8) + 4 = 52.
 __global__ __launch_bounds__(RS_THREADS) void ts_histogram_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ bucket_totals,
-    int nbuckets, int shift, uint32_t nblocks, uint32_t *__restrict__ hist, uint32_t cap = 0xFFFFFFFFu)
+    int nbuckets, int shift, uint32_t nblocks, uint32_t *__restrict__ hist, uint32_t cap = 0xFFFFFFFFu, const Ex4dTsBlock *__restrict__ block_table = nullptr)
 {
     __shared__ uint32_t h[256];
     __shared__ TsLocateLds loc;
     h[threadIdx.x] = 0;
-    const TsBlock tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);      // (contains the barriers that publish h = 0)
+    TsBlock tb;
+    if (block_table) { tb = ts_block_from_table(block_table, blockIdx.x); __syncthreads(); }      // (the barrier publishes h = 0)
+    else tb = ts_locate_block(bucket_totals, nbuckets, blockIdx.x, loc);      // (contains the barriers that publish h = 0)
     if (tb.count != 0) {
         uint32_t k[RS_ITEMS];
 #pragma unroll
@@ -1188,17 +1201,19 @@ hipError_t ex4d_tile_sort_msd(const uint32_t *keys, const uint32_t *vals, uint32
 // Pass B of the MSD tile sort on its own (round 6: behind the row-segment partition of ex4d_rowsort.hip): `packed` holds, bucket after
 // bucket (bucket = tile row, `totals[nbuckets]` instances each, in depth order inside a bucket), one word per instance,
 // column << (32 - low_bits) | Gaussian id.  Writes point_list, the tile ranges (tile = bucket * stride + column) and, on request, the tile ids.
-size_t ex4d_tile_sort_pass_b_hist_words(uint32_t R) { return (size_t)256 * (rs_num_blocks(R) + 258); }
+// [256][blocks] + totals, then the block table of the row-segment sort (6 words per block, 8-byte aligned: the word count in front of it is even)
+size_t ex4d_tile_sort_pass_b_hist_words(uint32_t R) { return (size_t)256 * (rs_num_blocks(R) + 258) + (size_t)6 * (rs_num_blocks(R) + 258); }
+size_t ex4d_tile_sort_pass_b_table_offset(uint32_t R) { return (size_t)256 * (rs_num_blocks(R) + 258); }
 hipError_t ex4d_tile_sort_pass_b(const uint32_t *packed, const uint32_t *totals, int nbuckets, int low_bits, uint32_t stride, uint32_t R, uint32_t cap,
-    uint32_t *histB, uint32_t *point_list, uint32_t *tile_ids_out, uint2 *ranges, hipStream_t stream)
+    uint32_t *histB, uint32_t *point_list, uint32_t *tile_ids_out, uint2 *ranges, hipStream_t stream, const Ex4dTsBlock *block_table)
 {
     if (R == 0) return hipSuccess;
-    const uint32_t nbB = rs_num_blocks(R) + (uint32_t)nbuckets + 1u;
-    hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, totals, nbuckets, 32 - low_bits, nbB, histB, cap);
+    const uint32_t nbB = ex4d_tile_sort_pass_b_blocks(R, nbuckets);
+    hipLaunchKernelGGL(ts_histogram_kernel, dim3(nbB), dim3(RS_THREADS), 0, stream, packed, totals, nbuckets, 32 - low_bits, nbB, histB, cap, block_table);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << low_bits), dim3(256), 0, stream, nbB, histB, 256u);
 #define TS_SCATTER_B(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 2, NB>), dim3(nbB), dim3(RS_THREADS), 0, stream, packed, (const uint32_t *)nullptr, tile_ids_out, point_list, \
         R, 32 - low_bits, low_bits, nbB, histB, low_bits, totals, nbuckets, ranges, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, \
-        (const uint32_t *)nullptr, stride, cap)
+        (const uint32_t *)nullptr, stride, cap, block_table)
     if (low_bits == 7) TS_SCATTER_B(7); else if (low_bits == 8) TS_SCATTER_B(8); else TS_SCATTER_B(0);
 #undef TS_SCATTER_B
     return hipGetLastError();

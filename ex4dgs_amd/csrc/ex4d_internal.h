@@ -73,6 +73,11 @@ struct ImgState {
 #define SCAN_CHUNK 2048                   // items per block in the tiles_touched scan
 
 static inline uint32_t rs_num_blocks(uint32_t n) { return (n + RS_CHUNK - 1) / RS_CHUNK; }
+// Pass B of the tile sort cuts every bucket (tile row) into blocks of <= RS_CHUNK words, no block straddling two buckets.  One record per block;
+// round 6: written ONCE per frame by workgroup 0 of the row partition's scatter kernel (ex4d_rowsort.hip) instead of re-derived by every
+// workgroup of both pass-B kernels from the bucket totals (two scans, three barriers and a search each).
+struct Ex4dTsBlock { uint32_t start, count, bucket, fb_first, fb_next, bucket_start; };
+static inline uint32_t ex4d_tile_sort_pass_b_blocks(uint32_t R, int nbuckets) { return rs_num_blocks(R) + (uint32_t)nbuckets + 1u; }      // upper bound = the pass-B grids
 
 // SH coefficients as the model stores them (include/ex4d_rasterizer.h: Ex4dSplitSH); all pointers null = one [P,M,3] tensor
 struct ShSplit { const float *dc[2]; const float *rest[2]; int n_static; };

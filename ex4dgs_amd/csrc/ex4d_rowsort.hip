@@ -236,7 +236,7 @@ __device__ unsigned long long g_rows_prof[8];      // developer profile (option 
 template <int NRP, int CAP>
 __global__ __launch_bounds__(ROW_THREADS) void rows_seg_scatter_kernel(uint32_t P, int NR, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ r4, const uint2 *__restrict__ r8, const uint32_t *__restrict__ hist, uint32_t nblocks,
-    uint32_t *__restrict__ words, uint32_t cap, int shift, int probe)
+    uint32_t *__restrict__ words, uint32_t cap, int shift, int probe, Ex4dTsBlock *__restrict__ block_table, uint32_t table_blocks)
 {
     constexpr int PAD = NRP + 4;
     __shared__ __attribute__((aligned(16))) uint32_t wave_cnt[4][PAD];
@@ -275,6 +275,19 @@ __global__ __launch_bounds__(ROW_THREADS) void rows_seg_scatter_kernel(uint32_t 
         for (int w = 0; w < 4; w++) { c[w] = tid < NR ? wave_cnt[w][tid] : 0u; tot += c[w]; }
         uint32_t total, itotal, ls, is;
         block_excl_scan2(tot, it, tmp, ls, is, total, itotal);
+        if (block_table && blockIdx.x == 0) {              // (workgroup-uniform)
+            // Pass B's block table (Ex4dTsBlock, ex4d_internal.h): thread t = tile row t knows the row's instances (`it`) and its first output
+            // position (`is`); an exclusive scan of the rows' block counts gives the row's first block.  Records behind the last block: empty.
+            const uint32_t nblk = tid < NR ? (it + RS_CHUNK - 1u) / RS_CHUNK : 0u;
+            uint32_t fb_total;
+            const uint32_t fb = block_excl_scan(nblk, tmp, fb_total);
+            for (uint32_t j = 0; j < nblk; j++) {
+                const uint32_t within = j * RS_CHUNK;
+                if (fb + j < table_blocks)            // (an asynchronous frame beyond its capacity: invalid anyway, but nothing is written out of bounds)
+                    block_table[fb + j] = { is + within, (it - within) < RS_CHUNK ? (it - within) : (uint32_t)RS_CHUNK, (uint32_t)tid, fb, fb + nblk, is };
+            }
+            for (uint32_t e = fb_total + tid; e < table_blocks; e += ROW_THREADS) block_table[e] = { 0u, 0u, 0u, 0u, 0u, 0u };
+        }
         if (tid < NRP) { local_start[tid] = ls; inst_base[tid] = is + ipre; }      // (rows >= NR: the block's total -- the end of the last row's run)
         if (tid < NR) { wave_cnt[0][tid] = ls; wave_cnt[1][tid] = ls + c[0]; wave_cnt[2][tid] = ls + c[0] + c[1]; wave_cnt[3][tid] = ls + c[0] + c[1] + c[2]; }
         if (tid == 0) s_total = total;
@@ -390,8 +403,9 @@ static inline int bits_for(int n) { int b = 1; while ((1 << b) < n) b++; return 
 }  // namespace
 
 hipError_t ex4d_tile_sort_pass_b(const uint32_t *packed, const uint32_t *totals, int nbuckets, int low_bits, uint32_t stride, uint32_t R, uint32_t cap,
-    uint32_t *histB, uint32_t *point_list, uint32_t *tile_ids_out, uint2 *ranges, hipStream_t stream);
+    uint32_t *histB, uint32_t *point_list, uint32_t *tile_ids_out, uint2 *ranges, hipStream_t stream, const Ex4dTsBlock *block_table);
 size_t ex4d_tile_sort_pass_b_hist_words(uint32_t R);
+size_t ex4d_tile_sort_pass_b_table_offset(uint32_t R);
 
 static int g_rows_probe = 0;
 void ex4d_set_rows_probe(int v) { g_rows_probe = v; }
@@ -420,13 +434,16 @@ hipError_t ex4d_tile_sort_rows(int P, int gx, int gy, const uint32_t *order, con
     hipLaunchKernelGGL(rows_scan_kernel, dim3(2 * gy), dim3(256), 0, stream, nbA, histA, (uint32_t)(2 * gy), frame_total, (uint32_t)gy);
     // rects more than 3.5 rows high on average (config 5: 6): the larger segment stage
     const bool big = S == 0 ? (uint64_t)cap > 20ull * (uint32_t)P : 2ull * S > 7ull * (uint32_t)P;
+    // pass B's block table behind its histogram (same buffer): written by workgroup 0 of the scatter kernel below
+    Ex4dTsBlock *block_table = reinterpret_cast<Ex4dTsBlock *>(histB + ex4d_tile_sort_pass_b_table_offset(cap));
+    const uint32_t table_blocks = ex4d_tile_sort_pass_b_blocks(cap, gy);
 #define ROWS_A(NRP, CAP) hipLaunchKernelGGL((rows_seg_scatter_kernel<NRP, CAP>), dim3(nbA), dim3(ROW_THREADS), 0, stream, (uint32_t)P, gy, order, r4, r8, (const uint32_t *)histA, nbA, \
-        words, cap, 32 - bx, g_rows_probe)
+        words, cap, 32 - bx, g_rows_probe, block_table, table_blocks)
     if (gy <= 64) { if (big) ROWS_A(64, 2048); else ROWS_A(64, 1024); }
     else if (gy <= 128) { if (big) ROWS_A(128, 2048); else ROWS_A(128, 1024); }
     else { if (big) ROWS_A(256, 2048); else ROWS_A(256, 1024); }
 #undef ROWS_A
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return ex4d_tile_sort_pass_b(words, totA + gy, gy, bx, (uint32_t)gx, cap, cap, histB, point_list, tile_ids_out, ranges, stream);
+    return ex4d_tile_sort_pass_b(words, totA + gy, gy, bx, (uint32_t)gx, cap, cap, histB, point_list, tile_ids_out, ranges, stream, block_table);
 }
