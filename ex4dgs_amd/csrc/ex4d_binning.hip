@@ -327,6 +327,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     }
     const uint32_t base = block_first + wave * (CHUNK / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
+    // (round 6) the histogram words this thread's digits need behind the ranking -- the block's own prefix, the digit totals / the bucket's
+    // span of the row-scanned histogram -- are requested HERE, in front of the items: their round trip (scattered 4-byte loads) hides behind
+    // the load + ranking phase instead of standing between two barriers of the workgroup's critical path
+    constexpr int BPT_PRE = BINS / RS_THREADS;
+    uint32_t pre_pf[BPT_PRE], pre_gt[BPT_PRE], pre_hb[BPT_PRE];
+#pragma unroll
+    for (int k = 0; k < BPT_PRE; k++) {
+        const int d = tid * BPT_PRE + k;
+        const bool live = d < nbins;
+        if (MODE == 2) {
+            pre_pf[k] = live ? hist[(size_t)d * nblocks + tb.fb_first] : 0u;
+            pre_gt[k] = live ? hist[(size_t)d * nblocks + tb.fb_next] : 0u;
+        } else {
+            pre_pf[k] = 0u;
+            pre_gt[k] = live ? hist[(size_t)BINS * nblocks + d] : 0u;
+        }
+        pre_hb[k] = live ? hist[(size_t)d * nblocks + blockIdx.x] : 0u;
+    }
     uint32_t key[ITEMS], val[ITEMS], pos[ITEMS], rct[MODE == 3 ? ITEMS : 1];
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
@@ -397,14 +415,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 #pragma unroll
             for (int w = 0; w < 4; w++) c[k][w] = live ? wave_cnt[w][d] : 0u;
             tot[k] = c[k][0] + c[k][1] + c[k][2] + c[k][3];
+            static_assert(BPT == BPT_PRE, "the prefetched histogram words follow the digit ownership of this phase");
             if (MODE == 2) {
                 // items of this digit inside the bucket = difference of the row's exclusive prefix at the bucket's first block and
                 // at the next bucket's first block (blocks past the table hold zero counts, so the prefix there is the row total)
-                pf[k] = live ? hist[(size_t)d * nblocks + tb.fb_first] : 0u;
-                gtot[k] = live ? hist[(size_t)d * nblocks + tb.fb_next] - pf[k] : 0u;
+                pf[k] = pre_pf[k];
+                gtot[k] = live ? pre_gt[k] - pf[k] : 0u;
             } else {
                 pf[k] = 0u;
-                gtot[k] = live ? hist[(size_t)BINS * nblocks + d] : 0u;
+                gtot[k] = pre_gt[k];
             }
             tsum += tot[k]; gsum += gtot[k];
         }
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
             const int d = tid * BPT + k;
             if (d < nbins) {
                 local_start[d] = ls;
-                global_base[d] = gb + hist[(size_t)d * nblocks + blockIdx.x] - pf[k];
+                global_base[d] = gb + pre_hb[k] - pf[k];
                 // tile (bucket, d) occupies [gb, gb + gtot): identifyTileRanges (CR/rasterizer_impl.cu:118-140) without reading the keys
                 if (MODE == 2 && blockIdx.x == tb.fb_first && gtot[k] != 0u) {
                     const uint32_t e = gb + gtot[k];
