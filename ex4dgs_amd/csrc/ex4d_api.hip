@@ -403,6 +403,7 @@ static int forward_impl(
     // tile lists by the row-segment sort (round 6): it reads the rects in depth order and nothing else -- no instance offsets
     const bool rows_sort = g_tile_rows.load(std::memory_order_relaxed) != 0 && ex4d_tile_sort_rows_applies(P, gx, gy);
     const bool fused_scan = msd_mode == 2 && !rows_sort;
+    const bool lsd_gather = !msd_depth && rows_sort && packed_rects;      // LSD depth sort in front of the row-segment sort: its last pass hands over the rects
     if (msd_depth) {
         STAGE(ex4d_depth_sort_msd(g.sort_keys_a, g.sort_vals_a, g.rects4, g.sort_keys_b, g.depth_order, g.rects4_b, (uint32_t)P, key_invisible,
                                   g.total, g.key_ranges, g.sort_hist, g.bucket_starts, (uint32_t)g_depth_local_cap.load(std::memory_order_relaxed), stream,
@@ -417,15 +418,20 @@ static int forward_impl(
     } else {
         bool in_first = true;
         // (the ids the sort starts from are 0 .. P-1: its first pass generates them instead of reading an array the per-Gaussian kernel would have to write)
-        STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream, nullptr, true), prm, stream);
+        // round 6, in front of the row-segment tile sort: the sort's last pass gathers the packed rects into depth order and clears the tile
+        // ranges itself -- no gathering scan kernel (21 us at 1.0 M Gaussians) behind the LSD sort: scenes with a depth wall, calls in a graph
+        STAGE(ex4d_radix_sort_pairs(keys0, vals0, keys1, vals1, (uint32_t)P, key_bits, g.sort_hist, &in_first, stream, nullptr, true,
+                                    lsd_gather ? g.rects4 : nullptr, lsd_gather ? g.rects4_b : nullptr, lsd_gather ? im.ranges : nullptr, T), prm, stream);
         if (in_first == start_in_b) return fail(EX4D_ERR_HIP, "internal: depth sort ended in the wrong buffer");
         MARK(0, "depth_sort");
-        // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)
-        STAGE(ex4d_launch_scan_tiles(P, g.rects, packed_rects ? g.rects4 : nullptr, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
-        MARK(0, "scan_tiles");
+        if (!lsd_gather) {
+            // 3. instance offsets in depth order + total (the total also lands in g.total[0]: device-side instance count)
+            STAGE(ex4d_launch_scan_tiles(P, g.rects, packed_rects ? g.rects4 : nullptr, g.depth_order, g.sorted_rects, g.sorted_offsets, g.scan_block_sums, T, im.ranges, g.total, stream), prm, stream);
+            MARK(0, "scan_tiles");
+        }
     }
-    const uint2 *dup_rects = msd_depth ? nullptr : g.sorted_rects;
-    const uint32_t *dup_rects4 = msd_depth ? g.rects4_b : nullptr;
+    const uint2 *dup_rects = (msd_depth || lsd_gather) ? nullptr : g.sorted_rects;
+    const uint32_t *dup_rects4 = (msd_depth || lsd_gather) ? g.rects4_b : nullptr;
     uint32_t R = 0;                      // instance count (synchronous) or capacity (asynchronous): sizes the binning buffer and the grids
     uint32_t segment_sum = 0;            // tile-row segments of the frame (synchronous forward; asynchronous: bounded by the capacity)
     const uint32_t *n_dev = nullptr;     // asynchronous: the kernels read the actual count here
@@ -435,7 +441,7 @@ static int forward_impl(
         // (hipMemcpyDefault: the status may live in pinned host memory or -- e.g. for calls recorded into a graph -- in device memory)
         // (fused scan: the instance count is written by the duplication kernel -- the copy follows it, below)
         // (row-segment sort behind the MSD depth sort: its first kernel sums the instance count -- the copy follows it, below)
-        const bool count_later = fused_scan || (rows_sort && msd_depth);
+        const bool count_later = fused_scan || (rows_sort && msd_depth) || lsd_gather;
         if (!count_later) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         R = (uint32_t)prm->instance_capacity;
         segment_sum = 0;          // (not known on the host: the row partition picks its segment stage from the capacity -- round 6: passing the capacity
@@ -486,9 +492,9 @@ static int forward_impl(
         if (R > 0) {
             STAGE(ex4d_tile_sort_rows(P, gx, gy, g.depth_order, dup_rects4, dup_rects, b.keys_tmp, b.point_list,
                                       g_tile_ids.load(std::memory_order_relaxed) ? b.tile_ids : nullptr, R, segment_sum, g.row_hist, b.sort_hist, im.ranges,
-                                      (async && msd_depth) ? g.total : nullptr, stream), prm, stream);
+                                      (async && (msd_depth || lsd_gather)) ? g.total : nullptr, stream), prm, stream);
         }
-        if (async && msd_depth) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
+        if (async && (msd_depth || lsd_gather)) HIP_TRY(hipMemcpyAsync(num_rendered, g.total, sizeof(Ex4dFrameStatus), hipMemcpyDefault, stream));
         MARK(0, "tile_sort");
     } else if (R > 0 && ex4d_tile_sort_msd_applies(P, tile_bits(T))) {
         // MSD-first sort on packed words; the tile ranges fall out of its second pass (ex4d_binning.hip: ex4d_tile_sort_msd).

@@ -280,6 +280,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
     // has bucket = tile row, digit = tile column: the image's tiles per row); out_cap = capacity of the packed / output arrays (an
     // asynchronous frame whose instance count exceeds it is re-run by the caller: nothing may be touched behind it)
     if (n_dev) { const uint32_t nd = *n_dev; n = nd < n ? nd : n; }      // (see rs_histogram_kernel)
+    // MODE 0, last pass of the LSD depth sort in front of the row-segment tile sort (round 6): the zero-fill of the tile ranges rides along
+    // (range_stride = number of tiles), and the write-out below gathers every item's packed rect by its value (rects_in -> rects_out)
+    if (MODE == 0 && ranges) for (uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x; i < range_stride; i += gridDim.x * RS_THREADS) ranges[i] = make_uint2(0u, 0u);
     if (MODE != 2 && blockIdx.x * (uint32_t)(RS_THREADS * ITEMS) >= n) return;      // behind the last item (uniform: the whole workgroup)
     __shared__ uint32_t wave_cnt[4][BINS];        // per-wave digit counts -> exclusive block-local offsets
     __shared__ uint32_t local_start[BINS];        // first block-local slot of each digit
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
         if constexpr (MODE == 2) kv = make_uint2(stage_w[p], 0u); else kv = stage[p];
         const uint32_t d = digit_of(kv.x);
         const uint32_t dst = global_base[d] + (p - local_start[d]);
-        if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; }
+        if (MODE == 0) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; if (rects_in) rects_out[dst] = rects_in[kv.y]; }
         if constexpr (MODE == 3) { keys_out[dst] = kv.x; vals_out[dst] = kv.y; rects_out[dst] = stage_r[p]; }
         if (MODE == 1) keys_out[dst] = ((kv.x & ((1u << low_bits) - 1u)) << (32 - low_bits)) | kv.y;
         if (MODE == 2 && dst < out_cap) {
@@ -1088,8 +1091,11 @@ size_t ex4d_radix_hist_words(uint32_t n) { return (size_t)1024 * rs_blocks_for(n
 int ex4d_radix_passes(uint32_t n, int end_bit) { const int mb = rs_max_bits_for(n); return (end_bit + mb - 1) / mb; }
 
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev, bool iota_values)
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev, bool iota_values,
+    const uint32_t *gather_in, uint32_t *gather_out, uint2 *zero_ranges, int num_ranges)
 {
+    // gather_in / gather_out (optional): the LAST pass also writes gather_out[sorted position] = gather_in[value] (the packed tile rects in
+    // depth order for the row-segment tile sort: no gathering scan kernel behind the sort); zero_ranges: cleared by that pass
     *result_in_a = true;
     if (n == 0) return hipSuccess;
     const uint32_t nb = rs_blocks_for(n);
@@ -1104,13 +1110,17 @@ hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *k
         if (small) {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_SMALL_ITEMS, 512, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist, n_dev);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 512u);
-#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr, n_dev)
+            const bool last = pass == npass - 1;
+#define RS_SMALL_SCATTER(NB) hipLaunchKernelGGL((rs_scatter_kernel<RS_SMALL_ITEMS, 512, 0, NB>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, \
+                last ? zero_ranges : (uint2 *)nullptr, n_dev, last ? gather_in : (const uint32_t *)nullptr, last ? gather_out : (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t)num_ranges)
             if (nbits == 9) RS_SMALL_SCATTER(9); else if (nbits == 8) RS_SMALL_SCATTER(8); else RS_SMALL_SCATTER(0);
 #undef RS_SMALL_SCATTER
         } else {
             hipLaunchKernelGGL((rs_histogram_kernel<RS_ITEMS, 256, 1>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, n, shift, mask, nb, hist, n_dev);
             hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1u << nbits), dim3(256), 0, stream, nb, hist, 256u);
-            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0, nullptr, n_dev);
+            const bool last = pass == npass - 1;
+            hipLaunchKernelGGL((rs_scatter_kernel<RS_ITEMS, 256, 0, 0>), dim3(nb), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift, nbits, nb, hist, 0, nullptr, 0,
+                last ? zero_ranges : (uint2 *)nullptr, n_dev, last ? gather_in : (const uint32_t *)nullptr, last ? gather_out : (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t)num_ranges);
         }
         uint32_t *t = kin; kin = kout; kout = t;
         t = (pass == 0) ? vnext : vin; vin = vout; vout = t;

@@ -104,7 +104,8 @@ hipError_t ex4d_launch_preprocess_bwd(const Ex4dParams &prm, const float *means3
 // (keys_out, vals_out) which must be one of the two ping-pong pairs; returns which through *result_in_a.
 // n_dev (optional): the item count in device memory, n then is the capacity the grids are sized for (asynchronous forward)
 hipError_t ex4d_radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev = nullptr, bool iota_values = false);      // iota_values: the input values are 0 .. n-1 (vals_a is not read by the first pass)
+    uint32_t n, int end_bit, uint32_t *hist, bool *result_in_a, hipStream_t stream, const uint32_t *n_dev = nullptr, bool iota_values = false,
+    const uint32_t *gather_in = nullptr, uint32_t *gather_out = nullptr, uint2 *zero_ranges = nullptr, int num_ranges = 0);      // last pass: gather_out[position] = gather_in[value]; zero_ranges[0 .. num_ranges) cleared      // iota_values: the input values are 0 .. n-1 (vals_a is not read by the first pass)
 size_t ex4d_radix_hist_words(uint32_t n);
 int ex4d_radix_passes(uint32_t n, int end_bit);      // number of passes ex4d_radix_sort_pairs will run (decides where the result lands)
 
